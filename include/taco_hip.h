@@ -1,0 +1,136 @@
+/* taco_hip.h -- C ABI of libtaco_hip.so, the MI355X (gfx950) implementation of the Tacotron acoustic-model
+ * hot path of barronalex/Tacotron (models/tacotron.py + models/ops.py).
+ *
+ * The reference has NO FFI / plugin boundary (it is a pure-Python TF-1.2 graph), so every entry
+ * point below cites the reference function whose arithmetic it replaces.  Conventions:
+ *   - every function returns int: 0 = ok, negative = TACO_E* (never throws, never exits);
+ *     taco_last_error_string() describes the last failure on the calling thread;
+ *   - all pointers except `shape`/tables are DEVICE pointers, contiguous row-major, fp32 unless stated;
+ *   - one call = stream-ordered enqueues on `stream` (a hipStream_t passed as void*); no allocation, no
+ *     host synchronisation, no ownership transfer.  The caller supplies parameters, inputs, outputs and a
+ *     workspace of taco_workspace_bytes() bytes;
+ *   - tensors are batch-major (B, T, C); weights use the reference's TF variable layouts
+ *     (dense kernel (in,out); conv1d kernel (k,Cin,Cout); GRUCell gates kernel (Cin+H,2H) r-then-u ...).
+ */
+#ifndef TACO_HIP_H
+#define TACO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#pragma GCC visibility push(default)
+
+#define TACO_VERSION 100
+
+#define TACO_OK 0
+#define TACO_EINVAL (-1)   /* bad argument / unsupported shape   */
+#define TACO_ELAUNCH (-2)  /* HIP launch or runtime error        */
+#define TACO_ENOTFOUND (-3)
+
+/* activation codes for taco_conv_gemm */
+#define TACO_ACT_NONE 0
+#define TACO_ACT_RELU 1
+#define TACO_ACT_SIGMOID 2
+#define TACO_ACT_TANH 3
+
+/* Problem shape.  Model widths (embed 256, prenet 256/128, CBHG 128, attention/decoder 256, 80 mels, 1025 bins,
+ * K=16/8 conv banks) are the reference's Config constants (tacotron.py:12-33, 131, 147) and are compiled in. */
+typedef struct TacoShape {
+  int32_t B;   /* batch (Config.batch_size = 32)                                    */
+  int32_t Tt;  /* padded text length                                               */
+  int32_t Td;  /* decoder steps = Config.max_decode_iter (tacotron.py:13)          */
+  int32_t r;   /* mel frames per decoder step (audio.r, audio.py:15-17)            */
+  int32_t V;   /* vocab_size (train.py:22)                                         */
+} TacoShape;
+
+/* One row of the parameter / workspace tables. */
+typedef struct TacoTensorInfo {
+  char name[64];
+  int64_t offset; /* in floats from the base pointer */
+  int64_t size;   /* in floats                      */
+  int32_t ndim;
+  int32_t dims[4];
+} TacoTensorInfo;
+
+int taco_version(void);
+const char* taco_last_error_string(void);
+
+/* ---- parameter layout: one flat fp32 buffer, TF variable order (tacotron.py:107-154 graph order) ---------- */
+int64_t taco_param_count(const TacoShape* shape);
+/* Fills up to `cap` rows; returns the number of tensors (or negative error). */
+int taco_param_table(const TacoShape* shape, TacoTensorInfo* rows, int cap);
+
+/* ---- workspace ------------------------------------------------------------------------------------------ */
+/* Bytes needed by taco_forward / taco_backward / taco_infer for `shape` (train != 0 includes backward stashes). */
+int64_t taco_workspace_bytes(const TacoShape* shape, int train);
+/* Named intermediate tensors inside the workspace (for parity tests / debugging). */
+int taco_workspace_table(const TacoShape* shape, int train, TacoTensorInfo* rows, int cap);
+
+/* ---- op level ------------------------------------------------------------------------------------------- */
+/* C[m, n] = post( act( sum_{tap<taps} sum_{k<K} A[row(m,tap), k] * W[tap][k][n] + bias[n] ) )
+ *   row(m,tap): m = b*T + t  ->  t' = t + tap - pad_l ; zero row unless 0 <= t' < T   ('same' conv1d, ops.py:54-60;
+ *   taps = 1, pad_l = 0 is tf.layers.dense, tacotron.py:40-43).
+ *   post(y) = (keep ? y * keep[m,n] * 2 : y) * scale[n] + shift[n] + residual[m,n]   (each optional / nullable)
+ *   Cpre (nullable) receives the value before scale/shift/residual.  W tap stride is K*ldw floats. */
+int taco_conv_gemm(const float* A, int lda, const float* W, int ldw, const float* bias, const float* scale,
+                   const float* shift, const float* residual, int ldr, const uint8_t* keep, float* C, int ldc,
+                   float* Cpre, int M, int N, int K, int taps, int T, int pad_l, int act, void* stream);
+
+/* dW[tap][k][n] (+)= sum_m A[row(m,tap), k] * dY[m, n]   (weight gradient of the op above; accumulate != 0 adds) */
+int taco_gemm_tn(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, int M, int N, int K, int taps,
+                 int T, int pad_l, int accumulate, void* stream);
+
+/* Reference GEMM on scalar FMAs (debug aid for the MFMA kernels; same contract as taco_conv_gemm without post). */
+int taco_debug_gemm_naive(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc,
+                          int M, int N, int K, int taps, int T, int pad_l, int act, void* stream);
+
+/* Bidirectional GRU(128) over the full padded length (ops.py:117-128; tf.nn.bidirectional_dynamic_rnn without
+ * sequence_length).  x (B,T,128); weights in TF GRUCell layout: wg (256,256), bg (256), wc (256,128), bc (128) per
+ * direction.  out (B,T,256) = concat(fw,bw).  ruc (B,T,768) receives r,u,c for both directions (nullable).
+ * xg (B,T,768) is scratch for the hoisted input projections. */
+int taco_bigru_fwd(const float* x, const float* wg_fw, const float* bg_fw, const float* wc_fw, const float* bc_fw,
+                   const float* wg_bw, const float* bg_bw, const float* wc_bw, const float* bc_bw, float* xg,
+                   float* out, float* ruc, int B, int T, void* stream);
+
+/* ---- model level ---------------------------------------------------------------------------------------- */
+/* Tacotron.inference with train=True (tacotron.py:107-154) + add_loss_op (tacotron.py:156-165).
+ *   text (B,Tt) int32; text_length (B) int32; mel (B,Td,80r); stft (B,Td,1025r);
+ *   masks (uint8 0/1, nullable = no dropout / no sampling):
+ *     enc_keep1 (B,Tt,256), enc_keep2 (B,Tt,128)  encoder pre_net dropout keep masks (tacotron.py:128)
+ *     dec_keep1 (B,Td,256), dec_keep2 (B,Td,128)  decoder pre_net dropout keep masks (tacotron.py:64-71)
+ *     sample (Td,B): 1 => step t+1 of row b is fed cell_output[t] (ScheduledOutputTrainingHelper, tacotron.py:84-85)
+ *   outputs: seq2seq_output (B,Td,80r), output (B,Td,1025r), alignments (B,Td,Tt), loss[3] = {total, seq2seq, output}. */
+int taco_forward(const TacoShape* shape, const float* params, const int32_t* text, const int32_t* text_length,
+                 const float* mel, const float* stft, const uint8_t* enc_keep1, const uint8_t* enc_keep2,
+                 const uint8_t* dec_keep1, const uint8_t* dec_keep2, const uint8_t* sample, float* seq2seq_output,
+                 float* output, float* alignments, float* loss, void* workspace, void* stream);
+
+/* Gradient of loss w.r.t. every parameter (opt.compute_gradients, tacotron.py:172), after taco_forward on the same
+ * workspace with the same inputs / masks.  seq2seq_output and alignments are the tensors taco_forward produced.
+ * grads has taco_param_count floats and is overwritten. */
+int taco_backward(const TacoShape* shape, const float* params, const int32_t* text, const int32_t* text_length,
+                  const float* seq2seq_output, const float* alignments, const uint8_t* enc_keep1,
+                  const uint8_t* enc_keep2, const uint8_t* dec_keep1, const uint8_t* dec_keep2, const uint8_t* sample,
+                  float* grads, void* workspace, void* stream);
+
+/* Tacotron.inference with train=False (test.py:29, ops.InferenceHelper ops.py:5-25): zeros first frame, feeds back
+ * its own output, always Td steps, no dropout.  mel/stft/loss absent. */
+int taco_infer(const TacoShape* shape, const float* params, const int32_t* text, const int32_t* text_length,
+               float* seq2seq_output, float* output, float* alignments, void* workspace, void* stream);
+
+/* add_train_op (tacotron.py:167-185): global-norm clip (cap_grads) then TF-form Adam, in place.
+ *   step = global_step after this update (1-based).  scratch: >= 8 floats.  gnorm_out[1] receives ||g||. */
+int taco_clip_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float cap,
+                        int64_t step, float* scratch, float* gnorm_out, void* stream);
+
+/* Bernoulli(p_keep) bytes from a counter-based hash RNG (replaces TF's dropout / Bernoulli sampler state). */
+int taco_fill_bernoulli(uint8_t* out, int64_t n, float p_one, uint64_t seed, void* stream);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif /* TACO_HIP_H */

@@ -1,0 +1,189 @@
+"""Second, independently written CPU restatement of the reference model, on torch-CPU primitives with
+autograd -- TEST INFRASTRUCTURE ONLY (gradient oracle + `cpu_baseline` timing leg of bench.py).
+
+PARITY UNPINNED (see oracle/taco_numpy.py header): TensorFlow 1.2 cannot run here.  This file exists so
+that two implementations written against different primitives (NumPy shifted-matmul convs / manual
+softmax there; F.conv1d / F.max_pool1d / torch.softmax / torch.bmm + autograd here) must agree before
+either is used to judge the HIP path.
+
+Follows /root/reference/models/tacotron.py:35-195 and /root/reference/models/ops.py:5-132; parameter
+names/layouts are those of oracle/taco_numpy.py::param_spec (TF variable layouts).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-3
+
+
+def _conv_same(x, kernel, bias):
+    # x (B,T,Cin); kernel TF layout (k,Cin,Cout) -> torch (Cout,Cin,k).  ops.py:54-60
+    k = kernel.shape[0]
+    pl = (k - 1) // 2
+    pr = k - 1 - pl
+    xt = F.pad(x.transpose(1, 2), (pl, pr))
+    y = F.conv1d(xt, kernel.permute(2, 1, 0), bias)
+    return y.transpose(1, 2)
+
+
+def _bn(x, gamma, beta):
+    # ops.py:64,87 -- inference-mode BN with moving mean 0 / var 1
+    return x * (gamma * (1.0 / math.sqrt(1.0 + BN_EPS))) + beta
+
+
+def _maxpool(x):
+    # ops.py:66-71 -- pool 2, stride 1, SAME (pad after with -inf)
+    xt = F.pad(x.transpose(1, 2), (0, 1), value=float('-inf'))
+    return F.max_pool1d(xt, 2, 1).transpose(1, 2)
+
+
+def _gru(x, h, wg, bg, wc, bc):
+    H = h.shape[-1]
+    g = torch.sigmoid(torch.addmm(bg, torch.cat([x, h], 1), wg))
+    r, u = g.split(H, 1)
+    c = torch.tanh(torch.addmm(bc, torch.cat([x, r * h], 1), wc))
+    return u * h + (1 - u) * c
+
+
+def _bigru(x, p, prefix):
+    B, T, _ = x.shape
+    H = p[prefix + 'fw/gates/bias'].shape[0] // 2
+    outs = []
+    for name, order in (('fw', range(T)), ('bw', range(T - 1, -1, -1))):
+        wg, bg = p[prefix + name + '/gates/kernel'], p[prefix + name + '/gates/bias']
+        wc, bc = p[prefix + name + '/candidate/kernel'], p[prefix + name + '/candidate/bias']
+        h = x.new_zeros(B, H)
+        seq = [None] * T
+        for t in order:
+            h = _gru(x[:, t], h, wg, bg, wc, bc)
+            seq[t] = h
+        outs.append(torch.stack(seq, 1))
+    return torch.cat(outs, 2)
+
+
+def _highway(x, p, prefix):
+    if (prefix + 'adapt/kernel') in p:
+        x = F.linear(x, p[prefix + 'adapt/kernel'].t(), p[prefix + 'adapt/bias'])
+    t = torch.sigmoid(F.linear(x, p[prefix + 'T/kernel'].t(), p[prefix + 'T/bias']))
+    h = torch.relu(F.linear(x, p[prefix + 'H/kernel'].t(), p[prefix + 'H/bias']))
+    return h * t + x * (1 - t)
+
+
+def cbhg(x, p, prefix, K):
+    bank = torch.cat([torch.relu(_conv_same(x, p[prefix + 'bank_%d/kernel' % k], p[prefix + 'bank_%d/bias' % k]))
+                      for k in range(1, K + 1)], 2)
+    y = _maxpool(_bn(bank, p[prefix + 'bank_bn/gamma'], p[prefix + 'bank_bn/beta']))
+    y = torch.relu(_conv_same(y, p[prefix + 'proj1/kernel'], p[prefix + 'proj1/bias']))
+    y = _bn(y, p[prefix + 'proj1_bn/gamma'], p[prefix + 'proj1_bn/beta'])
+    y = _conv_same(y, p[prefix + 'proj2/kernel'], p[prefix + 'proj2/bias'])
+    y = _bn(y, p[prefix + 'proj2_bn/gamma'], p[prefix + 'proj2_bn/beta'])
+    h = y + x
+    for l in range(4):
+        h = _highway(h, p, prefix + 'highway_%d/' % l)
+    return _bigru(h, p, prefix + 'bigru/')
+
+
+def _prenet(x, p, prefix, k1, k2):
+    l1 = torch.relu(F.linear(x, p[prefix + 'dense/kernel'].t(), p[prefix + 'dense/bias']))
+    if k1 is not None:
+        l1 = l1 * (2.0 * k1)
+    l2 = torch.relu(F.linear(l1, p[prefix + 'dense_1/kernel'].t(), p[prefix + 'dense_1/bias']))
+    if k2 is not None:
+        l2 = l2 * (2.0 * k2)
+    return l2
+
+
+def forward(p, inputs, r, n_steps, train, masks=None):
+    """p: dict name->tensor; inputs: dict of tensors (text int64, text_length int64, mel, stft);
+    masks: dict of float tensors (0/1).  Returns (seq2seq_output, output, alignments, encoded)."""
+    masks = masks or {}
+    g = (lambda k: masks.get(k)) if train else (lambda k: None)
+    text = inputs['text']
+    B, Tt = text.shape
+    emb = F.embedding(text, p['embedding'])
+    enc = cbhg(_prenet(emb, p, 'encoder/pre_net/', g('enc_keep1'), g('enc_keep2')), p, 'encoder/cbhg/', 16)
+
+    # attention memory (tacotron.py:48-52)
+    valid = torch.arange(Tt)[None, :] < inputs['text_length'][:, None]
+    values = enc * valid[:, :, None].to(enc.dtype)
+    keys = torch.matmul(values, p['decoder/memory_layer/kernel'])
+    v = p['decoder/attention_v']
+
+    nmel = 80
+    h = [enc.new_zeros(B, 256) for _ in range(3)]
+    att = enc.new_zeros(B, 256)
+    mel = inputs.get('mel') if train else None
+    prev = mel[:, 0] if mel is not None else enc.new_zeros(B, nmel * r)
+    outs, aligns = [], []
+    dk1, dk2, smp = g('dec_keep1'), g('dec_keep2'), g('sample')
+    for t in range(n_steps):
+        pn = _prenet(prev[:, nmel * (r - 1):], p, 'decoder/pre_net/',
+                     dk1[:, t] if dk1 is not None else None, dk2[:, t] if dk2 is not None else None)
+        x = F.linear(torch.cat([pn, att], 1), p['decoder/in_proj/kernel'].t(), p['decoder/in_proj/bias'])
+        inp = x
+        for l in range(3):
+            h[l] = _gru(inp, h[l], p['decoder/gru_%d/gates/kernel' % l], p['decoder/gru_%d/gates/bias' % l],
+                        p['decoder/gru_%d/candidate/kernel' % l], p['decoder/gru_%d/candidate/bias' % l])
+            inp = h[l]
+        o = F.linear(x + h[2], p['decoder/out_proj/kernel'].t(), p['decoder/out_proj/bias'])
+        q = torch.mm(o, p['decoder/query_layer/kernel'])
+        score = torch.tanh(keys + q[:, None, :]).matmul(v)
+        score = score.masked_fill(~valid, float('-inf'))
+        a = torch.softmax(score, 1)
+        ctx = torch.bmm(a[:, None, :], values)[:, 0]
+        att = torch.mm(torch.cat([o, ctx], 1), p['decoder/attention_layer/kernel'])
+        outs.append(o)
+        aligns.append(a)
+        if mel is None:
+            prev = o
+        elif t + 1 < n_steps:
+            prev = mel[:, t + 1]
+            if smp is not None:
+                prev = torch.where(smp[t][:, None] > 0.5, o, prev)
+    s2s = torch.stack(outs, 1)
+    al = torch.stack(aligns, 1)
+    post = cbhg(s2s.reshape(B, n_steps * r, nmel), p, 'post/cbhg/', 8)
+    out = F.linear(post, p['post/dense/kernel'].t(), p['post/dense/bias']).reshape(B, n_steps, -1)
+    return s2s, out, al, enc
+
+
+def loss_fn(s2s, out, mel, stft):
+    return (s2s - mel).abs().sum() + (out - stft).abs().sum()
+
+
+def to_torch(pnp, dtype=torch.float64, requires_grad=False):
+    return {k: torch.tensor(v, dtype=dtype, requires_grad=requires_grad) for k, v in pnp.items()}
+
+
+def loss_and_grads(pnp, inputs_np, r, n_steps, masks_np=None, dtype=torch.float64):
+    """Convenience: numpy in, numpy out.  Returns (loss, s2s, out, align, grads dict)."""
+    p = to_torch(pnp, dtype, True)
+    inputs = {
+        'text': torch.tensor(inputs_np['text'], dtype=torch.int64),
+        'text_length': torch.tensor(inputs_np['text_length'], dtype=torch.int64),
+        'mel': torch.tensor(inputs_np['mel'], dtype=dtype),
+        'stft': torch.tensor(inputs_np['stft'], dtype=dtype),
+    }
+    masks = {k: torch.tensor(v, dtype=dtype) for k, v in (masks_np or {}).items()}
+    s2s, out, al, _ = forward(p, inputs, r, n_steps, True, masks)
+    loss = loss_fn(s2s, out, inputs['mel'], inputs['stft'])
+    loss.backward()
+    grads = {k: (t.grad.numpy() if t.grad is not None else None) for k, t in p.items()}
+    return float(loss), s2s.detach().numpy(), out.detach().numpy(), al.detach().numpy(), grads
+
+
+def clip_adam_step(params, grads, m, v, step, lr, cap=5.0, b1=0.9, b2=0.999, eps=1e-8):
+    """tacotron.py:167-185 on torch tensors (in place).  Returns global norm."""
+    with torch.no_grad():
+        gn = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).item()
+        scale = cap / max(gn, cap) if cap > 0 else 1.0
+        lr_t = lr * math.sqrt(1 - b2 ** step) / (1 - b1 ** step)
+        for k in params:
+            g = grads[k] * scale
+            m[k].mul_(b1).add_(g, alpha=1 - b1)
+            v[k].mul_(b2).addcmul_(g, g, value=1 - b2)
+            params[k].sub_(lr_t * m[k] / (v[k].sqrt() + eps))
+    return gn

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Builds libtaco_hip.so for gfx950 in-tree (tacotron_amd/libtaco_hip.so).  hipcc cross-compiles without a GPU.
+set -euo pipefail
+cd "$(dirname "$0")"
+OUT=../libtaco_hip.so
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -fPIC -fvisibility=hidden"
+mkdir -p ../../build/obj
+pids=()
+for f in gemm elementwise bigru decoder layout model; do
+  hipcc $FLAGS -c $f.hip -o ../../build/obj/$f.o &
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT ../../build/obj/{gemm,elementwise,bigru,decoder,layout,model}.o
+echo "built $(realpath $OUT)"

@@ -1,0 +1,77 @@
+// common.h -- shared host/device helpers for libtaco_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/taco_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- host-side error plumbing -----------------------------------------------------------------------------
+void taco_set_error(const char* fmt, ...);
+
+#define TACO_REQUIRE(cond, ...)        \
+  do {                                 \
+    if (!(cond)) {                     \
+      taco_set_error(__VA_ARGS__);     \
+      return TACO_EINVAL;              \
+    }                                  \
+  } while (0)
+
+#define TACO_LAUNCH_CHECK(what)                                             \
+  do {                                                                      \
+    hipError_t e__ = hipGetLastError();                                     \
+    if (e__ != hipSuccess) {                                                \
+      taco_set_error("%s: %s", what, hipGetErrorString(e__));               \
+      return TACO_ELAUNCH;                                                  \
+    }                                                                       \
+  } while (0)
+
+#define TACO_TRY(expr)          \
+  do {                          \
+    int rc__ = (expr);          \
+    if (rc__ != TACO_OK) return rc__; \
+  } while (0)
+
+// Model constants (reference Config, tacotron.py:12-33; CBHG widths ops.py:48-49, tacotron.py:131,147).
+constexpr int kEmbed = 256;
+constexpr int kPre1 = 256;
+constexpr int kPre2 = 128;
+constexpr int kCb = 128;    // CBHG channel width / GRU units
+constexpr int kAtt = 256;   // attention_units
+constexpr int kDec = 256;   // decoder_units
+constexpr int kMel = 80;
+constexpr int kFft = 1025;
+constexpr float kBnEps = 1e-3f;
+
+// ---- device math ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float tanh_f(float x) {
+  // 2/(1+e^-2x) - 1 : absolute error ~1e-7, saturates cleanly (e^-2x -> inf gives -1, -> 0 gives 1).
+  return 2.0f / (1.0f + expf(-2.0f * x)) - 1.0f;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float apply_act(float x, int act) {
+  switch (act) {
+    case TACO_ACT_RELU: return fmaxf(x, 0.0f);
+    case TACO_ACT_SIGMOID: return sigmoid_f(x);
+    case TACO_ACT_TANH: return tanh_f(x);
+    default: return x;
+  }
+}
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,457 @@
+// elementwise.hip -- HBM-bound glue kernels of the Tacotron hot path: embedding gather/scatter (tacotron.py:111-114),
+// BN-affine + max-pool (ops.py:64-71), highway blend (ops.py:46), activation/dropout derivatives, column reductions
+// for bias / BN gradients, L1 loss + sign gradient (tacotron.py:158-160), weight transposes for the backward GEMMs,
+// global-norm clip + TF-form Adam (tacotron.py:167-185) and the Bernoulli mask generator.
+// All are float4-vectorised where the layout allows, grid-stride, one pass over their tensors.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+inline int grid_for(int64_t n_items, int per_block = kThreads, int cap = 4096) {
+  int64_t g = (n_items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red /* >= 4 floats LDS */) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  const int nw = (blockDim.x + 63) >> 6;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+
+__global__ void embedding_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids,
+                                 float* __restrict__ out, int64_t rows, int V) {
+  const int64_t total = rows * (kEmbed / 4);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / (kEmbed / 4);
+    const int c4 = (int)(i % (kEmbed / 4));
+    int id = ids[row];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(table + (int64_t)id * kEmbed)[c4];
+  }
+}
+
+__global__ void embedding_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ ids,
+                                     float* __restrict__ dtable, int64_t rows, int V) {
+  const int64_t total = rows * kEmbed;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / kEmbed;
+    const int c = (int)(i % kEmbed);
+    int id = ids[row];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    atomicAdd(&dtable[(int64_t)id * kEmbed + c], dout[i]);
+  }
+}
+
+__global__ void bn_maxpool_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                  const float* __restrict__ beta, float* __restrict__ y, int B, int T, int C) {
+  const int C4 = C / 4;
+  const int64_t total = (int64_t)B * T * C4;
+  const float rs = 1.0f / sqrtf(1.0f + kBnEps);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const int64_t row = i / C4;
+    const int t = (int)(row % T);
+    const float4 g = reinterpret_cast<const float4*>(gamma)[c4];
+    const float4 b = reinterpret_cast<const float4*>(beta)[c4];
+    const float4 a = reinterpret_cast<const float4*>(x)[i];
+    float4 z = make_float4(a.x * (g.x * rs) + b.x, a.y * (g.y * rs) + b.y, a.z * (g.z * rs) + b.z, a.w * (g.w * rs) + b.w);
+    if (t + 1 < T) {
+      const float4 a2 = reinterpret_cast<const float4*>(x)[i + C4];
+      z.x = fmaxf(z.x, a2.x * (g.x * rs) + b.x);
+      z.y = fmaxf(z.y, a2.y * (g.y * rs) + b.y);
+      z.z = fmaxf(z.z, a2.z * (g.z * rs) + b.z);
+      z.w = fmaxf(z.w, a2.w * (g.w * rs) + b.w);
+    }
+    reinterpret_cast<float4*>(y)[i] = z;
+  }
+}
+
+// blockDim = (64 channels, 4 row lanes); grid = (C/64 ceil, row chunks)
+__global__ void bn_maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                      const float* __restrict__ beta, const float* __restrict__ dy,
+                                      float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                      int B, int T, int C, int rows_per_block) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  const int64_t M = (int64_t)B * T;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  const float rs = 1.0f / sqrtf(1.0f + kBnEps);
+  float ag = 0.f, ab = 0.f;
+  if (c < C) {
+    const float s = gamma[c] * rs, be = beta[c];
+    for (int64_t row = r0 + threadIdx.y; row < r1; row += 4) {
+      const int t = (int)(row % T);
+      const float xv = x[row * C + c];
+      const float z = xv * s + be;
+      float dz = 0.f;
+      if (t == T - 1) {
+        dz = dy[row * C + c];
+      } else {
+        const float zn = x[(row + 1) * C + c] * s + be;
+        if (z >= zn) dz = dy[row * C + c];
+      }
+      if (t > 0) {
+        const float zp = x[(row - 1) * C + c] * s + be;
+        if (z > zp) dz += dy[(row - 1) * C + c];
+      }
+      dx[row * C + c] = dz * s;
+      ag += dz * xv * rs;
+      ab += dz;
+    }
+  }
+  __shared__ float red[2][4][64];
+  red[0][threadIdx.y][threadIdx.x] = ag;
+  red[1][threadIdx.y][threadIdx.x] = ab;
+  __syncthreads();
+  if (threadIdx.y == 0 && c < C) {
+    float g = 0.f, b = 0.f;
+    for (int i = 0; i < 4; ++i) {
+      g += red[0][i][threadIdx.x];
+      b += red[1][i][threadIdx.x];
+    }
+    atomicAdd(&dgamma[c], g);
+    atomicAdd(&dbeta[c], b);
+  }
+}
+
+__global__ void highway_combine_kernel(const float* __restrict__ th, const float* __restrict__ x,
+                                       float* __restrict__ y, int64_t M) {
+  const int64_t total = M * (kCb / 4);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / (kCb / 4);
+    const int c4 = (int)(i % (kCb / 4));
+    const float4 t = reinterpret_cast<const float4*>(th + row * 2 * kCb)[c4];
+    const float4 h = reinterpret_cast<const float4*>(th + row * 2 * kCb + kCb)[c4];
+    const float4 xv = reinterpret_cast<const float4*>(x)[i];
+    float4 o;
+    o.x = h.x * t.x + xv.x * (1.f - t.x);
+    o.y = h.y * t.y + xv.y * (1.f - t.y);
+    o.z = h.z * t.z + xv.z * (1.f - t.z);
+    o.w = h.w * t.w + xv.w * (1.f - t.w);
+    reinterpret_cast<float4*>(y)[i] = o;
+  }
+}
+
+__global__ void highway_combine_bwd_kernel(const float* __restrict__ th, const float* __restrict__ x,
+                                           const float* __restrict__ dy, float* __restrict__ dth,
+                                           float* __restrict__ dx, int64_t M) {
+  const int64_t total = M * kCb;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / kCb;
+    const int c = (int)(i % kCb);
+    const float t = th[row * 2 * kCb + c];
+    const float h = th[row * 2 * kCb + kCb + c];
+    const float g = dy[i];
+    dth[row * 2 * kCb + c] = g * (h - x[i]) * t * (1.f - t);
+    dth[row * 2 * kCb + kCb + c] = h > 0.f ? g * t : 0.f;
+    dx[i] = g * (1.f - t);
+  }
+}
+
+__global__ void act_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                               const uint8_t* __restrict__ keep, float* __restrict__ dz, int64_t n, int act) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float yv = y[i];
+    float g = dy[i];
+    if (act == TACO_ACT_RELU) g = yv > 0.f ? g : 0.f;
+    else if (act == TACO_ACT_SIGMOID) g = g * yv * (1.f - yv);
+    else if (act == TACO_ACT_TANH) g = g * (1.f - yv * yv);
+    if (keep) g = keep[i] ? g * 2.0f : 0.f;
+    dz[i] = g;
+  }
+}
+
+// blockDim = (64 cols, 4 row lanes); grid = (N/64 ceil, row chunks)
+__global__ void affine_act_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ gamma,
+                                      const float* __restrict__ dy, float* __restrict__ dz, float* __restrict__ dgamma,
+                                      float* __restrict__ dbeta, int64_t M, int N, int act, int rows_per_block) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  const float rs = 1.0f / sqrtf(1.0f + kBnEps);
+  float ag = 0.f, ab = 0.f;
+  if (c < N) {
+    const float s = gamma[c] * rs;
+    for (int64_t row = r0 + threadIdx.y; row < r1; row += 4) {
+      const float g = dy[row * N + c];
+      const float p = pre[row * N + c];
+      ag += g * p * rs;
+      ab += g;
+      float d = g * s;
+      if (act == TACO_ACT_RELU && !(p > 0.f)) d = 0.f;
+      dz[row * N + c] = d;
+    }
+  }
+  __shared__ float red[2][4][64];
+  red[0][threadIdx.y][threadIdx.x] = ag;
+  red[1][threadIdx.y][threadIdx.x] = ab;
+  __syncthreads();
+  if (threadIdx.y == 0 && c < N) {
+    float g = 0.f, b = 0.f;
+    for (int i = 0; i < 4; ++i) {
+      g += red[0][i][threadIdx.x];
+      b += red[1][i][threadIdx.x];
+    }
+    atomicAdd(&dgamma[c], g);
+    atomicAdd(&dbeta[c], b);
+  }
+}
+
+__global__ void colsum_kernel(const float* __restrict__ x, int ld, float* __restrict__ out, int64_t M, int N,
+                              int rows_per_block) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  float a = 0.f;
+  if (c < N)
+    for (int64_t row = r0 + threadIdx.y; row < r1; row += 4) a += x[row * ld + c];
+  __shared__ float red[4][64];
+  red[threadIdx.y][threadIdx.x] = a;
+  __syncthreads();
+  if (threadIdx.y == 0 && c < N) atomicAdd(&out[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ void mask_rows_kernel(const float* __restrict__ x, const int32_t* __restrict__ len, float* __restrict__ y,
+                                 int B, int T, int C) {
+  const int C4 = C / 4;
+  const int64_t total = (int64_t)B * T * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / C4;
+    const int b = (int)(row / T), t = (int)(row % T);
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    if (t >= len[b]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    reinterpret_cast<float4*>(y)[i] = v;
+  }
+}
+
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = a[i] + b[i];
+}
+
+__global__ void l1_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ grad, int ldg,
+                          float* __restrict__ loss_slot, int64_t M, int N) {
+  __shared__ float red[8];
+  float acc = 0.f;
+  const int64_t total = M * ldg;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / ldg;
+    const int n = (int)(i % ldg);
+    float g = 0.f;
+    if (n < N) {
+      const float d = a[m * N + n] - b[m * N + n];
+      acc += fabsf(d);
+      g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    }
+    if (grad) grad[i] = g;
+  }
+  const float t = block_sum(acc, red);
+  if (threadIdx.x == 0) atomicAdd(loss_slot, t);
+}
+
+__global__ void finish_loss_kernel(float* loss) { loss[0] = loss[1] + loss[2]; }
+
+__global__ void bn_fold_kernel(const float* __restrict__ gamma, float* __restrict__ scale, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) scale[i] = gamma[i] * (1.0f / sqrtf(1.0f + kBnEps));
+}
+
+// out[tp][n][k] = in[taps-1-tp][k][n]; 32x32 tiles through LDS.  grid = (N/32, K/32, taps), block = (32, 8)
+__global__ void transpose_flip_kernel(const float* __restrict__ in, float* __restrict__ out, int taps, int K, int N) {
+  __shared__ float tile[32][33];
+  const int tp = blockIdx.z;
+  const float* src = in + (int64_t)(taps - 1 - tp) * K * N;
+  float* dst = out + (int64_t)tp * K * N;
+  const int n0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    const int k = k0 + j, n = n0 + threadIdx.x;
+    tile[j][threadIdx.x] = (k < K && n < N) ? src[(int64_t)k * N + n] : 0.f;
+  }
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    const int n = n0 + j, k = k0 + threadIdx.x;
+    if (n < N && k < K) dst[(int64_t)n * K + k] = tile[threadIdx.x][j];
+  }
+}
+
+__global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+  __shared__ float red[8];
+  float acc = 0.f;
+  const int64_t n4 = n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n - n4 * 4)) {
+    const float v = x[n4 * 4 + threadIdx.x];
+    acc += v * v;
+  }
+  const float t = block_sum(acc, red);
+  if (threadIdx.x == 0) atomicAdd(out, t);
+}
+
+__global__ void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                 float* __restrict__ v, int64_t n, float lr_t, float cap, const float* __restrict__ sumsq,
+                                 float* __restrict__ gnorm_out) {
+  const float gn = sqrtf(sumsq[0]);
+  const float scale = cap > 0.f ? cap / fmaxf(gn, cap) : 1.0f;
+  if (gnorm_out && blockIdx.x == 0 && threadIdx.x == 0) gnorm_out[0] = gn;
+  const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * scale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+__global__ void bernoulli_kernel(uint8_t* __restrict__ out, int64_t n, uint32_t thresh, uint64_t seed) {
+  // each thread produces 8 bytes from one 64-bit hash: 8-bit resolution per draw would be too coarse, so draw
+  // one hash per byte pair (2 x 32-bit lanes).
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i * 2 < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t h = splitmix64(seed * 0xD1342543DE82EF95ull + (uint64_t)i);
+    const uint32_t lo = (uint32_t)h, hi = (uint32_t)(h >> 32);
+    out[i * 2] = lo < thresh ? 1 : 0;
+    if (i * 2 + 1 < n) out[i * 2 + 1] = hi < thresh ? 1 : 0;
+  }
+}
+
+}  // namespace
+
+#define EW_LAUNCH(kernel, n_items, stream, ...)                                                        \
+  do {                                                                                                 \
+    hipLaunchKernelGGL(kernel, dim3(grid_for(n_items)), dim3(kThreads), 0, stream, __VA_ARGS__);      \
+    TACO_LAUNCH_CHECK(#kernel);                                                                        \
+  } while (0)
+
+int launch_embedding(const float* table, const int32_t* ids, float* out, int64_t rows, int V, hipStream_t s) {
+  EW_LAUNCH(embedding_kernel, rows * (kEmbed / 4), s, table, ids, out, rows, V);
+  return TACO_OK;
+}
+int launch_embedding_bwd(const float* dout, const int32_t* ids, float* dtable, int64_t rows, int V, hipStream_t s) {
+  EW_LAUNCH(embedding_bwd_kernel, rows * kEmbed, s, dout, ids, dtable, rows, V);
+  return TACO_OK;
+}
+int launch_bn_maxpool(const float* x, const float* gamma, const float* beta, float* y, int B, int T, int C, hipStream_t s) {
+  TACO_REQUIRE(C % 4 == 0, "bn_maxpool: C %% 4 != 0");
+  EW_LAUNCH(bn_maxpool_kernel, (int64_t)B * T * (C / 4), s, x, gamma, beta, y, B, T, C);
+  return TACO_OK;
+}
+static inline void col_grid(int64_t M, int N, dim3& grid, int& rpb) {
+  int chunks = (int)((M + 127) / 128);
+  if (chunks > 512) chunks = 512;
+  if (chunks < 1) chunks = 1;
+  rpb = (int)((M + chunks - 1) / chunks);
+  grid = dim3((N + 63) / 64, (unsigned)((M + rpb - 1) / rpb));
+}
+int launch_bn_maxpool_bwd(const float* x, const float* gamma, const float* beta, const float* dy, float* dx,
+                          float* dgamma, float* dbeta, int B, int T, int C, hipStream_t s) {
+  dim3 grid;
+  int rpb;
+  col_grid((int64_t)B * T, C, grid, rpb);
+  hipLaunchKernelGGL(bn_maxpool_bwd_kernel, grid, dim3(64, 4), 0, s, x, gamma, beta, dy, dx, dgamma, dbeta, B, T, C, rpb);
+  TACO_LAUNCH_CHECK("bn_maxpool_bwd");
+  return TACO_OK;
+}
+int launch_highway_combine(const float* th, const float* x, float* y, int64_t M, hipStream_t s) {
+  EW_LAUNCH(highway_combine_kernel, M * (kCb / 4), s, th, x, y, M);
+  return TACO_OK;
+}
+int launch_highway_combine_bwd(const float* th, const float* x, const float* dy, float* dth, float* dx, int64_t M,
+                               hipStream_t s) {
+  EW_LAUNCH(highway_combine_bwd_kernel, M * kCb, s, th, x, dy, dth, dx, M);
+  return TACO_OK;
+}
+int launch_act_bwd(const float* y, const float* dy, const uint8_t* keep, float* dz, int64_t n, int act, hipStream_t s) {
+  EW_LAUNCH(act_bwd_kernel, n, s, y, dy, keep, dz, n, act);
+  return TACO_OK;
+}
+int launch_affine_act_bwd(const float* pre, const float* gamma, const float* dy, float* dz, float* dgamma, float* dbeta,
+                          int64_t M, int N, int act, hipStream_t s) {
+  dim3 grid;
+  int rpb;
+  col_grid(M, N, grid, rpb);
+  hipLaunchKernelGGL(affine_act_bwd_kernel, grid, dim3(64, 4), 0, s, pre, gamma, dy, dz, dgamma, dbeta, M, N, act, rpb);
+  TACO_LAUNCH_CHECK("affine_act_bwd");
+  return TACO_OK;
+}
+int launch_colsum(const float* x, int ld, float* out, int64_t M, int N, hipStream_t s) {
+  dim3 grid;
+  int rpb;
+  col_grid(M, N, grid, rpb);
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(64, 4), 0, s, x, ld, out, M, N, rpb);
+  TACO_LAUNCH_CHECK("colsum");
+  return TACO_OK;
+}
+int launch_mask_rows(const float* x, const int32_t* len, float* y, int B, int T, int C, hipStream_t s) {
+  TACO_REQUIRE(C % 4 == 0, "mask_rows: C %% 4 != 0");
+  EW_LAUNCH(mask_rows_kernel, (int64_t)B * T * (C / 4), s, x, len, y, B, T, C);
+  return TACO_OK;
+}
+int launch_add(const float* a, const float* b, float* y, int64_t n, hipStream_t s) {
+  EW_LAUNCH(add_kernel, n, s, a, b, y, n);
+  return TACO_OK;
+}
+int launch_l1(const float* a, const float* b, float* grad, int ldg, float* loss_slot, int64_t M, int N, hipStream_t s) {
+  TACO_REQUIRE(ldg >= N, "l1: ldg < N");
+  hipLaunchKernelGGL(l1_kernel, dim3(grid_for(M * ldg, kThreads, 2048)), dim3(kThreads), 0, s, a, b, grad, ldg, loss_slot, M, N);
+  TACO_LAUNCH_CHECK("l1");
+  return TACO_OK;
+}
+int launch_finish_loss(float* loss, hipStream_t s) {
+  hipLaunchKernelGGL(finish_loss_kernel, dim3(1), dim3(1), 0, s, loss);
+  TACO_LAUNCH_CHECK("finish_loss");
+  return TACO_OK;
+}
+int launch_bn_fold(const float* gamma, float* scale, int n, hipStream_t s) {
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, s, gamma, scale, n);
+  TACO_LAUNCH_CHECK("bn_fold");
+  return TACO_OK;
+}
+int launch_transpose_flip(const float* in, float* out, int taps, int K, int N, hipStream_t s) {
+  dim3 grid((N + 31) / 32, (K + 31) / 32, taps);
+  hipLaunchKernelGGL(transpose_flip_kernel, grid, dim3(32, 8), 0, s, in, out, taps, K, N);
+  TACO_LAUNCH_CHECK("transpose_flip");
+  return TACO_OK;
+}
+int launch_sumsq(const float* x, int64_t n, float* out, hipStream_t s) {
+  TACO_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "sumsq: x must be 16-byte aligned");
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4 + 1, kThreads, 1024)), dim3(kThreads), 0, s, x, n, out);
+  TACO_LAUNCH_CHECK("sumsq");
+  return TACO_OK;
+}
+int launch_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float cap, int64_t step,
+                     const float* sumsq, float* gnorm_out, hipStream_t s) {
+  const double b1 = 0.9, b2 = 0.999;
+  const double lr_t = (double)lr * sqrt(1.0 - pow(b2, (double)step)) / (1.0 - pow(b1, (double)step));
+  hipLaunchKernelGGL(clip_adam_kernel, dim3(grid_for(n, kThreads, 2048)), dim3(kThreads), 0, s, p, g, m, v, n,
+                     (float)lr_t, cap, sumsq, gnorm_out);
+  TACO_LAUNCH_CHECK("clip_adam");
+  return TACO_OK;
+}
+int launch_bernoulli(uint8_t* out, int64_t n, float p_one, uint64_t seed, hipStream_t s) {
+  double t = (double)p_one * 4294967296.0;
+  uint32_t thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (t <= 0 ? 0u : (uint32_t)t);
+  hipLaunchKernelGGL(bernoulli_kernel, dim3(grid_for((n + 1) / 2)), dim3(kThreads), 0, s, out, n, thresh, seed);
+  TACO_LAUNCH_CHECK("bernoulli");
+  return TACO_OK;
+}

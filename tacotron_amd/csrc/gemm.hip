@@ -1,0 +1,423 @@
+// gemm.hip -- fp32 MFMA (v_mfma_f32_32x32x2_f32) GEMM family for the feed-forward part of the Tacotron hot path.
+//
+//   conv_gemm (NN): C = post(act(sum_tap shift_tap(A) . W[tap] + bias))  -- tf.layers.dense (tacotron.py:40-43,148),
+//                   tf.layers.conv1d 'same' (ops.py:54-60,80-86), hoisted GRU input projections (ops.py:117-128),
+//                   and (with pre-transposed weights) every activation gradient dA = dZ . W^T.
+//   gemm_tn       : dW[tap] += shift_tap(A)^T . dY              -- every weight gradient (tacotron.py:172).
+//
+// Tiling: 256 threads = 4 waves (2x2), each wave WMxWN 32x32 MFMA tiles; block tile (64*WM) x (64*WN), BK = 16.
+// A/B tiles are staged k-major in LDS so that the f32 MFMA operand fetch (lane l -> [k = l>>5][i = l&31]) is a
+// conflict-free 32-lane contiguous ds_read_b32.  Global loads are float4 along the contiguous dimension with a
+// scalar fallback for unaligned leading dimensions (e.g. 1025-wide linear frames).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int BK = 16;
+
+struct RowInfo {
+  int m;      // global output row
+  int t;      // position inside its sequence
+  bool ok;    // m < M
+};
+
+template <int WM, int WN>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmBatch batch) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int LDS_A = BM + 4, LDS_B = BN + 4;
+  constexpr int A_PER = BM / 64;   // float4 loads of A per thread per tile  (BM rows x 4 float4)
+  constexpr int B_PER = BN / 64;   // float4 loads of W per thread per tile  (16 rows x BN/4 float4)
+  const ConvGemmProblem& P = batch.p[blockIdx.z];
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  if (m0 >= P.M || n0 >= P.N) return;
+
+  __shared__ __attribute__((aligned(16))) float As[2][BK][LDS_A];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDS_B];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const bool vecA = P.flags & 1, vecB = P.flags & 2;
+
+  // --- loader mapping ---
+  const int a_kq = tid & 3;          // which float4 along k (4 per row)
+  const int a_row = tid >> 2;        // 0..63 (+64*i)
+  RowInfo ar[A_PER];
+#pragma unroll
+  for (int i = 0; i < A_PER; ++i) {
+    int m = m0 + a_row + 64 * i;
+    ar[i].m = m;
+    ar[i].ok = m < P.M;
+    ar[i].t = ar[i].ok ? (m % P.T) : 0;
+  }
+  constexpr int B_COLS4 = BN / 4;            // float4 per W row
+  const int b_c4 = tid % B_COLS4;
+  const int b_k = tid / B_COLS4;             // 0 .. 256/B_COLS4-1
+  constexpr int B_KSTEP = 256 / B_COLS4;     // rows covered per pass (8 for BN=128, 16 for BN=64)
+
+  const int ktiles = (P.K + BK - 1) / BK;
+  const int nit = P.taps * ktiles;
+
+  float4 ra[A_PER], rb[B_PER];
+
+  auto load_tile = [&](int it) {
+    const int tap = it / ktiles;
+    const int k0 = (it - tap * ktiles) * BK;
+    const int sh = tap - P.pad_l;
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int st = ar[i].t + sh;
+      if (ar[i].ok && st >= 0 && st < P.T) {
+        const int k = k0 + a_kq * 4;
+        const float* p = P.A + (int64_t)(ar[i].m + sh) * P.lda + k;
+        if (vecA && k + 3 < P.K) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (k < P.K) v.x = p[0];
+          if (k + 1 < P.K) v.y = p[1];
+          if (k + 2 < P.K) v.z = p[2];
+          if (k + 3 < P.K) v.w = p[3];
+        }
+      }
+      ra[i] = v;
+    }
+    const float* Wt = P.W + (int64_t)tap * P.K * P.ldw;
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int k = k0 + b_k + i * B_KSTEP;
+      const int n = n0 + b_c4 * 4;
+      if (k < P.K && (B_PER * B_KSTEP == BK || b_k + i * B_KSTEP < BK)) {
+        const float* p = Wt + (int64_t)k * P.ldw + n;
+        if (vecB && n + 3 < P.N) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (n < P.N) v.x = p[0];
+          if (n + 1 < P.N) v.y = p[1];
+          if (n + 2 < P.N) v.z = p[2];
+          if (n + 3 < P.N) v.w = p[3];
+        }
+      }
+      rb[i] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      const int r = a_row + 64 * i;
+      As[buf][a_kq * 4 + 0][r] = ra[i].x;
+      As[buf][a_kq * 4 + 1][r] = ra[i].y;
+      As[buf][a_kq * 4 + 2][r] = ra[i].z;
+      As[buf][a_kq * 4 + 3][r] = ra[i].w;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      const int k = b_k + i * B_KSTEP;
+      if (k < BK) *reinterpret_cast<float4*>(&Bs[buf][k][b_c4 * 4]) = rb[i];
+    }
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  const int lk = lane >> 5, li = lane & 31;
+  for (int it = 0; it < nit; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < nit) load_tile(it + 1);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a[WM], b[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) a[i] = As[buf][kk + lk][wm * (32 * WM) + i * 32 + li];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) b[j] = Bs[buf][kk + lk][wn * (32 * WN) + j * 32 + li];
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (it + 1 < nit) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // --- epilogue: C/D layout col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ---
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int n = n0 + wn * (32 * WN) + j * 32 + li;
+      if (n >= P.N) continue;
+      const float bias = P.bias ? P.bias[n] : 0.f;
+      const float sc = P.scale ? P.scale[n] : 1.f;
+      const float sf = P.shift ? P.shift[n] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * (32 * WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+        if (m >= P.M) continue;
+        float v = apply_act(acc[i][j][e] + bias, P.act);
+        if (P.keep) v = P.keep[(int64_t)m * P.N + n] ? v * 2.0f : 0.0f;
+        if (P.Cpre) P.Cpre[(int64_t)m * P.ldc + n] = v;
+        if (P.scale || P.shift) v = v * sc + sf;
+        if (P.residual) v += P.residual[(int64_t)m * P.ldr + n];
+        P.C[(int64_t)m * P.ldc + n] = v;
+      }
+    }
+  }
+}
+
+// dW[z][tap][k][n] += sum_m A[z][row(m,tap)][k] * dY[z][m][n]; reduction over m split across blockIdx.z slices.
+template <int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs P) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;   // BM tiles the k (output row) dimension
+  constexpr int LDS_A = BM + 4, LDS_B = BN + 4;
+  constexpr int A_PER = BM / 64, B_PER = BN / 64;
+  const int k0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  int z = blockIdx.z;
+  const int split = z % P.splits;
+  z /= P.splits;
+  const int tap = z % P.taps;
+  const int bz = z / P.taps;
+  const float* A = P.A + (int64_t)bz * P.strideA;
+  const float* Y = P.Y + (int64_t)bz * P.strideY;
+  float* W = P.W + (int64_t)bz * P.strideW + (int64_t)tap * P.K * P.ldw;
+
+  __shared__ __attribute__((aligned(16))) float As[2][BK][LDS_A];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDS_B];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const bool vecA = P.flags & 1, vecB = P.flags & 2;
+  const int sh = tap - P.pad_l;
+
+  constexpr int A_COLS4 = BM / 4, B_COLS4 = BN / 4;
+  constexpr int A_RSTEP = 256 / A_COLS4, B_RSTEP = 256 / B_COLS4;
+  const int a_c4 = tid % A_COLS4, a_r = tid / A_COLS4;
+  const int b_c4 = tid % B_COLS4, b_r = tid / B_COLS4;
+
+  const int m_begin = split * P.chunk;
+  const int m_end = min(P.M, m_begin + P.chunk);
+  const int nit = (m_end - m_begin + BK - 1) / BK;
+  if (nit <= 0) return;
+
+  float4 ra[A_PER], rb[B_PER];
+  auto load_tile = [&](int it) {
+    const int mm0 = m_begin + it * BK;
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int r = a_r + i * A_RSTEP;
+      const int m = mm0 + r;
+      if (r < BK && m < m_end) {
+        const int st = (m % P.T) + sh;
+        if (st >= 0 && st < P.T) {
+          const int k = k0 + a_c4 * 4;
+          const float* p = A + (int64_t)(m + sh) * P.lda + k;
+          if (vecA && k + 3 < P.K) {
+            v = *reinterpret_cast<const float4*>(p);
+          } else {
+            if (k < P.K) v.x = p[0];
+            if (k + 1 < P.K) v.y = p[1];
+            if (k + 2 < P.K) v.z = p[2];
+            if (k + 3 < P.K) v.w = p[3];
+          }
+        }
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int r = b_r + i * B_RSTEP;
+      const int m = mm0 + r;
+      if (r < BK && m < m_end) {
+        const int n = n0 + b_c4 * 4;
+        const float* p = Y + (int64_t)m * P.ldy + n;
+        if (vecB && n + 3 < P.N) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (n < P.N) v.x = p[0];
+          if (n + 1 < P.N) v.y = p[1];
+          if (n + 2 < P.N) v.z = p[2];
+          if (n + 3 < P.N) v.w = p[3];
+        }
+      }
+      rb[i] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      const int r = a_r + i * A_RSTEP;
+      if (r < BK) *reinterpret_cast<float4*>(&As[buf][r][a_c4 * 4]) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      const int r = b_r + i * B_RSTEP;
+      if (r < BK) *reinterpret_cast<float4*>(&Bs[buf][r][b_c4 * 4]) = rb[i];
+    }
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  const int lk = lane >> 5, li = lane & 31;
+  for (int it = 0; it < nit; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < nit) load_tile(it + 1);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a[WM], b[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) a[i] = As[buf][kk + lk][wm * (32 * WM) + i * 32 + li];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) b[j] = Bs[buf][kk + lk][wn * (32 * WN) + j * 32 + li];
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (it + 1 < nit) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int n = n0 + wn * (32 * WN) + j * 32 + li;
+      if (n >= P.N) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int k = k0 + wm * (32 * WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+        if (k >= P.K) continue;
+        atomicAdd(&W[(int64_t)k * P.ldw + n], acc[i][j][e]);
+      }
+    }
+  }
+}
+
+__global__ void gemm_naive_kernel(ConvGemmProblem P) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)P.M * P.N) return;
+  const int m = (int)(idx / P.N), n = (int)(idx % P.N);
+  const int t = m % P.T;
+  float acc = 0.f;
+  for (int tap = 0; tap < P.taps; ++tap) {
+    const int st = t + tap - P.pad_l;
+    if (st < 0 || st >= P.T) continue;
+    const float* a = P.A + (int64_t)(m + tap - P.pad_l) * P.lda;
+    const float* w = P.W + (int64_t)tap * P.K * P.ldw + n;
+    for (int k = 0; k < P.K; ++k) acc = fmaf(a[k], w[(int64_t)k * P.ldw], acc);
+  }
+  if (P.bias) acc += P.bias[n];
+  P.C[(int64_t)m * P.ldc + n] = apply_act(acc, P.act);
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+void conv_gemm_set_flags(ConvGemmProblem& p) {
+  p.flags = 0;
+  if (p.lda % 4 == 0 && aligned16(p.A)) p.flags |= 1;
+  if (p.ldw % 4 == 0 && aligned16(p.W) && ((int64_t)p.K * p.ldw) % 4 == 0) p.flags |= 2;
+}
+
+int launch_conv_gemm_batch(ConvGemmBatch& batch, hipStream_t stream) {
+  TACO_REQUIRE(batch.n >= 1 && batch.n <= kMaxGemmBatch, "conv_gemm: batch size %d out of range", batch.n);
+  int maxM = 0, maxN = 0;
+  double work = 0;
+  for (int i = 0; i < batch.n; ++i) {
+    ConvGemmProblem& p = batch.p[i];
+    TACO_REQUIRE(p.A && p.W && p.C, "conv_gemm: null operand");
+    TACO_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0 && p.taps > 0 && p.T > 0, "conv_gemm: bad dims M=%d N=%d K=%d taps=%d T=%d",
+                 p.M, p.N, p.K, p.taps, p.T);
+    TACO_REQUIRE(p.M % p.T == 0, "conv_gemm: M (%d) must be a multiple of T (%d)", p.M, p.T);
+    conv_gemm_set_flags(p);
+    maxM = p.M > maxM ? p.M : maxM;
+    maxN = p.N > maxN ? p.N : maxN;
+    work += (double)cdiv(p.M, 128) * cdiv(p.N, 128);
+  }
+  // Big tiles only when they still fill the chip (256 CUs); otherwise 64x64 tiles for more workgroups.
+  if (work >= 384) {
+    dim3 grid(cdiv(maxM, 128), cdiv(maxN, 128), batch.n);
+    hipLaunchKernelGGL((conv_gemm_kernel<2, 2>), grid, dim3(256), 0, stream, batch);
+  } else {
+    dim3 grid(cdiv(maxM, 64), cdiv(maxN, 64), batch.n);
+    hipLaunchKernelGGL((conv_gemm_kernel<1, 1>), grid, dim3(256), 0, stream, batch);
+  }
+  TACO_LAUNCH_CHECK("conv_gemm");
+  return TACO_OK;
+}
+
+int launch_conv_gemm(const ConvGemmProblem& p, hipStream_t stream) {
+  ConvGemmBatch b;
+  b.n = 1;
+  b.p[0] = p;
+  return launch_conv_gemm_batch(b, stream);
+}
+
+int launch_gemm_tn(GemmTnArgs a, bool zero_first, hipStream_t stream) {
+  TACO_REQUIRE(a.A && a.Y && a.W, "gemm_tn: null operand");
+  TACO_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.taps > 0 && a.T > 0 && a.batch > 0, "gemm_tn: bad dims");
+  TACO_REQUIRE(a.M % a.T == 0, "gemm_tn: M (%d) must be a multiple of T (%d)", a.M, a.T);
+  a.flags = 0;
+  if (a.lda % 4 == 0 && aligned16(a.A) && a.strideA % 4 == 0) a.flags |= 1;
+  if (a.ldy % 4 == 0 && aligned16(a.Y) && a.strideY % 4 == 0) a.flags |= 2;
+  if (zero_first) {
+    for (int b = 0; b < a.batch; ++b) {
+      hipError_t e = hipMemset2DAsync(a.W + (int64_t)b * a.strideW, (size_t)a.ldw * 4, 0, (size_t)a.N * 4,
+                                      (size_t)a.taps * a.K, stream);
+      if (e != hipSuccess) {
+        taco_set_error("gemm_tn memset: %s", hipGetErrorString(e));
+        return TACO_ELAUNCH;
+      }
+    }
+  }
+  const bool big = (int64_t)cdiv(a.K, 128) * cdiv(a.N, 128) * a.taps * a.batch >= 128 && a.K >= 128 && a.N >= 128;
+  const int bm = big ? 128 : 64;
+  const int64_t tiles = (int64_t)cdiv(a.K, bm) * cdiv(a.N, bm) * a.taps * a.batch;
+  int splits = (int)((768 + tiles - 1) / tiles);
+  const int max_splits = cdiv(a.M, 64);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int chunk = cdiv(a.M, splits);
+  chunk = cdiv(chunk, BK) * BK;
+  splits = cdiv(a.M, chunk);
+  a.splits = splits;
+  a.chunk = chunk;
+  dim3 grid(cdiv(a.K, bm), cdiv(a.N, bm), a.batch * a.taps * splits);
+  if (big)
+    hipLaunchKernelGGL((gemm_tn_kernel<2, 2>), grid, dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL((gemm_tn_kernel<1, 1>), grid, dim3(256), 0, stream, a);
+  TACO_LAUNCH_CHECK("gemm_tn");
+  return TACO_OK;
+}
+
+int launch_gemm_naive(const ConvGemmProblem& p, hipStream_t stream) {
+  const int64_t n = (int64_t)p.M * p.N;
+  hipLaunchKernelGGL(gemm_naive_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, p);
+  TACO_LAUNCH_CHECK("gemm_naive");
+  return TACO_OK;
+}

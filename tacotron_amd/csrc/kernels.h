@@ -1,0 +1,167 @@
+// kernels.h -- internal launch interface shared by the .hip translation units of libtaco_hip.so.
+#pragma once
+#include "common.h"
+
+// ---------------------------------------------------------------- gemm.hip
+constexpr int kMaxGemmBatch = 16;
+
+struct ConvGemmProblem {
+  const float* A = nullptr;
+  const float* W = nullptr;
+  const float* bias = nullptr;
+  const float* scale = nullptr;
+  const float* shift = nullptr;
+  const float* residual = nullptr;
+  const uint8_t* keep = nullptr;
+  float* C = nullptr;
+  float* Cpre = nullptr;
+  int lda = 0, ldw = 0, ldr = 0, ldc = 0;
+  int M = 0, N = 0, K = 0, taps = 1, T = 1, pad_l = 0, act = 0, flags = 0;
+};
+struct ConvGemmBatch {
+  ConvGemmProblem p[kMaxGemmBatch];
+  int n = 0;
+};
+struct GemmTnArgs {
+  const float* A = nullptr;
+  const float* Y = nullptr;
+  float* W = nullptr;
+  int lda = 0, ldy = 0, ldw = 0;
+  int M = 0, N = 0, K = 0, taps = 1, T = 1, pad_l = 0;
+  int batch = 1;
+  int64_t strideA = 0, strideY = 0, strideW = 0;
+  int splits = 1, chunk = 0, flags = 0;
+};
+
+int launch_conv_gemm_batch(ConvGemmBatch& batch, hipStream_t stream);
+int launch_conv_gemm(const ConvGemmProblem& p, hipStream_t stream);
+int launch_gemm_tn(GemmTnArgs a, bool zero_first, hipStream_t stream);
+int launch_gemm_naive(const ConvGemmProblem& p, hipStream_t stream);
+
+// ---------------------------------------------------------------- elementwise.hip
+int launch_embedding(const float* table, const int32_t* ids, float* out, int64_t rows, int V, hipStream_t s);
+int launch_embedding_bwd(const float* dout, const int32_t* ids, float* dtable, int64_t rows, int V, hipStream_t s);
+// y = maxpool2_same(x*scale+shift) along T; x,y (B*T, C)
+int launch_bn_maxpool(const float* x, const float* gamma, const float* beta, float* y, int B, int T, int C, hipStream_t s);
+// dx, dgamma, dbeta of the op above (dgamma/dbeta accumulated with atomics)
+int launch_bn_maxpool_bwd(const float* x, const float* gamma, const float* beta, const float* dy, float* dx,
+                          float* dgamma, float* dbeta, int B, int T, int C, hipStream_t s);
+// highway combine: th (M,256) = [T | H]; y = H*T + x*(1-T)
+int launch_highway_combine(const float* th, const float* x, float* y, int64_t M, hipStream_t s);
+// dth (M,256) = [dy*(H-x)*T(1-T) | dy*T*(H>0)], dx = dy*(1-T)
+int launch_highway_combine_bwd(const float* th, const float* x, const float* dy, float* dth, float* dx, int64_t M,
+                               hipStream_t s);
+// dz = dy * act'(y) [* keep*2]; in place allowed (dz == dy)
+int launch_act_bwd(const float* y, const float* dy, const uint8_t* keep, float* dz, int64_t n, int act, hipStream_t s);
+// BN-affine backward around a stored pre-affine activation:
+//   dgamma += sum_m dy*pre*rs, dbeta += sum_m dy, dz = dy*gamma*rs*act'(pre)   (rs = 1/sqrt(1+eps); act in {none, relu})
+int launch_affine_act_bwd(const float* pre, const float* gamma, const float* dy, float* dz, float* dgamma, float* dbeta,
+                          int64_t M, int N, int act, hipStream_t s);
+// out[n] += sum_m x[m*ld + n]
+int launch_colsum(const float* x, int ld, float* out, int64_t M, int N, hipStream_t s);
+// values = enc * (t < len[b])
+int launch_mask_rows(const float* x, const int32_t* len, float* y, int B, int T, int C, hipStream_t s);
+int launch_add(const float* a, const float* b, float* y, int64_t n, hipStream_t s);  // y = a + b
+// L1 losses + sign gradients.  loss[1] += sum|a-b| (slot given).  grad (ldg >= N) = sign(a-b), pad columns zeroed.
+int launch_l1(const float* a, const float* b, float* grad, int ldg, float* loss_slot, int64_t M, int N, hipStream_t s);
+int launch_finish_loss(float* loss, hipStream_t s);  // loss[0] = loss[1] + loss[2]
+// bn scale/shift vectors: scale = gamma/sqrt(1+eps), shift = beta
+int launch_bn_fold(const float* gamma, float* scale, int n, hipStream_t s);
+// transposes: out[tap'][n][k] = in[taps-1-tap'][k][n]
+int launch_transpose_flip(const float* in, float* out, int taps, int K, int N, hipStream_t s);
+int launch_sumsq(const float* x, int64_t n, float* out, hipStream_t s);  // out[0] += sum x^2 (double-free, fp32 tree)
+int launch_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float cap, int64_t step,
+                     const float* sumsq, float* gnorm_out, hipStream_t s);
+int launch_bernoulli(uint8_t* out, int64_t n, float p_one, uint64_t seed, hipStream_t s);
+
+// ---------------------------------------------------------------- bigru.hip
+struct BiGruWeights {
+  const float* wg[2];  // (256,256) rows [0,128) x-part, [128,256) h-part
+  const float* bg[2];  // (256)
+  const float* wc[2];  // (256,128)
+  const float* bc[2];  // (128)
+};
+// xg (B,T,768): per direction d: [d*384, d*384+256) gates x-proj (+bias), [d*384+256, d*384+384) candidate x-proj (+bias)
+int launch_bigru_fwd(const float* xg, const BiGruWeights& w, float* out, float* ruc, int B, int T, hipStream_t s);
+// Backward recurrence.  wgT/wcT: h-parts transposed: wghT (256,128) = Wg[128:,:]^T, wchT (128,128) = Wc[128:,:]^T.
+// dxg (B,T,768) receives pre-activation gradients [dgates | dcand] per direction.  rh (B,T,256) receives r*h_prev
+// per direction (for the candidate weight gradient).
+struct BiGruBwdWeights {
+  const float* wghT[2];
+  const float* wchT[2];
+};
+int launch_bigru_bwd(const float* dout, const float* out, const float* ruc, const BiGruBwdWeights& w, float* dxg,
+                     float* rh, int B, int T, hipStream_t s);
+
+// ---------------------------------------------------------------- decoder.hip
+struct DecWeights {
+  const float *pre_w1, *pre_b1, *pre_w2, *pre_b2;  // (80,256) (256,128)
+  const float *in_w, *in_b;                        // (384,256)
+  const float *gw[3], *gb[3], *cw[3], *cb[3];      // (512,512) (512) (512,256) (256)
+  const float *out_w, *out_b;                      // (256,80r)
+  const float* q_w;                                // (80r,256)
+  const float* att_v;                              // (256)
+  const float* att_w;                              // (80r+256,256)
+};
+// per-(b,t) forward stash record (floats)
+constexpr int kStP1 = 0;                  // 256  pre-net layer 1 (post relu, post dropout)
+constexpr int kStP2 = 256;                // 128
+constexpr int kStX = 384;                 // 256  in-proj output
+constexpr int kStH = 640;                 // 3*256 new GRU states
+constexpr int kStR = 1408;                // 3*256
+constexpr int kStU = 2176;                // 3*256
+constexpr int kStC = 2944;                // 3*256
+constexpr int kStRH = 3712;               // 3*256 r*h_prev
+constexpr int kStCtx = 4480;              // 256
+constexpr int kStAtt = 4736;              // 256
+constexpr int kStQ = 4992;                // 256
+constexpr int kStY = 5248;                // 256  x + h3 (out-proj input)
+constexpr int kStRec = 5504;
+// per-(b,t) gradient stash record (floats): pre-activation gradients feeding the weight-gradient GEMMs
+constexpr int kGsG = 0;                   // 3*512 gates pre-act grads
+constexpr int kGsC = 1536;                // 3*256 candidate pre-act grads
+constexpr int kGsX = 2304;                // 256 dx (in-proj output grad)
+constexpr int kGsQ = 2560;                // 256 dq
+constexpr int kGsAtt = 2816;              // 256 d attention (att-proj output grad)
+constexpr int kGsCtx = 3072;              // 256 d context
+constexpr int kGsP2 = 3328;               // 128 d prenet-2 pre-act
+constexpr int kGsP1 = 3456;               // 256 d prenet-1 pre-act
+constexpr int kGsO = 3712;                // 80r (<= 400) d cell_output (total)
+constexpr int kGsRec = 4112;
+
+struct DecFwdArgs {
+  DecWeights w;
+  const float* keys;     // (B,Tt,256)
+  const float* values;   // (B,Tt,256)
+  const int32_t* text_length;
+  const float* mel;      // (B,Td,80r) or null (inference)
+  const uint8_t* keep1;  // (B,Td,256) or null
+  const uint8_t* keep2;  // (B,Td,128) or null
+  const uint8_t* sample; // (Td,B) or null
+  float* out;            // (B,Td,80r)
+  float* align;          // (B,Td,Tt)
+  float* stash;          // (B,Td,kStRec) or null
+  float* prein;          // (B,Td,80) pre-net input frames actually used (train stash) or null
+  int B, Tt, Td, r;
+};
+int launch_decoder_fwd(const DecFwdArgs& a, hipStream_t s);
+
+struct DecBwdArgs {
+  DecWeights wT;         // every matrix TRANSPOSED (out,in); biases unused
+  const float* att_v;    // (256)
+  const float* keys;
+  const float* values;
+  const int32_t* text_length;
+  const uint8_t* keep1;
+  const uint8_t* keep2;
+  const uint8_t* sample;
+  const float* dout;     // (B,Td,80r) dLoss/d seq2seq_output (direct: L1 sign + post-net path)
+  const float* out;      // (B,Td,80r)
+  const float* align;    // (B,Td,Tt)
+  const float* stash;    // (B,Td,kStRec)
+  float* gstash;         // (B,Td,kGsRec)
+  float* dkeys;          // (B,Tt,256) zero-initialised, accumulated
+  float* datt_v;         // (256) accumulated (atomics)
+  int B, Tt, Td, r;
+};
+int launch_decoder_bwd(const DecBwdArgs& a, hipStream_t s);

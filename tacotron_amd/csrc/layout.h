@@ -1,0 +1,89 @@
+// layout.h -- parameter / transposed-parameter / workspace layouts of libtaco_hip.so.
+// The parameter order is the reference graph's variable order (tacotron.py:107-154) with TF variable layouts; it
+// must match oracle/taco_numpy.py::param_spec (asserted by tests/test_layout.py).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+struct DenseP {
+  int64_t w = -1, b = -1;
+  int in = 0, out = 0;
+};
+struct GruP {
+  int64_t wg = -1, bg = -1, wc = -1, bc = -1;
+  int cin = 0, h = 0;
+};
+struct CbhgP {
+  int K = 0, cin = 0, c1 = 0, c2 = 0;
+  int64_t bank_w[16], bank_b[16];
+  int64_t bank_g = -1, bank_be = -1;
+  int64_t p1_w = -1, p1_b = -1, p1_g = -1, p1_be = -1;
+  int64_t p2_w = -1, p2_b = -1, p2_g = -1, p2_be = -1;
+  bool has_adapt = false;
+  DenseP adapt;
+  DenseP hwT[4], hwH[4];
+  GruP fw, bw;
+};
+struct ParamLayout {
+  int64_t emb = -1;
+  DenseP enc_pre1, enc_pre2;
+  CbhgP enc;
+  int64_t mem_w = -1;
+  DenseP dec_pre1, dec_pre2, in_proj;
+  GruP gru[3];
+  DenseP out_proj;
+  int64_t q_w = -1, att_v = -1, att_w = -1;
+  CbhgP post;
+  DenseP post_dense;
+  int64_t total = 0;
+  std::vector<TacoTensorInfo> rows;
+};
+
+// Transposed (and tap-flipped) copies used by the backward pass; offsets into the workspace "paramsT" region.
+struct CbhgT {
+  int64_t bank[16];      // (k, 128, cin)
+  int64_t p1 = -1;       // (3, c1, K*128)
+  int64_t p2 = -1;       // (3, c2, c1)
+  int64_t adapt = -1;    // (128, c2)
+  int64_t hw[4];         // (256, 128): rows [0,128) = Wt^T, [128,256) = Wh^T
+  int64_t gru_x = -1;    // (768, 128): [Wg_fw[:128]^T ; Wc_fw[:128]^T ; Wg_bw[:128]^T ; Wc_bw[:128]^T]
+  int64_t wghT[2];       // (256, 128) = Wg[128:]^T
+  int64_t wchT[2];       // (128, 128) = Wc[128:]^T
+};
+struct TransLayout {
+  int64_t enc_pre1 = -1, enc_pre2 = -1;
+  CbhgT enc;
+  int64_t mem_w = -1;
+  int64_t dec_pre1 = -1, dec_pre2 = -1, in_proj = -1;
+  int64_t gw[3], cw[3];
+  int64_t out_proj = -1, q_w = -1, att_w = -1;
+  CbhgT post;
+  int64_t post_dense = -1;
+  int64_t total = 0;
+};
+
+struct CbhgWs {
+  int64_t bank, pool, pj1pre, pj1, pj2pre, res, adapt, h[5], th[4], xg, out, ruc;
+  int64_t s_bank, s_p1, s_p2;  // folded BN scales
+};
+struct WsLayout {
+  // forward
+  int64_t emb, p1, p2;
+  CbhgWs enc;
+  int64_t values, keys;
+  int64_t stash, prein;
+  CbhgWs post;
+  int64_t loss;  // 4 floats
+  // backward
+  int64_t ds2s, dout_pad, paramsT, gstash, dkeys, dvalues, ds2s_tot;
+  int64_t gA, gB, gC, gD, gE, gF, gG, scratch;
+  int64_t total = 0;  // floats
+  std::vector<TacoTensorInfo> rows;
+};
+
+void build_param_layout(const TacoShape& s, ParamLayout& L);
+void build_trans_layout(const TacoShape& s, const ParamLayout& P, TransLayout& T);
+void build_ws_layout(const TacoShape& s, bool train, const TransLayout& T, WsLayout& W);
+int validate_shape(const TacoShape* s);

@@ -1,0 +1,216 @@
+// layout.hip -- host-only: parameter table (TF variable order), transposed-weight table, workspace table.
+#include "layout.h"
+#include "kernels.h"
+
+#include <stdarg.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "ok";
+void taco_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* taco_last_error_string(void) { return g_err; }
+extern "C" int taco_version(void) { return TACO_VERSION; }
+
+int validate_shape(const TacoShape* s) {
+  TACO_REQUIRE(s != nullptr, "shape is null");
+  TACO_REQUIRE(s->B >= 1 && s->B <= 4096, "B=%d out of range", s->B);
+  TACO_REQUIRE(s->Tt >= 1 && s->Tt <= 4096, "Tt=%d out of range", s->Tt);
+  TACO_REQUIRE(s->Td >= 1 && s->Td <= 8192, "Td=%d out of range", s->Td);
+  TACO_REQUIRE(s->r >= 1 && s->r <= 5, "r=%d out of range (1..5)", s->r);
+  TACO_REQUIRE(s->V >= 1, "V=%d out of range", s->V);
+  return TACO_OK;
+}
+
+namespace {
+struct Adder {
+  std::vector<TacoTensorInfo>* rows;
+  int64_t off = 0;
+  int64_t align = 1;
+  int64_t add(const std::string& name, std::initializer_list<int64_t> dims) {
+    TacoTensorInfo r;
+    memset(&r, 0, sizeof(r));
+    snprintf(r.name, sizeof(r.name), "%s", name.c_str());
+    int64_t sz = 1;
+    int i = 0;
+    for (int64_t d : dims) {
+      r.dims[i++] = (int32_t)d;
+      sz *= d;
+    }
+    r.ndim = i;
+    off = (off + align - 1) / align * align;
+    r.offset = off;
+    r.size = sz;
+    if (rows) rows->push_back(r);
+    off += sz;
+    return r.offset;
+  }
+};
+
+void add_dense(Adder& a, const std::string& n, int in, int out, bool bias, DenseP& d) {
+  d.in = in;
+  d.out = out;
+  d.w = a.add(n + "/kernel", {in, out});
+  d.b = bias ? a.add(n + "/bias", {out}) : -1;
+}
+void add_gru(Adder& a, const std::string& n, int cin, int h, GruP& g) {
+  g.cin = cin;
+  g.h = h;
+  g.wg = a.add(n + "/gates/kernel", {cin + h, 2 * h});
+  g.bg = a.add(n + "/gates/bias", {2 * h});
+  g.wc = a.add(n + "/candidate/kernel", {cin + h, h});
+  g.bc = a.add(n + "/candidate/bias", {h});
+}
+void add_cbhg(Adder& a, const std::string& p, int K, int cin, int c1, int c2, CbhgP& c) {
+  c.K = K;
+  c.cin = cin;
+  c.c1 = c1;
+  c.c2 = c2;
+  for (int k = 1; k <= K; ++k) {
+    c.bank_w[k - 1] = a.add(p + "bank_" + std::to_string(k) + "/kernel", {k, cin, kCb});
+    c.bank_b[k - 1] = a.add(p + "bank_" + std::to_string(k) + "/bias", {kCb});
+  }
+  c.bank_g = a.add(p + "bank_bn/gamma", {K * kCb});
+  c.bank_be = a.add(p + "bank_bn/beta", {K * kCb});
+  c.p1_w = a.add(p + "proj1/kernel", {3, K * kCb, c1});
+  c.p1_b = a.add(p + "proj1/bias", {c1});
+  c.p1_g = a.add(p + "proj1_bn/gamma", {c1});
+  c.p1_be = a.add(p + "proj1_bn/beta", {c1});
+  c.p2_w = a.add(p + "proj2/kernel", {3, c1, c2});
+  c.p2_b = a.add(p + "proj2/bias", {c2});
+  c.p2_g = a.add(p + "proj2_bn/gamma", {c2});
+  c.p2_be = a.add(p + "proj2_bn/beta", {c2});
+  c.has_adapt = (c2 != kCb);
+  for (int l = 0; l < 4; ++l) {
+    const std::string hp = p + "highway_" + std::to_string(l) + "/";
+    if (l == 0 && c.has_adapt) add_dense(a, hp + "adapt", c2, kCb, true, c.adapt);
+    add_dense(a, hp + "T", kCb, kCb, true, c.hwT[l]);
+    add_dense(a, hp + "H", kCb, kCb, true, c.hwH[l]);
+  }
+  add_gru(a, p + "bigru/fw", kCb, kCb, c.fw);
+  add_gru(a, p + "bigru/bw", kCb, kCb, c.bw);
+}
+}  // namespace
+
+void build_param_layout(const TacoShape& s, ParamLayout& L) {
+  L.rows.clear();
+  Adder a{&L.rows};
+  const int R80 = kMel * s.r;
+  L.emb = a.add("embedding", {s.V, kEmbed});
+  add_dense(a, "encoder/pre_net/dense", kEmbed, kPre1, true, L.enc_pre1);
+  add_dense(a, "encoder/pre_net/dense_1", kPre1, kPre2, true, L.enc_pre2);
+  add_cbhg(a, "encoder/cbhg/", 16, kPre2, kCb, kCb, L.enc);
+  L.mem_w = a.add("decoder/memory_layer/kernel", {2 * kCb, kAtt});
+  add_dense(a, "decoder/pre_net/dense", kMel, kPre1, true, L.dec_pre1);
+  add_dense(a, "decoder/pre_net/dense_1", kPre1, kPre2, true, L.dec_pre2);
+  add_dense(a, "decoder/in_proj", kPre2 + kAtt, kDec, true, L.in_proj);
+  for (int l = 0; l < 3; ++l) add_gru(a, "decoder/gru_" + std::to_string(l), kDec, kDec, L.gru[l]);
+  add_dense(a, "decoder/out_proj", kDec, R80, true, L.out_proj);
+  L.q_w = a.add("decoder/query_layer/kernel", {R80, kAtt});
+  L.att_v = a.add("decoder/attention_v", {kAtt});
+  L.att_w = a.add("decoder/attention_layer/kernel", {R80 + kAtt, kAtt});
+  add_cbhg(a, "post/cbhg/", 8, kMel, 256, kMel, L.post);
+  add_dense(a, "post/dense", 2 * kCb, kFft, true, L.post_dense);
+  L.total = a.off;
+}
+
+static void trans_cbhg(Adder& a, const CbhgP& c, CbhgT& t) {
+  for (int k = 1; k <= c.K; ++k) t.bank[k - 1] = a.add("", {k, kCb, c.cin});
+  t.p1 = a.add("", {3, c.c1, c.K * kCb});
+  t.p2 = a.add("", {3, c.c2, c.c1});
+  t.adapt = c.has_adapt ? a.add("", {kCb, c.c2}) : -1;
+  for (int l = 0; l < 4; ++l) t.hw[l] = a.add("", {2 * kCb, kCb});
+  t.gru_x = a.add("", {6 * kCb, kCb});
+  for (int d = 0; d < 2; ++d) {
+    t.wghT[d] = a.add("", {2 * kCb, kCb});
+    t.wchT[d] = a.add("", {kCb, kCb});
+  }
+}
+
+void build_trans_layout(const TacoShape& s, const ParamLayout& P, TransLayout& T) {
+  Adder a{nullptr};
+  a.align = 4;
+  const int R80 = kMel * s.r;
+  T.enc_pre1 = a.add("", {kPre1, kEmbed});
+  T.enc_pre2 = a.add("", {kPre2, kPre1});
+  trans_cbhg(a, P.enc, T.enc);
+  T.mem_w = a.add("", {kAtt, 2 * kCb});
+  T.dec_pre1 = a.add("", {kPre1, kMel});
+  T.dec_pre2 = a.add("", {kPre2, kPre1});
+  T.in_proj = a.add("", {kDec, kPre2 + kAtt});
+  for (int l = 0; l < 3; ++l) {
+    T.gw[l] = a.add("", {2 * kDec, 2 * kDec});
+    T.cw[l] = a.add("", {kDec, 2 * kDec});
+  }
+  T.out_proj = a.add("", {R80, kDec});
+  T.q_w = a.add("", {kAtt, R80});
+  T.att_w = a.add("", {kAtt, R80 + kAtt});
+  trans_cbhg(a, P.post, T.post);
+  T.post_dense = a.add("", {kFft, 2 * kCb});
+  T.total = a.off;
+}
+
+static void ws_cbhg(Adder& a, const std::string& p, const CbhgP& c, int64_t M, bool train, CbhgWs& w) {
+  (void)train;
+  w.bank = a.add(p + "bank", {M, c.K * kCb});
+  w.pool = a.add(p + "pool", {M, c.K * kCb});
+  w.pj1pre = a.add(p + "pj1pre", {M, c.c1});
+  w.pj1 = a.add(p + "pj1", {M, c.c1});
+  w.pj2pre = a.add(p + "pj2pre", {M, c.c2});
+  w.res = a.add(p + "res", {M, c.c2});
+  w.adapt = c.has_adapt ? a.add(p + "adapt", {M, kCb}) : -1;
+  w.h[0] = c.has_adapt ? w.adapt : w.res;
+  for (int l = 1; l <= 4; ++l) w.h[l] = a.add(p + "h" + std::to_string(l), {M, kCb});
+  for (int l = 0; l < 4; ++l) w.th[l] = a.add(p + "th" + std::to_string(l), {M, 2 * kCb});
+  w.xg = a.add(p + "xg", {M, 6 * kCb});
+  w.out = a.add(p + "out", {M, 2 * kCb});
+  w.ruc = a.add(p + "ruc", {M, 6 * kCb});
+  w.s_bank = a.add(p + "s_bank", {c.K * kCb});
+  w.s_p1 = a.add(p + "s_p1", {c.c1});
+  w.s_p2 = a.add(p + "s_p2", {c.c2});
+}
+
+void build_ws_layout(const TacoShape& s, bool train, const TransLayout& T, WsLayout& W) {
+  W.rows.clear();
+  Adder a{&W.rows};
+  a.align = 64;  // 256-byte alignment of every workspace tensor
+  ParamLayout P;
+  build_param_layout(s, P);
+  const int R80 = kMel * s.r;
+  const int64_t M1 = (int64_t)s.B * s.Tt, MD = (int64_t)s.B * s.Td, M2 = MD * s.r;
+  W.emb = a.add("enc.emb", {M1, kEmbed});
+  W.p1 = a.add("enc.p1", {M1, kPre1});
+  W.p2 = a.add("enc.p2", {M1, kPre2});
+  ws_cbhg(a, "enc.", P.enc, M1, train, W.enc);
+  W.values = a.add("dec.values", {M1, kAtt});
+  W.keys = a.add("dec.keys", {M1, kAtt});
+  W.stash = train ? a.add("dec.stash", {MD, kStRec}) : -1;
+  W.prein = train ? a.add("dec.prein", {MD, kMel}) : -1;
+  ws_cbhg(a, "post.", P.post, M2, train, W.post);
+  W.loss = a.add("loss", {4});
+  if (train) {
+    const int64_t Mx = M1 > M2 ? M1 : M2;
+    W.ds2s = a.add("bwd.ds2s", {MD, R80});
+    W.dout_pad = a.add("bwd.dout_pad", {M2, 1028});
+    W.paramsT = a.add("bwd.paramsT", {T.total});
+    W.gstash = a.add("bwd.gstash", {MD, kGsRec});
+    W.dkeys = a.add("bwd.dkeys", {M1, kAtt});
+    W.dvalues = a.add("bwd.dvalues", {M1, kAtt});
+    W.ds2s_tot = a.add("bwd.ds2s_tot", {MD, R80});
+    W.gA = a.add("bwd.gA", {Mx, 16 * kCb});
+    W.gB = a.add("bwd.gB", {Mx, 16 * kCb});
+    W.gC = a.add("bwd.gC", {Mx, 6 * kCb});
+    W.gD = a.add("bwd.gD", {Mx, 2 * kCb});
+    W.gE = a.add("bwd.gE", {Mx, 2 * kCb});
+    W.gF = a.add("bwd.gF", {Mx, 2 * kCb});
+    W.gG = a.add("bwd.gG", {Mx, 2 * kCb});
+    W.scratch = a.add("bwd.scratch", {64});
+  } else {
+    W.ds2s = W.dout_pad = W.paramsT = W.gstash = W.dkeys = W.dvalues = W.ds2s_tot = -1;
+    W.gA = W.gB = W.gC = W.gD = W.gE = W.gF = W.gG = W.scratch = -1;
+  }
+  W.total = (a.off + 63) / 64 * 64;
+}

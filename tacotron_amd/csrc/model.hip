@@ -1,0 +1,623 @@
+// model.hip -- host-side orchestration of the Tacotron hot path on one GPU + the C ABI (include/taco_hip.h).
+// Every function only ENQUEUES work on the caller's stream: no allocation, no synchronisation.
+//
+//   taco_forward  = Tacotron.inference(train=True) + add_loss_op       (tacotron.py:107-165)
+//   taco_backward = opt.compute_gradients(loss)                        (tacotron.py:172)
+//   taco_infer    = Tacotron.inference(train=False)                    (tacotron.py:107-154, ops.py:5-25)
+#include <map>
+#include <mutex>
+#include <tuple>
+
+#include "common.h"
+#include "kernels.h"
+#include "layout.h"
+
+namespace {
+
+struct Layouts {
+  ParamLayout P;
+  TransLayout T;
+  WsLayout Wtrain, Winfer;
+};
+
+const Layouts& layouts_for(const TacoShape& s) {
+  static std::mutex mu;
+  static std::map<std::tuple<int, int, int, int, int>, Layouts*> cache;
+  std::lock_guard<std::mutex> g(mu);
+  auto key = std::make_tuple(s.B, s.Tt, s.Td, s.r, s.V);
+  auto it = cache.find(key);
+  if (it != cache.end()) return *it->second;
+  Layouts* L = new Layouts();
+  build_param_layout(s, L->P);
+  build_trans_layout(s, L->P, L->T);
+  build_ws_layout(s, true, L->T, L->Wtrain);
+  build_ws_layout(s, false, L->T, L->Winfer);
+  cache[key] = L;
+  return *L;
+}
+
+struct CbhgBufs {
+  float *bank, *pool, *pj1pre, *pj1, *pj2pre, *res, *adapt, *h[5], *th[4], *xg, *out, *ruc, *s_bank, *s_p1, *s_p2;
+};
+CbhgBufs cbhg_bufs(float* ws, const CbhgWs& w) {
+  CbhgBufs b;
+  b.bank = ws + w.bank; b.pool = ws + w.pool; b.pj1pre = ws + w.pj1pre; b.pj1 = ws + w.pj1; b.pj2pre = ws + w.pj2pre;
+  b.res = ws + w.res; b.adapt = w.adapt >= 0 ? ws + w.adapt : nullptr;
+  for (int l = 0; l < 5; ++l) b.h[l] = ws + w.h[l];
+  for (int l = 0; l < 4; ++l) b.th[l] = ws + w.th[l];
+  b.xg = ws + w.xg; b.out = ws + w.out; b.ruc = ws + w.ruc;
+  b.s_bank = ws + w.s_bank; b.s_p1 = ws + w.s_p1; b.s_p2 = ws + w.s_p2;
+  return b;
+}
+
+ConvGemmProblem dense_problem(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M,
+                              int N, int K, int act) {
+  ConvGemmProblem p;
+  p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.bias = bias; p.C = C; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K; p.taps = 1; p.T = M; p.pad_l = 0; p.act = act;
+  return p;
+}
+
+BiGruWeights bigru_weights(const float* P, const CbhgP& c) {
+  BiGruWeights w;
+  w.wg[0] = P + c.fw.wg; w.bg[0] = P + c.fw.bg; w.wc[0] = P + c.fw.wc; w.bc[0] = P + c.fw.bc;
+  w.wg[1] = P + c.bw.wg; w.bg[1] = P + c.bw.bg; w.wc[1] = P + c.bw.wc; w.bc[1] = P + c.bw.bc;
+  return w;
+}
+
+// ops.CBHG forward (ops.py:48-132).  x (B*T, cin).
+int cbhg_fwd(const float* P, const CbhgP& c, const float* x, int B, int T, const CbhgBufs& w, bool keep_ruc,
+             hipStream_t s) {
+  const int M = B * T, KC = c.K * kCb;
+  // conv bank: K 'same' convs + ReLU, concatenated on channels (ops.py:54-62) -- one batched launch
+  {
+    ConvGemmBatch batch;
+    batch.n = c.K;
+    for (int k = 1; k <= c.K; ++k) {
+      ConvGemmProblem& p = batch.p[k - 1];
+      p = ConvGemmProblem();
+      p.A = x; p.lda = c.cin; p.W = P + c.bank_w[k - 1]; p.ldw = kCb; p.bias = P + c.bank_b[k - 1];
+      p.C = w.bank + (k - 1) * kCb; p.ldc = KC; p.M = M; p.N = kCb; p.K = c.cin; p.taps = k; p.T = T;
+      p.pad_l = (k - 1) / 2; p.act = TACO_ACT_RELU;
+    }
+    TACO_TRY(launch_conv_gemm_batch(batch, s));
+  }
+  // BN-affine + max-pool(2,1,same) (ops.py:64-71)
+  TACO_TRY(launch_bn_maxpool(w.bank, P + c.bank_g, P + c.bank_be, w.pool, B, T, KC, s));
+  // conv projections (ops.py:75-87) + residual (ops.py:92)
+  TACO_TRY(launch_bn_fold(P + c.p1_g, w.s_p1, c.c1, s));
+  TACO_TRY(launch_bn_fold(P + c.p2_g, w.s_p2, c.c2, s));
+  {
+    ConvGemmProblem p;
+    p.A = w.pool; p.lda = KC; p.W = P + c.p1_w; p.ldw = c.c1; p.bias = P + c.p1_b; p.scale = w.s_p1; p.shift = P + c.p1_be;
+    p.C = w.pj1; p.Cpre = w.pj1pre; p.ldc = c.c1; p.M = M; p.N = c.c1; p.K = KC; p.taps = 3; p.T = T; p.pad_l = 1;
+    p.act = TACO_ACT_RELU;
+    TACO_TRY(launch_conv_gemm(p, s));
+  }
+  {
+    ConvGemmProblem p;
+    p.A = w.pj1; p.lda = c.c1; p.W = P + c.p2_w; p.ldw = c.c2; p.bias = P + c.p2_b; p.scale = w.s_p2; p.shift = P + c.p2_be;
+    p.residual = x; p.ldr = c.cin; p.C = w.res; p.Cpre = w.pj2pre; p.ldc = c.c2; p.M = M; p.N = c.c2; p.K = c.c1;
+    p.taps = 3; p.T = T; p.pad_l = 1; p.act = TACO_ACT_NONE;
+    TACO_TRY(launch_conv_gemm(p, s));
+  }
+  // highway x4 (ops.py:27-46, 97-107)
+  if (c.has_adapt)
+    TACO_TRY(launch_conv_gemm(dense_problem(w.res, c.c2, P + c.adapt.w, kCb, P + c.adapt.b, w.adapt, kCb, M, kCb, c.c2,
+                                            TACO_ACT_NONE), s));
+  for (int l = 0; l < 4; ++l) {
+    ConvGemmBatch batch;
+    batch.n = 2;
+    batch.p[0] = dense_problem(w.h[l], kCb, P + c.hwT[l].w, kCb, P + c.hwT[l].b, w.th[l], 2 * kCb, M, kCb, kCb, TACO_ACT_SIGMOID);
+    batch.p[1] = dense_problem(w.h[l], kCb, P + c.hwH[l].w, kCb, P + c.hwH[l].b, w.th[l] + kCb, 2 * kCb, M, kCb, kCb, TACO_ACT_RELU);
+    TACO_TRY(launch_conv_gemm_batch(batch, s));
+    TACO_TRY(launch_highway_combine(w.th[l], w.h[l], w.h[l + 1], M, s));
+  }
+  // bi-GRU: hoisted x-side projections (4 problems) + persistent recurrence (ops.py:117-128)
+  {
+    ConvGemmBatch batch;
+    batch.n = 4;
+    const GruP* g[2] = {&c.fw, &c.bw};
+    for (int d = 0; d < 2; ++d) {
+      batch.p[2 * d] = dense_problem(w.h[4], kCb, P + g[d]->wg, 2 * kCb, P + g[d]->bg, w.xg + d * 3 * kCb, 6 * kCb, M,
+                                     2 * kCb, kCb, TACO_ACT_NONE);
+      batch.p[2 * d + 1] = dense_problem(w.h[4], kCb, P + g[d]->wc, kCb, P + g[d]->bc, w.xg + d * 3 * kCb + 2 * kCb,
+                                         6 * kCb, M, kCb, kCb, TACO_ACT_NONE);
+    }
+    TACO_TRY(launch_conv_gemm_batch(batch, s));
+  }
+  TACO_TRY(launch_bigru_fwd(w.xg, bigru_weights(P, c), w.out, keep_ruc ? w.ruc : nullptr, B, T, s));
+  return TACO_OK;
+}
+
+DecWeights dec_weights(const float* P, const ParamLayout& L) {
+  DecWeights w;
+  w.pre_w1 = P + L.dec_pre1.w; w.pre_b1 = P + L.dec_pre1.b; w.pre_w2 = P + L.dec_pre2.w; w.pre_b2 = P + L.dec_pre2.b;
+  w.in_w = P + L.in_proj.w; w.in_b = P + L.in_proj.b;
+  for (int l = 0; l < 3; ++l) {
+    w.gw[l] = P + L.gru[l].wg; w.gb[l] = P + L.gru[l].bg; w.cw[l] = P + L.gru[l].wc; w.cb[l] = P + L.gru[l].bc;
+  }
+  w.out_w = P + L.out_proj.w; w.out_b = P + L.out_proj.b;
+  w.q_w = P + L.q_w; w.att_v = P + L.att_v; w.att_w = P + L.att_w;
+  return w;
+}
+
+// encoder + attention memory + decoder + post-net; shared by train and inference forward.
+int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const float* P, const int32_t* text,
+                 const int32_t* text_length, const float* mel, const uint8_t* ek1, const uint8_t* ek2, const uint8_t* dk1,
+                 const uint8_t* dk2, const uint8_t* sample, float* s2s, float* output, float* align, float* ws, bool train,
+                 hipStream_t s) {
+  const ParamLayout& PL = L.P;
+  const int B = sh.B, Tt = sh.Tt, Td = sh.Td, r = sh.r, R80 = kMel * r;
+  const int M1 = B * Tt, M2 = B * Td * r;
+  // embedding + encoder pre_net (tacotron.py:111-114, 128)
+  TACO_TRY(launch_embedding(P + PL.emb, text, ws + W.emb, M1, sh.V, s));
+  {
+    ConvGemmProblem p = dense_problem(ws + W.emb, kEmbed, P + PL.enc_pre1.w, kPre1, P + PL.enc_pre1.b, ws + W.p1, kPre1, M1,
+                                      kPre1, kEmbed, TACO_ACT_RELU);
+    p.keep = train ? ek1 : nullptr;
+    TACO_TRY(launch_conv_gemm(p, s));
+    ConvGemmProblem q = dense_problem(ws + W.p1, kPre1, P + PL.enc_pre2.w, kPre2, P + PL.enc_pre2.b, ws + W.p2, kPre2, M1,
+                                      kPre2, kPre1, TACO_ACT_RELU);
+    q.keep = train ? ek2 : nullptr;
+    TACO_TRY(launch_conv_gemm(q, s));
+  }
+  CbhgBufs eb = cbhg_bufs(ws, W.enc);
+  TACO_TRY(cbhg_fwd(P, PL.enc, ws + W.p2, B, Tt, eb, train, s));
+  // attention memory (BahdanauAttention.__init__; tacotron.py:48-52)
+  TACO_TRY(launch_mask_rows(eb.out, text_length, ws + W.values, B, Tt, kAtt, s));
+  TACO_TRY(launch_conv_gemm(dense_problem(ws + W.values, kAtt, P + PL.mem_w, kAtt, nullptr, ws + W.keys, kAtt, M1, kAtt,
+                                          2 * kCb, TACO_ACT_NONE), s));
+  // decoder (tacotron.py:134-138)
+  DecFwdArgs da;
+  da.w = dec_weights(P, PL);
+  da.keys = ws + W.keys; da.values = ws + W.values; da.text_length = text_length;
+  da.mel = train ? mel : nullptr;
+  da.keep1 = train ? dk1 : nullptr; da.keep2 = train ? dk2 : nullptr; da.sample = train ? sample : nullptr;
+  da.out = s2s; da.align = align;
+  da.stash = train ? ws + W.stash : nullptr;
+  da.prein = train ? ws + W.prein : nullptr;
+  da.B = B; da.Tt = Tt; da.Td = Td; da.r = r;
+  TACO_TRY(launch_decoder_fwd(da, s));
+  // post-net (tacotron.py:142-152): (B,Td,80r) reinterpreted as (B, Td*r, 80)
+  CbhgBufs pb = cbhg_bufs(ws, W.post);
+  TACO_TRY(cbhg_fwd(P, PL.post, s2s, B, Td * r, pb, train, s));
+  TACO_TRY(launch_conv_gemm(dense_problem(pb.out, 2 * kCb, P + PL.post_dense.w, kFft, P + PL.post_dense.b, output, kFft, M2,
+                                          kFft, 2 * kCb, TACO_ACT_NONE), s));
+  (void)R80;
+  return TACO_OK;
+}
+
+int tn(const float* A, int lda, int K, const float* Y, int ldy, int N, float* W, int ldw, int M, int T, int pad_l,
+       hipStream_t s, int taps = 1) {
+  GemmTnArgs a;
+  a.A = A; a.lda = lda; a.Y = Y; a.ldy = ldy; a.W = W; a.ldw = ldw; a.M = M; a.N = N; a.K = K; a.taps = taps; a.T = T;
+  a.pad_l = pad_l;
+  return launch_gemm_tn(a, false, s);
+}
+
+// Builds every transposed / flipped weight copy the backward pass needs.
+int prepare_transposes(const float* P, const ParamLayout& L, const TransLayout& T, float* PT, int r, hipStream_t s) {
+  const int R80 = kMel * r;
+  auto tr = [&](int64_t src, int64_t dst, int taps, int K, int N) { return launch_transpose_flip(P + src, PT + dst, taps, K, N, s); };
+  TACO_TRY(tr(L.enc_pre1.w, T.enc_pre1, 1, kEmbed, kPre1));
+  TACO_TRY(tr(L.enc_pre2.w, T.enc_pre2, 1, kPre1, kPre2));
+  const CbhgP* cp[2] = {&L.enc, &L.post};
+  const CbhgT* ct[2] = {&T.enc, &T.post};
+  for (int i = 0; i < 2; ++i) {
+    const CbhgP& c = *cp[i];
+    const CbhgT& t = *ct[i];
+    for (int k = 1; k <= c.K; ++k) TACO_TRY(tr(c.bank_w[k - 1], t.bank[k - 1], k, c.cin, kCb));
+    TACO_TRY(tr(c.p1_w, t.p1, 3, c.K * kCb, c.c1));
+    TACO_TRY(tr(c.p2_w, t.p2, 3, c.c1, c.c2));
+    if (c.has_adapt) TACO_TRY(tr(c.adapt.w, t.adapt, 1, c.c2, kCb));
+    for (int l = 0; l < 4; ++l) {
+      TACO_TRY(tr(c.hwT[l].w, t.hw[l], 1, kCb, kCb));
+      TACO_TRY(tr(c.hwH[l].w, t.hw[l] + kCb * kCb, 1, kCb, kCb));
+    }
+    const GruP* g[2] = {&c.fw, &c.bw};
+    for (int d = 0; d < 2; ++d) {
+      // x-parts: rows [0,128) of gates (128x256) and candidate (128x128) kernels
+      TACO_TRY(tr(g[d]->wg, t.gru_x + (int64_t)d * 3 * kCb * kCb, 1, kCb, 2 * kCb));
+      TACO_TRY(tr(g[d]->wc, t.gru_x + (int64_t)d * 3 * kCb * kCb + 2 * kCb * kCb, 1, kCb, kCb));
+      // h-parts: rows [128,256)
+      TACO_TRY(tr(g[d]->wg + (int64_t)kCb * 2 * kCb, t.wghT[d], 1, kCb, 2 * kCb));
+      TACO_TRY(tr(g[d]->wc + (int64_t)kCb * kCb, t.wchT[d], 1, kCb, kCb));
+    }
+  }
+  TACO_TRY(tr(L.mem_w, T.mem_w, 1, 2 * kCb, kAtt));
+  TACO_TRY(tr(L.dec_pre1.w, T.dec_pre1, 1, kMel, kPre1));
+  TACO_TRY(tr(L.dec_pre2.w, T.dec_pre2, 1, kPre1, kPre2));
+  TACO_TRY(tr(L.in_proj.w, T.in_proj, 1, kPre2 + kAtt, kDec));
+  for (int l = 0; l < 3; ++l) {
+    TACO_TRY(tr(L.gru[l].wg, T.gw[l], 1, 2 * kDec, 2 * kDec));
+    TACO_TRY(tr(L.gru[l].wc, T.cw[l], 1, 2 * kDec, kDec));
+  }
+  TACO_TRY(tr(L.out_proj.w, T.out_proj, 1, kDec, R80));
+  TACO_TRY(tr(L.q_w, T.q_w, 1, R80, kAtt));
+  TACO_TRY(tr(L.att_w, T.att_w, 1, R80 + kAtt, kAtt));
+  TACO_TRY(tr(L.post_dense.w, T.post_dense, 1, 2 * kCb, kFft));
+  return TACO_OK;
+}
+
+struct BwdScratch {
+  float *gA, *gB, *gC, *gD, *gE, *gF, *gG;
+};
+
+// CBHG backward.  dOut (M,256) -> dX (M,cin) written to `dx_out`; parameter gradients accumulated into G.
+// x is the CBHG input.  Scratch: gA/gB (M, K*128), gC (M,768), gD..gG (M,256).
+int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const CbhgT& t, const float* x, const float* dOut,
+             int B, int T, const CbhgBufs& w, const BwdScratch& sc, float* dx_out, hipStream_t s) {
+  const int M = B * T, KC = c.K * kCb;
+  // ---- bi-GRU ----
+  float* dxg = sc.gC;   // (M,768)
+  float* rh = sc.gD;    // (M,256)
+  BiGruBwdWeights bw;
+  for (int d = 0; d < 2; ++d) {
+    bw.wghT[d] = PT + t.wghT[d];
+    bw.wchT[d] = PT + t.wchT[d];
+  }
+  TACO_TRY(launch_bigru_bwd(dOut, w.out, w.ruc, bw, dxg, rh, B, T, s));
+  const GruP* g[2] = {&c.fw, &c.bw};
+  for (int d = 0; d < 2; ++d) {
+    const float* dG = dxg + d * 3 * kCb;
+    const float* dC = dG + 2 * kCb;
+    TACO_TRY(tn(w.h[4], kCb, kCb, dG, 6 * kCb, 2 * kCb, G + g[d]->wg, 2 * kCb, M, T, 0, s));
+    TACO_TRY(tn(w.out + d * kCb, 2 * kCb, kCb, dG, 6 * kCb, 2 * kCb, G + g[d]->wg + (int64_t)kCb * 2 * kCb, 2 * kCb, M, T,
+                d == 0 ? 1 : -1, s));
+    TACO_TRY(tn(w.h[4], kCb, kCb, dC, 6 * kCb, kCb, G + g[d]->wc, kCb, M, T, 0, s));
+    TACO_TRY(tn(rh + d * kCb, 2 * kCb, kCb, dC, 6 * kCb, kCb, G + g[d]->wc + (int64_t)kCb * kCb, kCb, M, T, 0, s));
+    TACO_TRY(launch_colsum(dG, 6 * kCb, G + g[d]->bg, M, 2 * kCb, s));
+    TACO_TRY(launch_colsum(dC, 6 * kCb, G + g[d]->bc, M, kCb, s));
+  }
+  float* gh = sc.gE;     // (M,128) gradient wrt current highway output
+  float* gh2 = sc.gF;    // ping-pong
+  TACO_TRY(launch_conv_gemm(dense_problem(dxg, 6 * kCb, PT + t.gru_x, kCb, nullptr, gh, kCb, M, kCb, 6 * kCb, TACO_ACT_NONE), s));
+  // ---- highway layers 3..0 ----
+  float* dth = sc.gD;    // (M,256) (rh no longer needed)
+  float* dxd = sc.gG;    // (M,128)
+  for (int l = 3; l >= 0; --l) {
+    TACO_TRY(launch_highway_combine_bwd(w.th[l], w.h[l], gh, dth, dxd, M, s));
+    TACO_TRY(tn(w.h[l], kCb, kCb, dth, 2 * kCb, kCb, G + c.hwT[l].w, kCb, M, M, 0, s));
+    TACO_TRY(tn(w.h[l], kCb, kCb, dth + kCb, 2 * kCb, kCb, G + c.hwH[l].w, kCb, M, M, 0, s));
+    TACO_TRY(launch_colsum(dth, 2 * kCb, G + c.hwT[l].b, M, kCb, s));
+    TACO_TRY(launch_colsum(dth + kCb, 2 * kCb, G + c.hwH[l].b, M, kCb, s));
+    ConvGemmProblem p = dense_problem(dth, 2 * kCb, PT + t.hw[l], kCb, nullptr, gh2, kCb, M, kCb, 2 * kCb, TACO_ACT_NONE);
+    p.residual = dxd;
+    p.ldr = kCb;
+    TACO_TRY(launch_conv_gemm(p, s));
+    float* tmp = gh; gh = gh2; gh2 = tmp;
+  }
+  // ---- adapt dense (post-net only) ----
+  float* dres = gh;      // (M, c2) gradient wrt `res`
+  if (c.has_adapt) {
+    TACO_TRY(tn(w.res, c.c2, c.c2, gh, kCb, kCb, G + c.adapt.w, kCb, M, M, 0, s));
+    TACO_TRY(launch_colsum(gh, kCb, G + c.adapt.b, M, kCb, s));
+    TACO_TRY(launch_conv_gemm(dense_problem(gh, kCb, PT + t.adapt, c.c2, nullptr, gh2, c.c2, M, c.c2, kCb, TACO_ACT_NONE), s));
+    dres = gh2;
+  }
+  // ---- res = bn(conv(pj1)) + x ----
+  float* dz2 = sc.gG;    // (M,c2)
+  TACO_TRY(launch_affine_act_bwd(w.pj2pre, P + c.p2_g, dres, dz2, G + c.p2_g, G + c.p2_be, M, c.c2, TACO_ACT_NONE, s));
+  TACO_TRY(tn(w.pj1, c.c1, c.c1, dz2, c.c2, c.c2, G + c.p2_w, c.c2, M, T, 1, s, 3));
+  TACO_TRY(launch_colsum(dz2, c.c2, G + c.p2_b, M, c.c2, s));
+  float* dpj1 = sc.gD;   // (M,c1)
+  {
+    ConvGemmProblem p;
+    p.A = dz2; p.lda = c.c2; p.W = PT + t.p2; p.ldw = c.c1; p.C = dpj1; p.ldc = c.c1; p.M = M; p.N = c.c1; p.K = c.c2;
+    p.taps = 3; p.T = T; p.pad_l = 1; p.act = TACO_ACT_NONE;
+    TACO_TRY(launch_conv_gemm(p, s));
+  }
+  float* dz1 = sc.gC;    // (M,c1)  (dxg no longer needed)
+  TACO_TRY(launch_affine_act_bwd(w.pj1pre, P + c.p1_g, dpj1, dz1, G + c.p1_g, G + c.p1_be, M, c.c1, TACO_ACT_RELU, s));
+  TACO_TRY(tn(w.pool, KC, KC, dz1, c.c1, c.c1, G + c.p1_w, c.c1, M, T, 1, s, 3));
+  TACO_TRY(launch_colsum(dz1, c.c1, G + c.p1_b, M, c.c1, s));
+  float* dpool = sc.gA;  // (M,KC)
+  {
+    ConvGemmProblem p;
+    p.A = dz1; p.lda = c.c1; p.W = PT + t.p1; p.ldw = KC; p.C = dpool; p.ldc = KC; p.M = M; p.N = KC; p.K = c.c1;
+    p.taps = 3; p.T = T; p.pad_l = 1; p.act = TACO_ACT_NONE;
+    TACO_TRY(launch_conv_gemm(p, s));
+  }
+  float* dbank = sc.gB;  // (M,KC)
+  TACO_TRY(launch_bn_maxpool_bwd(w.bank, P + c.bank_g, P + c.bank_be, dpool, dbank, G + c.bank_g, G + c.bank_be, B, T, KC, s));
+  TACO_TRY(launch_act_bwd(w.bank, dbank, nullptr, dbank, (int64_t)M * KC, TACO_ACT_RELU, s));
+  // ---- conv bank: weight/bias grads per width, input grad chained through `residual` ----
+  const float* acc = dres;  // residual connection: d res / d x = identity (c2 == cin)
+  int ldacc = c.c2;
+  float* pp[2] = {sc.gE, sc.gF};
+  // dres may live in gE or gF; ping-pong between the other one and gD
+  float* o0 = (dres == sc.gE) ? sc.gF : sc.gE;
+  float* o1 = sc.gD;
+  (void)pp;
+  for (int k = 1; k <= c.K; ++k) {
+    const float* dzk = dbank + (k - 1) * kCb;
+    TACO_TRY(tn(x, c.cin, c.cin, dzk, KC, kCb, G + c.bank_w[k - 1], kCb, M, T, (k - 1) / 2, s, k));
+    TACO_TRY(launch_colsum(dzk, KC, G + c.bank_b[k - 1], M, kCb, s));
+    ConvGemmProblem p;
+    float* outk = (k == c.K) ? dx_out : ((k & 1) ? o0 : o1);
+    p.A = dzk; p.lda = KC; p.W = PT + t.bank[k - 1]; p.ldw = c.cin; p.C = outk; p.ldc = c.cin; p.M = M; p.N = c.cin; p.K = kCb;
+    p.taps = k; p.T = T; p.pad_l = (k - 1) - (k - 1) / 2; p.act = TACO_ACT_NONE;
+    p.residual = acc; p.ldr = ldacc;
+    TACO_TRY(launch_conv_gemm(p, s));
+    acc = outk;
+    ldacc = c.cin;
+  }
+  return TACO_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int64_t taco_param_count(const TacoShape* shape) {
+  if (validate_shape(shape) != TACO_OK) return TACO_EINVAL;
+  return layouts_for(*shape).P.total;
+}
+
+static int copy_rows(const std::vector<TacoTensorInfo>& src, TacoTensorInfo* rows, int cap) {
+  const int n = (int)src.size();
+  if (rows)
+    for (int i = 0; i < n && i < cap; ++i) rows[i] = src[i];
+  return n;
+}
+
+extern "C" int taco_param_table(const TacoShape* shape, TacoTensorInfo* rows, int cap) {
+  TACO_TRY(validate_shape(shape));
+  return copy_rows(layouts_for(*shape).P.rows, rows, cap);
+}
+
+extern "C" int64_t taco_workspace_bytes(const TacoShape* shape, int train) {
+  if (validate_shape(shape) != TACO_OK) return TACO_EINVAL;
+  const Layouts& L = layouts_for(*shape);
+  return (train ? L.Wtrain.total : L.Winfer.total) * (int64_t)sizeof(float);
+}
+
+extern "C" int taco_workspace_table(const TacoShape* shape, int train, TacoTensorInfo* rows, int cap) {
+  TACO_TRY(validate_shape(shape));
+  const Layouts& L = layouts_for(*shape);
+  return copy_rows(train ? L.Wtrain.rows : L.Winfer.rows, rows, cap);
+}
+
+extern "C" int taco_forward(const TacoShape* shape, const float* params, const int32_t* text, const int32_t* text_length,
+                            const float* mel, const float* stft, const uint8_t* enc_keep1, const uint8_t* enc_keep2,
+                            const uint8_t* dec_keep1, const uint8_t* dec_keep2, const uint8_t* sample,
+                            float* seq2seq_output, float* output, float* alignments, float* loss, void* workspace,
+                            void* stream) {
+  TACO_TRY(validate_shape(shape));
+  TACO_REQUIRE(params && text && text_length && mel && stft && seq2seq_output && output && alignments && loss && workspace,
+               "taco_forward: null pointer argument");
+  const Layouts& L = layouts_for(*shape);
+  const WsLayout& W = L.Wtrain;
+  float* ws = static_cast<float*>(workspace);
+  hipStream_t s = as_stream(stream);
+  TACO_TRY(forward_impl(*shape, L, W, params, text, text_length, mel, enc_keep1, enc_keep2, dec_keep1, dec_keep2, sample,
+                        seq2seq_output, output, alignments, ws, true, s));
+  // add_loss_op (tacotron.py:156-165) + sign gradients for the backward pass
+  const int R80 = kMel * shape->r;
+  const int64_t MD = (int64_t)shape->B * shape->Td, M2 = MD * shape->r;
+  hipError_t e = hipMemsetAsync(ws + W.loss, 0, 4 * sizeof(float), s);
+  if (e != hipSuccess) {
+    taco_set_error("taco_forward: memset: %s", hipGetErrorString(e));
+    return TACO_ELAUNCH;
+  }
+  TACO_TRY(launch_l1(seq2seq_output, mel, ws + W.ds2s, R80, ws + W.loss + 1, MD, R80, s));
+  TACO_TRY(launch_l1(output, stft, ws + W.dout_pad, 1028, ws + W.loss + 2, M2, kFft, s));
+  TACO_TRY(launch_finish_loss(ws + W.loss, s));
+  e = hipMemcpyAsync(loss, ws + W.loss, 3 * sizeof(float), hipMemcpyDeviceToDevice, s);
+  if (e != hipSuccess) {
+    taco_set_error("taco_forward: memcpy: %s", hipGetErrorString(e));
+    return TACO_ELAUNCH;
+  }
+  return TACO_OK;
+}
+
+extern "C" int taco_infer(const TacoShape* shape, const float* params, const int32_t* text, const int32_t* text_length,
+                          float* seq2seq_output, float* output, float* alignments, void* workspace, void* stream) {
+  TACO_TRY(validate_shape(shape));
+  TACO_REQUIRE(params && text && text_length && seq2seq_output && output && alignments && workspace,
+               "taco_infer: null pointer argument");
+  const Layouts& L = layouts_for(*shape);
+  return forward_impl(*shape, L, L.Winfer, params, text, text_length, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                      seq2seq_output, output, alignments, static_cast<float*>(workspace), false, as_stream(stream));
+}
+
+
+extern "C" int taco_backward(const TacoShape* shape, const float* params, const int32_t* text, const int32_t* text_length,
+                             const float* seq2seq_output, const float* alignments, const uint8_t* enc_keep1,
+                             const uint8_t* enc_keep2, const uint8_t* dec_keep1, const uint8_t* dec_keep2,
+                             const uint8_t* sample, float* grads, void* workspace, void* stream) {
+  TACO_TRY(validate_shape(shape));
+  TACO_REQUIRE(params && text && text_length && seq2seq_output && alignments && grads && workspace,
+               "taco_backward: null pointer argument");
+  const Layouts& L = layouts_for(*shape);
+  const ParamLayout& PL = L.P;
+  const TransLayout& TL = L.T;
+  const WsLayout& W = L.Wtrain;
+  float* ws = static_cast<float*>(workspace);
+  float* G = grads;
+  const float* P = params;
+  hipStream_t s = as_stream(stream);
+  const int B = shape->B, Tt = shape->Tt, Td = shape->Td, r = shape->r, R80 = kMel * r;
+  const int M1 = B * Tt, MD = B * Td, M2 = MD * r, F = Td * r;
+  float* PT = ws + W.paramsT;
+
+  hipError_t e = hipMemsetAsync(G, 0, (size_t)PL.total * sizeof(float), s);
+  if (e == hipSuccess) e = hipMemsetAsync(ws + W.dkeys, 0, (size_t)M1 * kAtt * sizeof(float), s);
+  if (e == hipSuccess) e = hipMemsetAsync(ws + W.dvalues, 0, (size_t)M1 * kAtt * sizeof(float), s);
+  if (e != hipSuccess) {
+    taco_set_error("taco_backward: memset: %s", hipGetErrorString(e));
+    return TACO_ELAUNCH;
+  }
+  TACO_TRY(prepare_transposes(P, PL, TL, PT, r, s));
+  BwdScratch sc{ws + W.gA, ws + W.gB, ws + W.gC, ws + W.gD, ws + W.gE, ws + W.gF, ws + W.gG};
+  CbhgBufs pb = cbhg_bufs(ws, W.post), eb = cbhg_bufs(ws, W.enc);
+
+  // ---- final dense (tacotron.py:148): output = post_out . Wd + bd ----
+  const float* dOutPad = ws + W.dout_pad;  // (M2, 1028) = sign(output - stft), written by taco_forward
+  TACO_TRY(tn(pb.out, 2 * kCb, 2 * kCb, dOutPad, 1028, kFft, G + PL.post_dense.w, kFft, M2, M2, 0, s));
+  TACO_TRY(launch_colsum(dOutPad, 1028, G + PL.post_dense.b, M2, kFft, s));
+  float* dPostOut = sc.gG;  // (M2,256); consumed by the bi-GRU backward before gG is reused
+  TACO_TRY(launch_conv_gemm(dense_problem(dOutPad, 1028, PT + TL.post_dense, 2 * kCb, nullptr, dPostOut, 2 * kCb, M2, 2 * kCb,
+                                          kFft, TACO_ACT_NONE), s));
+  // ---- post-net CBHG (input = seq2seq_output viewed as (B, Td*r, 80)) ----
+  float* dPostIn = sc.gC;   // (M2, 80)
+  TACO_TRY(cbhg_bwd(P, PT, G, PL.post, TL.post, seq2seq_output, dPostOut, B, F, pb, sc, dPostIn, s));
+  // d seq2seq_output = sign(s2s - mel) + post-net path
+  float* dS2S = ws + W.ds2s_tot;
+  TACO_TRY(launch_add(ws + W.ds2s, dPostIn, dS2S, (int64_t)MD * R80, s));
+
+  // ---- decoder BPTT ----
+  float* gs = ws + W.gstash;
+  const float* st = ws + W.stash;
+  {
+    DecBwdArgs a;
+    DecWeights& w = a.wT;
+    w.pre_w1 = PT + TL.dec_pre1; w.pre_w2 = PT + TL.dec_pre2; w.in_w = PT + TL.in_proj;
+    w.pre_b1 = w.pre_b2 = w.in_b = w.out_b = nullptr;
+    for (int l = 0; l < 3; ++l) {
+      w.gw[l] = PT + TL.gw[l]; w.cw[l] = PT + TL.cw[l]; w.gb[l] = w.cb[l] = nullptr;
+    }
+    w.out_w = PT + TL.out_proj; w.q_w = PT + TL.q_w; w.att_w = PT + TL.att_w; w.att_v = P + PL.att_v;
+    a.att_v = P + PL.att_v;
+    a.keys = ws + W.keys; a.values = ws + W.values; a.text_length = text_length;
+    a.keep1 = dec_keep1; a.keep2 = dec_keep2; a.sample = sample;
+    a.dout = dS2S; a.out = seq2seq_output; a.align = alignments; a.stash = st; a.gstash = gs;
+    a.dkeys = ws + W.dkeys; a.datt_v = G + PL.att_v;
+    a.B = B; a.Tt = Tt; a.Td = Td; a.r = r;
+    TACO_TRY(launch_decoder_bwd(a, s));
+  }
+  // ---- decoder weight gradients: dense GEMMs over the B*Td stashed rows ----
+  {
+    const float* prein = ws + W.prein;
+    TACO_TRY(tn(prein, kMel, kMel, gs + kGsP1, kGsRec, kPre1, G + PL.dec_pre1.w, kPre1, MD, Td, 0, s));
+    TACO_TRY(launch_colsum(gs + kGsP1, kGsRec, G + PL.dec_pre1.b, MD, kPre1, s));
+    TACO_TRY(tn(st + kStP1, kStRec, kPre1, gs + kGsP2, kGsRec, kPre2, G + PL.dec_pre2.w, kPre2, MD, Td, 0, s));
+    TACO_TRY(launch_colsum(gs + kGsP2, kGsRec, G + PL.dec_pre2.b, MD, kPre2, s));
+    // in-proj: rows [0,128) pre-net output of step t, rows [128,384) attention of step t-1
+    TACO_TRY(tn(st + kStP2, kStRec, kPre2, gs + kGsX, kGsRec, kDec, G + PL.in_proj.w, kDec, MD, Td, 0, s));
+    TACO_TRY(tn(st + kStAtt, kStRec, kAtt, gs + kGsX, kGsRec, kDec, G + PL.in_proj.w + (int64_t)kPre2 * kDec, kDec, MD, Td, 1, s));
+    TACO_TRY(launch_colsum(gs + kGsX, kGsRec, G + PL.in_proj.b, MD, kDec, s));
+    for (int l = 0; l < 3; ++l) {
+      const float* inp = l == 0 ? st + kStX : st + kStH + (l - 1) * kDec;
+      const float* dG = gs + kGsG + l * 512;
+      const float* dC = gs + kGsC + l * kDec;
+      TACO_TRY(tn(inp, kStRec, kDec, dG, kGsRec, 2 * kDec, G + PL.gru[l].wg, 2 * kDec, MD, Td, 0, s));
+      TACO_TRY(tn(st + kStH + l * kDec, kStRec, kDec, dG, kGsRec, 2 * kDec, G + PL.gru[l].wg + (int64_t)kDec * 2 * kDec, 2 * kDec,
+                  MD, Td, 1, s));
+      TACO_TRY(tn(inp, kStRec, kDec, dC, kGsRec, kDec, G + PL.gru[l].wc, kDec, MD, Td, 0, s));
+      TACO_TRY(tn(st + kStRH + l * kDec, kStRec, kDec, dC, kGsRec, kDec, G + PL.gru[l].wc + (int64_t)kDec * kDec, kDec, MD, Td, 0, s));
+      TACO_TRY(launch_colsum(dG, kGsRec, G + PL.gru[l].bg, MD, 2 * kDec, s));
+      TACO_TRY(launch_colsum(dC, kGsRec, G + PL.gru[l].bc, MD, kDec, s));
+    }
+    TACO_TRY(tn(st + kStY, kStRec, kDec, gs + kGsO, kGsRec, R80, G + PL.out_proj.w, R80, MD, Td, 0, s));
+    TACO_TRY(launch_colsum(gs + kGsO, kGsRec, G + PL.out_proj.b, MD, R80, s));
+    TACO_TRY(tn(seq2seq_output, R80, R80, gs + kGsQ, kGsRec, kAtt, G + PL.q_w, kAtt, MD, Td, 0, s));
+    TACO_TRY(tn(seq2seq_output, R80, R80, gs + kGsAtt, kGsRec, kAtt, G + PL.att_w, kAtt, MD, Td, 0, s));
+    TACO_TRY(tn(st + kStCtx, kStRec, kAtt, gs + kGsAtt, kGsRec, kAtt, G + PL.att_w + (int64_t)R80 * kAtt, kAtt, MD, Td, 0, s));
+  }
+  // ---- attention memory: dvalues[b] = alignments[b]^T . dctx[b] ; keys = values . Wm ----
+  {
+    GemmTnArgs a;
+    a.A = alignments; a.lda = Tt; a.Y = gs + kGsCtx; a.ldy = kGsRec; a.W = ws + W.dvalues; a.ldw = kAtt;
+    a.M = Td; a.N = kAtt; a.K = Tt; a.taps = 1; a.T = Td; a.pad_l = 0; a.batch = B;
+    a.strideA = (int64_t)Td * Tt; a.strideY = (int64_t)Td * kGsRec; a.strideW = (int64_t)Tt * kAtt;
+    TACO_TRY(launch_gemm_tn(a, false, s));
+  }
+  TACO_TRY(tn(ws + W.values, kAtt, 2 * kCb, ws + W.dkeys, kAtt, kAtt, G + PL.mem_w, kAtt, M1, M1, 0, s));
+  float* dValTot = sc.gE;   // (M1,256)
+  {
+    ConvGemmProblem p = dense_problem(ws + W.dkeys, kAtt, PT + TL.mem_w, 2 * kCb, nullptr, dValTot, 2 * kCb, M1, 2 * kCb, kAtt,
+                                      TACO_ACT_NONE);
+    p.residual = ws + W.dvalues;
+    p.ldr = kAtt;
+    TACO_TRY(launch_conv_gemm(p, s));
+  }
+  float* dEnc = sc.gG;      // (M1,256)
+  TACO_TRY(launch_mask_rows(dValTot, text_length, dEnc, B, Tt, 2 * kCb, s));
+  // ---- encoder CBHG ----
+  float* dP2 = sc.gC;       // (M1,128)
+  TACO_TRY(cbhg_bwd(P, PT, G, PL.enc, TL.enc, ws + W.p2, dEnc, B, Tt, eb, sc, dP2, s));
+  // ---- encoder pre_net + embedding ----
+  float* dz2 = sc.gD;
+  TACO_TRY(launch_act_bwd(ws + W.p2, dP2, enc_keep2, dz2, (int64_t)M1 * kPre2, TACO_ACT_RELU, s));
+  TACO_TRY(tn(ws + W.p1, kPre1, kPre1, dz2, kPre2, kPre2, G + PL.enc_pre2.w, kPre2, M1, M1, 0, s));
+  TACO_TRY(launch_colsum(dz2, kPre2, G + PL.enc_pre2.b, M1, kPre2, s));
+  float* dz1 = sc.gE;
+  TACO_TRY(launch_conv_gemm(dense_problem(dz2, kPre2, PT + TL.enc_pre2, kPre1, nullptr, dz1, kPre1, M1, kPre1, kPre2,
+                                          TACO_ACT_NONE), s));
+  TACO_TRY(launch_act_bwd(ws + W.p1, dz1, enc_keep1, dz1, (int64_t)M1 * kPre1, TACO_ACT_RELU, s));
+  TACO_TRY(tn(ws + W.emb, kEmbed, kEmbed, dz1, kPre1, kPre1, G + PL.enc_pre1.w, kPre1, M1, M1, 0, s));
+  TACO_TRY(launch_colsum(dz1, kPre1, G + PL.enc_pre1.b, M1, kPre1, s));
+  float* dEmb = sc.gF;
+  TACO_TRY(launch_conv_gemm(dense_problem(dz1, kPre1, PT + TL.enc_pre1, kEmbed, nullptr, dEmb, kEmbed, M1, kEmbed, kPre1,
+                                          TACO_ACT_NONE), s));
+  TACO_TRY(launch_embedding_bwd(dEmb, text, G + PL.emb, M1, shape->V, s));
+  return TACO_OK;
+}
+
+extern "C" int taco_conv_gemm(const float* A, int lda, const float* W, int ldw, const float* bias, const float* scale,
+                              const float* shift, const float* residual, int ldr, const uint8_t* keep, float* C, int ldc,
+                              float* Cpre, int M, int N, int K, int taps, int T, int pad_l, int act, void* stream) {
+  ConvGemmProblem p;
+  p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.bias = bias; p.scale = scale; p.shift = shift; p.residual = residual;
+  p.ldr = ldr; p.keep = keep; p.C = C; p.ldc = ldc; p.Cpre = Cpre; p.M = M; p.N = N; p.K = K; p.taps = taps; p.T = T;
+  p.pad_l = pad_l; p.act = act;
+  return launch_conv_gemm(p, as_stream(stream));
+}
+
+extern "C" int taco_gemm_tn(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, int M, int N, int K,
+                            int taps, int T, int pad_l, int accumulate, void* stream) {
+  GemmTnArgs a;
+  a.A = A; a.lda = lda; a.Y = dY; a.ldy = ldy; a.W = dW; a.ldw = ldw; a.M = M; a.N = N; a.K = K; a.taps = taps; a.T = T;
+  a.pad_l = pad_l;
+  return launch_gemm_tn(a, accumulate == 0, as_stream(stream));
+}
+
+extern "C" int taco_debug_gemm_naive(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc,
+                                     int M, int N, int K, int taps, int T, int pad_l, int act, void* stream) {
+  TACO_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0 && taps > 0 && T > 0, "gemm_naive: bad arguments");
+  ConvGemmProblem p;
+  p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.bias = bias; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.taps = taps;
+  p.T = T; p.pad_l = pad_l; p.act = act;
+  return launch_gemm_naive(p, as_stream(stream));
+}
+
+extern "C" int taco_bigru_fwd(const float* x, const float* wg_fw, const float* bg_fw, const float* wc_fw, const float* bc_fw,
+                              const float* wg_bw, const float* bg_bw, const float* wc_bw, const float* bc_bw, float* xg,
+                              float* out, float* ruc, int B, int T, void* stream) {
+  TACO_REQUIRE(x && wg_fw && bg_fw && wc_fw && bc_fw && wg_bw && bg_bw && wc_bw && bc_bw && xg && out,
+               "bigru_fwd: null pointer argument");
+  hipStream_t s = as_stream(stream);
+  const int M = B * T;
+  BiGruWeights w;
+  w.wg[0] = wg_fw; w.bg[0] = bg_fw; w.wc[0] = wc_fw; w.bc[0] = bc_fw;
+  w.wg[1] = wg_bw; w.bg[1] = bg_bw; w.wc[1] = wc_bw; w.bc[1] = bc_bw;
+  ConvGemmBatch batch;
+  batch.n = 4;
+  for (int d = 0; d < 2; ++d) {
+    batch.p[2 * d] = dense_problem(x, kCb, w.wg[d], 2 * kCb, w.bg[d], xg + d * 3 * kCb, 6 * kCb, M, 2 * kCb, kCb, TACO_ACT_NONE);
+    batch.p[2 * d + 1] = dense_problem(x, kCb, w.wc[d], kCb, w.bc[d], xg + d * 3 * kCb + 2 * kCb, 6 * kCb, M, kCb, kCb, TACO_ACT_NONE);
+  }
+  TACO_TRY(launch_conv_gemm_batch(batch, s));
+  return launch_bigru_fwd(xg, w, out, ruc, B, T, s);
+}
+
+extern "C" int taco_clip_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float cap,
+                                   int64_t step, float* scratch, float* gnorm_out, void* stream) {
+  TACO_REQUIRE(params && grads && m && v && scratch && n > 0 && step >= 1, "clip_adam_step: bad arguments");
+  hipStream_t s = as_stream(stream);
+  hipError_t e = hipMemsetAsync(scratch, 0, 8 * sizeof(float), s);
+  if (e != hipSuccess) {
+    taco_set_error("clip_adam_step: memset: %s", hipGetErrorString(e));
+    return TACO_ELAUNCH;
+  }
+  TACO_TRY(launch_sumsq(grads, n, scratch, s));
+  return launch_clip_adam(params, grads, m, v, n, lr, cap, step, scratch, gnorm_out, s);
+}
+
+extern "C" int taco_fill_bernoulli(uint8_t* out, int64_t n, float p_one, uint64_t seed, void* stream) {
+  TACO_REQUIRE(out && n > 0, "fill_bernoulli: bad arguments");
+  return launch_bernoulli(out, n, p_one, seed, as_stream(stream));
+}
