@@ -129,6 +129,14 @@ int taco_clip_adam_step(float* params, const float* grads, float* m, float* v, i
 /* Bernoulli(p_keep) bytes from a counter-based hash RNG (replaces TF's dropout / Bernoulli sampler state). */
 int taco_fill_bernoulli(uint8_t* out, int64_t n, float p_one, uint64_t seed, void* stream);
 
+/* ---- measurement --------------------------------------------------------------------------------------------- */
+/* When enabled, every launch of the two persistent decoder kernels (the dominant kernels of a train step) is bracketed
+ * by hipEventRecord on the launch stream (a ring of 1024 event pairs per kernel; no synchronisation).
+ * taco_profile_read synchronises on the recorded events, writes up to `cap` elapsed times in milliseconds to the HOST
+ * array `ms` (oldest first), clears the ring and returns the count.  which: 0 = decoder forward, 1 = decoder backward. */
+int taco_profile_enable(int on);
+int taco_profile_read(int which, float* ms, int cap);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

@@ -172,7 +172,7 @@ def loss_and_grads(pnp, inputs_np, r, n_steps, masks_np=None, dtype=torch.float6
     loss = loss_fn(s2s, out, inputs['mel'], inputs['stft'])
     loss.backward()
     grads = {k: (t.grad.numpy() if t.grad is not None else None) for k, t in p.items()}
-    return float(loss), s2s.detach().numpy(), out.detach().numpy(), al.detach().numpy(), grads
+    return float(loss.detach()), s2s.detach().numpy(), out.detach().numpy(), al.detach().numpy(), grads
 
 
 def clip_adam_step(params, grads, m, v, step, lr, cap=5.0, b1=0.9, b2=0.999, eps=1e-8):

@@ -36,6 +36,37 @@ const Layouts& layouts_for(const TacoShape& s) {
   return *L;
 }
 
+
+// ---- HIP-event profiling ring for the dominant kernels (taco_profile_enable / taco_profile_read) ----
+struct ProfRing {
+  static constexpr int kCap = 1024;
+  hipEvent_t start[kCap], stop[kCap];
+  bool created = false;
+  int n = 0;
+};
+ProfRing g_prof[2];
+bool g_prof_on = false;
+
+int prof_begin(int which, hipStream_t s) {
+  if (!g_prof_on) return -1;
+  ProfRing& r = g_prof[which];
+  if (!r.created) {
+    for (int i = 0; i < ProfRing::kCap; ++i) {
+      if (hipEventCreate(&r.start[i]) != hipSuccess || hipEventCreate(&r.stop[i]) != hipSuccess) return -1;
+    }
+    r.created = true;
+  }
+  if (r.n >= ProfRing::kCap) return -1;
+  hipEventRecord(r.start[r.n], s);
+  return r.n;
+}
+void prof_end(int which, int slot, hipStream_t s) {
+  if (slot < 0) return;
+  ProfRing& r = g_prof[which];
+  hipEventRecord(r.stop[slot], s);
+  r.n = slot + 1;
+}
+
 struct CbhgBufs {
   float *bank, *pool, *pj1pre, *pj1, *pj2pre, *res, *adapt, *h[5], *th[4], *xg, *out, *ruc, *s_bank, *s_p1, *s_p2;
 };
@@ -178,7 +209,11 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
   da.stash = train ? ws + W.stash : nullptr;
   da.prein = train ? ws + W.prein : nullptr;
   da.B = B; da.Tt = Tt; da.Td = Td; da.r = r;
-  TACO_TRY(launch_decoder_fwd(da, s));
+  {
+    const int slot = prof_begin(0, s);
+    TACO_TRY(launch_decoder_fwd(da, s));
+    prof_end(0, slot, s);
+  }
   // post-net (tacotron.py:142-152): (B,Td,80r) reinterpreted as (B, Td*r, 80)
   CbhgBufs pb = cbhg_bufs(ws, W.post);
   TACO_TRY(cbhg_fwd(P, PL.post, s2s, B, Td * r, pb, train, s));
@@ -486,7 +521,9 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     a.dout = dS2S; a.out = seq2seq_output; a.align = alignments; a.stash = st; a.gstash = gs;
     a.dkeys = ws + W.dkeys; a.datt_v = G + PL.att_v;
     a.B = B; a.Tt = Tt; a.Td = Td; a.r = r;
+    const int slot = prof_begin(1, s);
     TACO_TRY(launch_decoder_bwd(a, s));
+    prof_end(1, slot, s);
   }
   // ---- decoder weight gradients: dense GEMMs over the B*Td stashed rows ----
   {
@@ -620,4 +657,24 @@ extern "C" int taco_clip_adam_step(float* params, const float* grads, float* m, 
 extern "C" int taco_fill_bernoulli(uint8_t* out, int64_t n, float p_one, uint64_t seed, void* stream) {
   TACO_REQUIRE(out && n > 0, "fill_bernoulli: bad arguments");
   return launch_bernoulli(out, n, p_one, seed, as_stream(stream));
+}
+
+extern "C" int taco_profile_enable(int on) {
+  g_prof_on = on != 0;
+  return TACO_OK;
+}
+
+extern "C" int taco_profile_read(int which, float* ms, int cap) {
+  TACO_REQUIRE(which == 0 || which == 1, "profile_read: which must be 0 or 1");
+  ProfRing& r = g_prof[which];
+  int n = 0;
+  for (int i = 0; i < r.n; ++i) {
+    if (hipEventSynchronize(r.stop[i]) != hipSuccess) break;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.start[i], r.stop[i]) != hipSuccess) break;
+    if (ms && n < cap) ms[n] = t;
+    ++n;
+  }
+  r.n = 0;
+  return n;
 }

@@ -1,0 +1,201 @@
+"""ctypes binding of libtaco_hip.so (include/taco_hip.h).
+
+PyTorch is used only as the device allocator / stream owner: every call passes raw device pointers
+(`tensor.data_ptr()`) and the current HIP stream.  There is NO CPU fallback: if the shared library is missing
+the import of this module raises, and every entry point raises `TacoError` on a non-zero return code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libtaco_hip.so')
+
+
+class TacoError(RuntimeError):
+    pass
+
+
+class TacoShape(C.Structure):
+    _fields_ = [('B', C.c_int32), ('Tt', C.c_int32), ('Td', C.c_int32), ('r', C.c_int32), ('V', C.c_int32)]
+
+    def __repr__(self):
+        return 'TacoShape(B=%d, Tt=%d, Td=%d, r=%d, V=%d)' % (self.B, self.Tt, self.Td, self.r, self.V)
+
+
+class TacoTensorInfo(C.Structure):
+    _fields_ = [('name', C.c_char * 64), ('offset', C.c_int64), ('size', C.c_int64), ('ndim', C.c_int32),
+                ('dims', C.c_int32 * 4)]
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        'tacotron_amd: %s not found -- build it with `python -c "import __graft_entry__ as g; g.build()"` '
+        '(or tacotron_amd/csrc/build.sh).  There is no CPU fallback.' % LIB_PATH)
+
+_lib = C.CDLL(LIB_PATH)
+
+_P = C.c_void_p
+_I = C.c_int
+_SH = C.POINTER(TacoShape)
+
+EXPORTS = {
+    'taco_version': (C.c_int, []),
+    'taco_last_error_string': (C.c_char_p, []),
+    'taco_param_count': (C.c_int64, [_SH]),
+    'taco_param_table': (C.c_int, [_SH, C.POINTER(TacoTensorInfo), _I]),
+    'taco_workspace_bytes': (C.c_int64, [_SH, _I]),
+    'taco_workspace_table': (C.c_int, [_SH, _I, C.POINTER(TacoTensorInfo), _I]),
+    'taco_conv_gemm': (C.c_int, [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'taco_gemm_tn': (C.c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'taco_debug_gemm_naive': (C.c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'taco_bigru_fwd': (C.c_int, [_P] * 12 + [_I, _I, _P]),
+    'taco_forward': (C.c_int, [_SH] + [_P] * 16),
+    'taco_backward': (C.c_int, [_SH] + [_P] * 13),
+    'taco_infer': (C.c_int, [_SH] + [_P] * 8),
+    'taco_clip_adam_step': (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_int64, _P, _P, _P]),
+    'taco_fill_bernoulli': (C.c_int, [_P, C.c_int64, C.c_float, C.c_uint64, _P]),
+    'taco_profile_enable': (C.c_int, [_I]),
+    'taco_profile_read': (C.c_int, [_I, C.POINTER(C.c_float), _I]),
+}
+for _name, (_res, _args) in EXPORTS.items():
+    _fn = getattr(_lib, _name)  # AttributeError here = the library does not export what include/taco_hip.h declares
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def last_error() -> str:
+    return _lib.taco_last_error_string().decode()
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise TacoError('%s failed (rc=%d): %s' % (what, rc, last_error()))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), 'taco: tensor must be contiguous'
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def make_shape(B, Tt, Td, r, V) -> TacoShape:
+    return TacoShape(int(B), int(Tt), int(Td), int(r), int(V))
+
+
+def version() -> int:
+    return _lib.taco_version()
+
+
+def param_count(shape: TacoShape) -> int:
+    n = _lib.taco_param_count(C.byref(shape))
+    if n < 0:
+        raise TacoError('taco_param_count: ' + last_error())
+    return n
+
+
+def _table(fn, *args):
+    n = fn(*args, None, 0)
+    if n < 0:
+        raise TacoError(last_error())
+    rows = (TacoTensorInfo * n)()
+    fn(*args, rows, n)
+    return [(r.name.decode(), int(r.offset), int(r.size), tuple(r.dims[i] for i in range(r.ndim))) for r in rows]
+
+
+def param_table(shape: TacoShape):
+    """[(name, offset_floats, size_floats, dims)] in TF variable order."""
+    return _table(_lib.taco_param_table, C.byref(shape))
+
+
+def workspace_bytes(shape: TacoShape, train: bool) -> int:
+    n = _lib.taco_workspace_bytes(C.byref(shape), int(train))
+    if n < 0:
+        raise TacoError('taco_workspace_bytes: ' + last_error())
+    return n
+
+
+def workspace_table(shape: TacoShape, train: bool):
+    return _table(_lib.taco_workspace_table, C.byref(shape), int(train))
+
+
+def conv_gemm(A, W, C_out, M, N, K, taps=1, T=None, pad_l=0, act=0, bias=None, scale=None, shift=None, residual=None,
+              keep=None, Cpre=None, lda=None, ldw=None, ldc=None, ldr=None):
+    T = M if T is None else T
+    _check(_lib.taco_conv_gemm(ptr(A), lda or K, ptr(W), ldw or N, ptr(bias), ptr(scale), ptr(shift), ptr(residual),
+                               ldr or N, ptr(keep), ptr(C_out), ldc or N, ptr(Cpre), M, N, K, taps, T, pad_l, act,
+                               stream_ptr()), 'taco_conv_gemm')
+
+
+def gemm_tn(A, dY, dW, M, N, K, taps=1, T=None, pad_l=0, accumulate=False, lda=None, ldy=None, ldw=None):
+    T = M if T is None else T
+    _check(_lib.taco_gemm_tn(ptr(A), lda or K, ptr(dY), ldy or N, ptr(dW), ldw or N, M, N, K, taps, T, pad_l,
+                             int(accumulate), stream_ptr()), 'taco_gemm_tn')
+
+
+def debug_gemm_naive(A, W, C_out, M, N, K, taps=1, T=None, pad_l=0, act=0, bias=None):
+    T = M if T is None else T
+    _check(_lib.taco_debug_gemm_naive(ptr(A), K, ptr(W), N, ptr(bias), ptr(C_out), N, M, N, K, taps, T, pad_l, act,
+                                      stream_ptr()), 'taco_debug_gemm_naive')
+
+
+def bigru_fwd(x, w, xg, out, ruc, B, T):
+    """w: dict with fw/bw gates/candidate kernels and biases (TF layout)."""
+    _check(_lib.taco_bigru_fwd(ptr(x), ptr(w['fw/gates/kernel']), ptr(w['fw/gates/bias']),
+                               ptr(w['fw/candidate/kernel']), ptr(w['fw/candidate/bias']),
+                               ptr(w['bw/gates/kernel']), ptr(w['bw/gates/bias']),
+                               ptr(w['bw/candidate/kernel']), ptr(w['bw/candidate/bias']),
+                               ptr(xg), ptr(out), ptr(ruc), B, T, stream_ptr()), 'taco_bigru_fwd')
+
+
+def forward(shape, params, text, text_length, mel, stft, masks, s2s, out, align, loss, workspace):
+    m = masks or {}
+    _check(_lib.taco_forward(C.byref(shape), ptr(params), ptr(text), ptr(text_length), ptr(mel), ptr(stft),
+                             ptr(m.get('enc_keep1')), ptr(m.get('enc_keep2')), ptr(m.get('dec_keep1')),
+                             ptr(m.get('dec_keep2')), ptr(m.get('sample')), ptr(s2s), ptr(out), ptr(align), ptr(loss),
+                             ptr(workspace), stream_ptr()), 'taco_forward')
+
+
+def backward(shape, params, text, text_length, s2s, align, masks, grads, workspace):
+    m = masks or {}
+    _check(_lib.taco_backward(C.byref(shape), ptr(params), ptr(text), ptr(text_length), ptr(s2s), ptr(align),
+                              ptr(m.get('enc_keep1')), ptr(m.get('enc_keep2')), ptr(m.get('dec_keep1')),
+                              ptr(m.get('dec_keep2')), ptr(m.get('sample')), ptr(grads), ptr(workspace), stream_ptr()),
+           'taco_backward')
+
+
+def infer(shape, params, text, text_length, s2s, out, align, workspace):
+    _check(_lib.taco_infer(C.byref(shape), ptr(params), ptr(text), ptr(text_length), ptr(s2s), ptr(out), ptr(align),
+                           ptr(workspace), stream_ptr()), 'taco_infer')
+
+
+def clip_adam_step(params, grads, m, v, lr, cap, step, scratch, gnorm_out):
+    _check(_lib.taco_clip_adam_step(ptr(params), ptr(grads), ptr(m), ptr(v), params.numel(), float(lr), float(cap),
+                                    int(step), ptr(scratch), ptr(gnorm_out), stream_ptr()), 'taco_clip_adam_step')
+
+
+def fill_bernoulli(out, p_one, seed):
+    _check(_lib.taco_fill_bernoulli(ptr(out), out.numel(), float(p_one), int(seed) & 0xFFFFFFFFFFFFFFFF, stream_ptr()),
+           'taco_fill_bernoulli')
+
+
+def profile_enable(on: bool):
+    _check(_lib.taco_profile_enable(int(on)), 'taco_profile_enable')
+
+
+def profile_read(which: int):
+    """Elapsed milliseconds of every recorded launch of decoder forward (0) / backward (1) since the last read."""
+    buf = (C.c_float * 1024)()
+    n = _lib.taco_profile_read(which, buf, 1024)
+    if n < 0:
+        raise TacoError('taco_profile_read: ' + last_error())
+    return [buf[i] for i in range(min(n, 1024))]

@@ -1,0 +1,196 @@
+"""GPU: op-level parity of the HIP kernels (through the C ABI) against NumPy fp64 restatements.
+Tolerances (fp32 kernel vs fp64 oracle): rel-L2 <= 2e-6 * sqrt(K)-ish, stated per test."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import taco_numpy as on
+from tests.util import report
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a)).to('cuda', dtype).contiguous()
+
+
+def conv_ref(A, W, bias, T, pad_l, act, keep=None, scale=None, shift=None, residual=None):
+    """A (M,K) with M = B*T; W (taps,K,N)."""
+    M, K = A.shape
+    taps, _, N = W.shape
+    B = M // T
+    x = A.reshape(B, T, K)
+    pad_r = taps - 1 - pad_l
+    xp = np.pad(x, ((0, 0), (max(pad_l, 0), max(pad_r, 0)), (0, 0)))
+    y = np.zeros((B, T, N))
+    for j in range(taps):
+        sh = j - pad_l
+        for t in range(T):
+            st = t + sh
+            if 0 <= st < T:
+                y[:, t] += x[:, st] @ W[j]
+    y = y.reshape(M, N)
+    if bias is not None:
+        y = y + bias
+    if act == 1:
+        y = np.maximum(y, 0)
+    elif act == 2:
+        y = on.sigmoid(y)
+    elif act == 3:
+        y = np.tanh(y)
+    if keep is not None:
+        y = y * keep * 2
+    pre = y.copy()
+    if scale is not None:
+        y = y * scale + (shift if shift is not None else 0)
+    if residual is not None:
+        y = y + residual
+    return y, pre
+
+
+def test_naive_gemm_plumbing(built_lib):
+    rng = np.random.default_rng(0)
+    M, N, K = 37, 24, 19
+    A, W, b = rng.standard_normal((M, K)), rng.standard_normal((1, K, N)), rng.standard_normal(N)
+    C = torch.zeros(M, N, device='cuda')
+    built_lib.debug_gemm_naive(dev(A), dev(W), C, M, N, K, bias=dev(b), act=1)
+    ref, _ = conv_ref(A, W, b, M, 0, 1)
+    r, m = report('naive gemm', C.cpu().numpy(), ref)
+    assert r < 1e-6
+
+
+CASES = [
+    # M, T, N, K, taps, pad_l, act, extras
+    (128, 128, 128, 128, 1, 0, 0, ''),
+    (256, 64, 128, 64, 3, 1, 1, 'bias'),
+    (70, 35, 80, 20, 3, 1, 1, 'bias,scale,residual,pre'),
+    (90, 9, 128, 128, 16, 7, 1, 'bias'),
+    (90, 9, 128, 80, 8, 3, 1, 'bias'),
+    (64, 64, 1025, 256, 1, 0, 0, 'bias'),
+    (200, 200, 256, 256, 1, 0, 1, 'bias,keep'),
+    (6400, 200, 256, 256, 1, 0, 2, 'bias'),        # big-tile path
+    (3000, 3000, 384, 136, 1, 0, 3, 'bias'),       # big-tile path with ragged edges
+    (36, 9, 128, 128, 5, 2, 0, 'residual'),
+    (36, 9, 80, 128, 6, 3, 0, ''),                 # backward-style pad (k-1 - (k-1)//2)
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=[str(c[:6]) for c in CASES])
+def test_conv_gemm(built_lib, case):
+    M, T, N, K, taps, pad_l, act, extras = case
+    rng = np.random.default_rng(hash(case[:6]) % 2**31)
+    A = rng.standard_normal((M, K))
+    W = rng.standard_normal((taps, K, N)) / np.sqrt(K * taps)
+    bias = rng.standard_normal(N) if 'bias' in extras else None
+    keep = rng.integers(0, 2, (M, N)).astype(np.uint8) if 'keep' in extras else None
+    scale = rng.standard_normal(N) if 'scale' in extras else None
+    shift = rng.standard_normal(N) if 'scale' in extras else None
+    res = rng.standard_normal((M, N)) if 'residual' in extras else None
+    C = torch.full((M, N), float('nan'), device='cuda')
+    Cpre = torch.full((M, N), float('nan'), device='cuda') if 'pre' in extras else None
+    built_lib.conv_gemm(dev(A), dev(W), C, M, N, K, taps=taps, T=T, pad_l=pad_l, act=act,
+                        bias=None if bias is None else dev(bias), scale=None if scale is None else dev(scale),
+                        shift=None if shift is None else dev(shift), residual=None if res is None else dev(res),
+                        keep=None if keep is None else dev(keep, torch.uint8), Cpre=Cpre)
+    ref, pre = conv_ref(A, W, bias, T, pad_l, act, keep, scale, shift, res)
+    r, m = report('conv_gemm %s' % (case[:7],), C.cpu().numpy(), ref)
+    assert r < 5e-6
+    if Cpre is not None:
+        assert report('  Cpre', Cpre.cpu().numpy(), pre)[0] < 5e-6
+
+
+def test_conv_gemm_strided_unaligned(built_lib):
+    """lda not a multiple of 4 (1025-wide rows) exercises the scalar-load path; ldc > N exercises column offsets."""
+    rng = np.random.default_rng(5)
+    M, K, N = 96, 1025, 256
+    A = rng.standard_normal((M, K))
+    W = rng.standard_normal((1, K, N)) / 32
+    C = torch.zeros(M, 300, device='cuda')
+    built_lib.conv_gemm(dev(A), dev(W), C[:, 20:], M, N, K, lda=1025, ldc=300)
+    ref, _ = conv_ref(A, W, None, M, 0, 0)
+    assert report('unaligned lda', C[:, 20:276].cpu().numpy(), ref)[0] < 5e-6
+    assert float(C[:, :20].abs().max()) == 0 and float(C[:, 276:].abs().max()) == 0
+
+
+TN_CASES = [(128, 128, 128, 128, 1, 0), (360, 36, 80, 128, 3, 1), (5760, 180, 256, 512, 1, 1), (400, 40, 128, 128, 1, -1),
+            (90, 9, 128, 128, 16, 7), (512, 512, 1025, 256, 1, 0), (77, 77, 20, 36, 1, 0)]
+
+
+@pytest.mark.parametrize('case', TN_CASES, ids=[str(c) for c in TN_CASES])
+def test_gemm_tn(built_lib, case):
+    M, T, N, K, taps, pad_l = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    A = rng.standard_normal((M, K))
+    dY = rng.standard_normal((M, N))
+    B = M // T
+    ref = np.zeros((taps, K, N))
+    x = A.reshape(B, T, K)
+    y = dY.reshape(B, T, N)
+    for j in range(taps):
+        sh = j - pad_l
+        for t in range(T):
+            st = t + sh
+            if 0 <= st < T:
+                ref[j] += x[:, st].T @ y[:, t]
+    dW = torch.full((taps, K, N), 7.0, device='cuda')
+    built_lib.gemm_tn(dev(A), dev(dY), dW, M, N, K, taps=taps, T=T, pad_l=pad_l, accumulate=False)
+    assert report('gemm_tn %s' % (case,), dW.cpu().numpy(), ref)[0] < 5e-6
+    built_lib.gemm_tn(dev(A), dev(dY), dW, M, N, K, taps=taps, T=T, pad_l=pad_l, accumulate=True)
+    assert report('  accumulate', dW.cpu().numpy(), 2 * ref)[0] < 5e-6
+
+
+@pytest.mark.parametrize('B,T', [(2, 9), (3, 50), (32, 200)])
+def test_bigru_fwd(built_lib, B, T):
+    rng = np.random.default_rng(B * 100 + T)
+    p = {}
+    for d in ('fw', 'bw'):
+        p['g/%s/gates/kernel' % d] = rng.uniform(-0.15, 0.15, (256, 256))
+        p['g/%s/gates/bias' % d] = 1 + rng.uniform(-0.3, 0.3, 256)
+        p['g/%s/candidate/kernel' % d] = rng.uniform(-0.15, 0.15, (256, 128))
+        p['g/%s/candidate/bias' % d] = rng.uniform(-0.3, 0.3, 128)
+    x = rng.standard_normal((B, T, 128))
+    ref = on.bigru(x, p, 'g/')
+    w = {k[2:]: dev(v) for k, v in p.items()}
+    xg = torch.zeros(B, T, 768, device='cuda')
+    out = torch.zeros(B, T, 256, device='cuda')
+    ruc = torch.zeros(B, T, 768, device='cuda')
+    built_lib.bigru_fwd(dev(x), w, xg, out, ruc, B, T)
+    r, m = report('bigru_fwd B=%d T=%d' % (B, T), out.cpu().numpy(), ref)
+    assert r < 2e-5 and m < 1e-4
+
+
+def test_bernoulli(built_lib):
+    out = torch.zeros(1 << 20, dtype=torch.uint8, device='cuda')
+    built_lib.fill_bernoulli(out, 0.5, 123)
+    a = out.cpu().numpy().copy()
+    assert set(np.unique(a)) == {0, 1} and abs(a.mean() - 0.5) < 3e-3
+    built_lib.fill_bernoulli(out, 0.5, 123)
+    assert np.array_equal(a, out.cpu().numpy())
+    built_lib.fill_bernoulli(out, 0.5, 124)
+    b = out.cpu().numpy()
+    assert abs((a == b).mean() - 0.5) < 3e-3           # independent streams
+    built_lib.fill_bernoulli(out, 0.25, 9)
+    assert abs(out.float().mean().item() - 0.25) < 3e-3
+    odd = torch.zeros(1001, dtype=torch.uint8, device='cuda')
+    built_lib.fill_bernoulli(odd, 1.0, 1)
+    assert int(odd.sum()) == 1001
+
+
+@pytest.mark.parametrize('gscale', [0.01, 30.0], ids=['noclip', 'clip'])
+def test_clip_adam_step(built_lib, gscale):
+    rng = np.random.default_rng(1)
+    n = 100003
+    p0 = rng.standard_normal(n)
+    p = {'w': p0.copy()}
+    m = {'w': np.zeros(n)}
+    v = {'w': np.zeros(n)}
+    P, Mm, Vv = dev(p0), torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    scratch, gn_out = torch.zeros(8, device='cuda'), torch.zeros(1, device='cuda')
+    for step in (1, 2, 3):
+        g = rng.standard_normal(n) * gscale
+        gn = on.clip_adam_step(p, {'w': g}, m, v, step, 5e-4)
+        built_lib.clip_adam_step(P, dev(g), Mm, Vv, 5e-4, 5.0, step, scratch, gn_out)
+        assert abs(gn_out.item() - gn) < 1e-4 * gn
+    assert report('adam params', P.cpu().numpy(), p['w'])[1] < 2e-6
+    assert report('adam m', Mm.cpu().numpy(), m['w'])[0] < 1e-5
+    assert report('adam v', Vv.cpu().numpy(), v['w'])[0] < 1e-5

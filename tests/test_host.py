@@ -1,0 +1,86 @@
+"""CPU: host-side mirror of the reference interface -- Config defaults, prompt front end, r-frame layout, synthetic
+batches, parameter initialisation rules."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tacotron_amd import config as cfg
+from tacotron_amd.audio import reshape_frames
+from tacotron_amd.data import load_prompts, pad, synthetic_batch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def test_config_defaults_equal_reference():
+    # models/tacotron.py:12-33, audio.py:10-17
+    c = cfg.Config()
+    assert c.max_decode_iter == 108000 // (2 * 300) == 180
+    assert (c.attention_units, c.decoder_units, c.mel_features, c.embed_dim, c.fft_size) == (256, 256, 80, 256, 1025)
+    assert (c.char_dropout_prob, c.audio_dropout_prob, c.scheduled_sample) == (0.5, 0.5, 0.5)
+    assert (c.num_speakers, c.speaker_embed_dim, c.cap_grads, c.batch_size) == (1, 16, 5, 32)
+    assert c.init_lr == 0.0005 and c.annealing_rate == 1
+    assert (cfg.n_fft, cfg.win_length, cfg.hop_length, cfg.maximum_audio_length, cfg.r) == (2048, 1200, 300, 108000, 2)
+    assert (cfg.SAVE_EVERY, cfg.MAX_TEXT_LEN, cfg.BATCH_SIZE) == (5000, 140, 32)
+    c.validate()
+    c.embed_dim = 128
+    with pytest.raises(ValueError):
+        c.validate()
+
+
+def test_reshape_frames_matches_reference_vectors():
+    g = np.load(os.path.join(GOLD, 'reshape_frames.npz'))
+    n = 0
+    for k in g.files:
+        if not k.startswith('x_'):
+            continue
+        r = int(k[3])
+        f = reshape_frames(g[k], r)
+        assert np.array_equal(f, g['fwd' + k[1:]]), k
+        assert np.array_equal(reshape_frames(f, r, forward=False), g['inv' + k[1:]]), k
+        n += 1
+    assert n == 4
+    # audio.py:106-115 self-test: ramp round trip
+    test = np.repeat(np.arange(40)[:, None] + 1, 7, axis=1)
+    assert np.array_equal(reshape_frames(reshape_frames(test.T, 2), 2, forward=False), test)
+    # forward layout at r=2 is row 4b+j = [frame 8b+j, frame 8b+j+4]
+    x = np.arange(16)[None, :].astype(float)
+    assert reshape_frames(x, 2).tolist() == [[0, 4], [1, 5], [2, 6], [3, 7], [8, 12], [9, 13], [10, 14], [11, 15]]
+
+
+def test_load_prompts_semantics():
+    ivocab = {0: '<pad>', 1: 'a', 2: 'b', 3: ' ', 4: 'c'}
+    prompts = ['ab c\n', 'zzab\n', 'c']
+    batches = list(load_prompts(prompts, ivocab, batch_size=2))
+    assert [b['text'].shape for b in batches] == [torch.Size([2, 140]), torch.Size([1, 140])]   # smaller final batch
+    assert batches[0]['text'][0, :5].tolist() == [1, 2, 3, 4, 0]
+    assert batches[0]['text'][1, :3].tolist() == [1, 2, 0]           # unknown chars dropped (data_input.py:94)
+    assert batches[0]['text_length'].tolist() == [5, 5]              # len(raw line) incl. newline / unknown (data_input.py:95)
+    assert pad([[1, 2], [3]], 4, 0).tolist() == [[1, 2, 0, 0], [3, 0, 0, 0]]
+
+
+def test_synthetic_batch_shape_and_determinism():
+    a = synthetic_batch(4, 20, 6, 2, 60, seed=1)
+    b = synthetic_batch(4, 20, 6, 2, 60, seed=1)
+    c = synthetic_batch(4, 20, 6, 2, 60, seed=1, rank=1)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert not torch.equal(a['mel'], c['mel'])
+    assert a['text_length'][0] == 20 and int(a['text'].max()) < 60
+    for i, L in enumerate(a['text_length'].tolist()):
+        assert torch.all(a['text'][i, L:] == 0) and torch.all(a['text'][i, :L] > 0)
+    assert a['mel'].shape == (4, 6, 160) and a['stft'].shape == (4, 6, 2050)
+
+
+def test_param_init_rules(built_lib):
+    from tacotron_amd.params import ParamBuffer, glorot_limit
+    pb = ParamBuffer(built_lib.make_shape(2, 8, 4, 2, 30)).init_(seed=0)
+    assert torch.all(pb.view('decoder/gru_0/gates/bias') == 1)       # GRUCell gates bias init 1.0
+    assert torch.all(pb.view('decoder/gru_0/candidate/bias') == 0)
+    assert torch.all(pb.view('encoder/cbhg/bank_bn/gamma') == 1) and torch.all(pb.view('post/cbhg/proj2_bn/beta') == 0)
+    k = pb.view('encoder/cbhg/bank_4/kernel')
+    lim = glorot_limit((4, 128, 128))
+    assert abs(lim - np.sqrt(6.0 / (4 * 128 + 4 * 128))) < 1e-12 and float(k.abs().max()) <= lim and float(k.std()) > 0.4 * lim
+    d = pb.to_dict()
+    pb2 = ParamBuffer(pb.shape).load_dict_(d)
+    assert torch.equal(pb.flat, pb2.flat)

@@ -1,0 +1,66 @@
+"""CPU: the C-ABI library loads, exports every symbol include/taco_hip.h declares, and its parameter table equals
+the oracle's TF-order spec.  No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import taco_numpy as on
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_exports_match_header(built_lib):
+    hdr = open(os.path.join(ROOT, 'include', 'taco_hip.h')).read()
+    declared = set(re.findall(r'\b(taco_[a-z_0-9]+)\s*\(', hdr))
+    assert declared, 'no declarations parsed'
+    raw = ctypes.CDLL(built_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(raw, name), 'libtaco_hip.so does not export %s' % name
+    assert declared == set(built_lib.EXPORTS), (declared ^ set(built_lib.EXPORTS))
+    assert built_lib.version() == 100
+
+
+@pytest.mark.parametrize('V,r', [(60, 2), (20, 5), (33, 3)])
+def test_param_table_matches_oracle_spec(built_lib, V, r):
+    shape = built_lib.make_shape(4, 10, 6, r, V)
+    table = built_lib.param_table(shape)
+    spec = on.param_spec(V, r)
+    assert len(table) == len(spec)
+    off = 0
+    for (name, o, size, dims), (n2, shp, _) in zip(table, spec):
+        assert name == n2 and o == off and tuple(shp) == dims and size == int(np.prod(shp))
+        assert o % 4 == 0, '%s not 16-byte aligned' % name
+        off += size
+    assert built_lib.param_count(shape) == off
+
+
+def test_nancy_param_count(built_lib):
+    assert built_lib.param_count(built_lib.make_shape(32, 200, 180, 2, 60)) == 6926609
+
+
+def test_workspace_table(built_lib):
+    shape = built_lib.make_shape(32, 200, 180, 2, 60)
+    for train in (True, False):
+        rows = built_lib.workspace_table(shape, train)
+        total = built_lib.workspace_bytes(shape, train)
+        names = [r[0] for r in rows]
+        assert 'enc.bank' in names and 'post.out' in names and ('dec.stash' in names) == train
+        end = 0
+        for name, off, size, dims in rows:
+            assert off % 64 == 0 and off >= end, name
+            end = off + size
+        assert end * 4 <= total
+    assert built_lib.workspace_bytes(shape, True) > built_lib.workspace_bytes(shape, False)
+
+
+def test_error_behaviour(built_lib):
+    bad = built_lib.make_shape(0, 10, 6, 2, 60)
+    with pytest.raises(built_lib.TacoError):
+        built_lib.param_count(bad)
+    assert 'B=0' in built_lib.last_error()
+    with pytest.raises(built_lib.TacoError):
+        built_lib.workspace_bytes(built_lib.make_shape(2, 10, 6, 9, 60), True)
+    assert 'r=9' in built_lib.last_error()

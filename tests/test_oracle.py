@@ -1,0 +1,118 @@
+"""CPU: the two independent restatements agree, gradients pass a finite-difference check, and the committed golden
+vectors are reproduced.  (PARITY UNPINNED vs TensorFlow 1.2 -- see oracle/taco_numpy.py.)"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import taco_numpy as on
+from oracle import taco_torch as ot
+from tests.util import small_case
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _f64(masks):
+    return {k: v.astype(np.float64) for k, v in masks.items()}
+
+
+def test_param_count_matches_survey():
+    # 6,926,609 trainable fp32 at V=60, r=2
+    assert sum(int(np.prod(s)) for _, s, _ in on.param_spec(60, 2)) == 6926609
+
+
+@pytest.mark.parametrize('r', [2, 5])
+def test_numpy_and_torch_restatements_agree(r):
+    V = 20
+    p = on.init_params(V, r, seed=1, perturb=0.3)
+    inp, masks = small_case(r=r, V=V, Td=4)
+    inp = {k: (v.astype(np.float64) if v.dtype == np.float32 else v) for k, v in inp.items()}
+    s2s, out, al, enc = on.forward(p, inp, r, 4, True, _f64(masks))
+    loss = on.loss_fn(s2s, out, inp['mel'], inp['stft'])
+    lt, s2, o2, a2, grads = ot.loss_and_grads(p, inp, r, 4, _f64(masks))
+    assert abs(loss - lt) <= 1e-10 * abs(loss)
+    assert np.abs(s2s - s2).max() < 1e-11 and np.abs(out - o2).max() < 1e-11 and np.abs(al - a2).max() < 1e-12
+    assert all(g is not None for g in grads.values())
+    # inference mode
+    s2s, out, al, _ = on.forward(p, inp, r, 4, False)
+    with torch.no_grad():
+        t = ot.forward(ot.to_torch(p), {'text': torch.tensor(inp['text'], dtype=torch.int64),
+                                        'text_length': torch.tensor(inp['text_length'], dtype=torch.int64)}, r, 4, False)
+    assert np.abs(s2s - t[0].numpy()).max() < 1e-11 and np.abs(out - t[1].numpy()).max() < 1e-11
+
+
+def test_alignments_are_masked_distributions():
+    p = on.init_params(20, 2, seed=2)
+    inp, masks = small_case()
+    _, _, al, _ = on.forward(p, {k: v for k, v in inp.items()}, 2, 5, False)
+    assert np.allclose(al.sum(-1), 1.0)
+    for b, L in enumerate(inp['text_length']):
+        assert np.all(al[b, :, L:] == 0)
+
+
+def test_autograd_matches_finite_differences():
+    """Central differences of the NumPy forward vs torch autograd, on a few scalars of different tensors."""
+    r, V, Td = 2, 12, 3
+    p = on.init_params(V, r, seed=5, perturb=0.2)
+    inp, masks = small_case(r=r, V=V, Tt=6, Td=Td, seed=11)
+    inp = {k: (v.astype(np.float64) if v.dtype == np.float32 else v) for k, v in inp.items()}
+    fm = _f64(masks)
+    _, _, _, _, grads = ot.loss_and_grads(p, inp, r, Td, fm)
+
+    def loss_of(pp):
+        s2s, out, _, _ = on.forward(pp, inp, r, Td, True, fm)
+        return on.loss_fn(s2s, out, inp['mel'], inp['stft'])
+
+    rng = np.random.default_rng(0)
+    for name in ['decoder/attention_v', 'decoder/gru_1/gates/kernel', 'encoder/cbhg/bank_3/kernel',
+                 'decoder/memory_layer/kernel', 'post/cbhg/proj1_bn/gamma', 'decoder/pre_net/dense/kernel',
+                 'encoder/cbhg/bigru/bw/candidate/kernel']:
+        idx = tuple(rng.integers(0, s) for s in p[name].shape)
+        eps = 1e-6
+        base = p[name][idx]
+        p[name][idx] = base + eps
+        lp = loss_of(p)
+        p[name][idx] = base - eps
+        lm = loss_of(p)
+        p[name][idx] = base
+        fd = (lp - lm) / (2 * eps)
+        an = grads[name][idx]
+        # |x| kinks make the loss only piecewise smooth; tolerate small mismatch
+        assert abs(fd - an) <= 2e-4 * max(1.0, abs(an)), (name, fd, an)
+
+
+@pytest.mark.parametrize('r', [2, 5])
+def test_golden_fixture_reproduced(r):
+    g = np.load(os.path.join(GOLD, 'model_r%d.npz' % r))
+    V, Td = int(g['V']), int(g['Td'])
+    p = on.init_params(V, r, seed=int(g['seed']), perturb=float(g['perturb']))
+    assert abs(np.abs(on.flatten_params(p, V, r, np.float64)).sum() - float(g['param_checksum'])) < 1e-9
+    inp = {'text': g['text'], 'text_length': g['text_length'], 'mel': g['mel'].astype(np.float64),
+           'stft': g['stft'].astype(np.float64)}
+    masks = {k[5:]: g[k].astype(np.float64) for k in g.files if k.startswith('mask_')}
+    s2s, out, al, enc = on.forward(p, inp, r, Td, True, masks)
+    assert np.abs(s2s - g['seq2seq_output']).max() < 1e-12
+    assert np.abs(out - g['output']).max() < 1e-12
+    assert np.abs(al - g['alignments']).max() < 1e-13
+    assert abs(on.loss_fn(s2s, out, inp['mel'], inp['stft']) - float(g['loss'])) < 1e-9
+    assert len(g['assumptions']) == len(on.ASSUMPTIONS)
+
+
+def test_clip_adam_restatements_agree():
+    rng = np.random.default_rng(0)
+    p = {'a': rng.standard_normal((5, 3)), 'b': rng.standard_normal(7)}
+    g = {'a': rng.standard_normal((5, 3)) * 10, 'b': rng.standard_normal(7) * 10}
+    m = {k: np.zeros_like(v) for k, v in p.items()}
+    v = {k: np.zeros_like(x) for k, x in p.items()}
+    pt = {k: torch.tensor(x) for k, x in p.items()}
+    gt = {k: torch.tensor(x) for k, x in g.items()}
+    mt = {k: torch.zeros_like(x) for k, x in pt.items()}
+    vt = {k: torch.zeros_like(x) for k, x in pt.items()}
+    for step in (1, 2, 3):
+        gn = on.clip_adam_step(p, g, m, v, step, 5e-4)
+        gn2 = ot.clip_adam_step(pt, gt, mt, vt, step, 5e-4)
+        assert abs(gn - gn2) < 1e-9
+    for k in p:
+        assert np.abs(p[k] - pt[k].numpy()).max() < 1e-12
+    assert gn > 5  # the clip branch was exercised
