@@ -1,8 +1,9 @@
 """GPU: whole-path parity of libtaco_hip.so against the CPU restatements (PARITY UNPINNED vs TF 1.2, see oracle/).
 
-Stated tolerances (fp32 HIP vs fp64 oracle): seq2seq_output / output rel-L2 <= 1e-4 and max-abs <= 1e-3; alignments
-max-abs <= 1e-5; loss rel <= 1e-5; per-tensor gradients rel-L2 <= 1e-3 (tensors whose reference norm is < 1e-6 of the
+Stated tolerances (fp32 HIP vs fp64 oracle): seq2seq_output / output rel-L2 <= 1e-5 and max-abs <= 5e-5; alignments
+max-abs <= 1e-6; loss rel <= 1e-5; per-tensor gradients rel-L2 <= 2e-4 (tensors whose reference norm is < 1e-6 of the
 largest are compared in absolute terms); attention argmax exact wherever the reference top-1/top-2 margin >= 1e-4.
+(Measured on MI355X in round 1: outputs ~3e-7 rel-L2, worst gradient 1.1e-5.)
 """
 import os
 
@@ -125,7 +126,7 @@ def test_forward_train_matches_golden(built_lib, r):
     r3, m3 = report('alignments', al, g['alignments'])
     loss = R.loss.cpu().numpy()
     print('  loss', loss, float(g['loss']))
-    assert r1 < 1e-4 and m1 < 1e-3 and r2 < 1e-4 and m2 < 1e-3 and m3 < 1e-5
+    assert r1 < 1e-5 and m1 < 5e-5 and r2 < 1e-5 and m2 < 5e-5 and m3 < 1e-6
     assert abs(loss[0] - float(g['loss'])) <= 1e-5 * float(g['loss'])
     assert abs(loss[0] - (loss[1] + loss[2])) <= 1e-5 * loss[0]
     ok = g['argmax_margin'] >= 1e-4
@@ -144,10 +145,10 @@ def test_infer_matches_golden(built_lib, r):
     r1, m1 = report('infer seq2seq_output', R.s2s.cpu().numpy(), g['infer_seq2seq_output'])
     r2, m2 = report('infer output', R.out.cpu().numpy(), g['infer_output'])
     r3, m3 = report('infer alignments', R.al.cpu().numpy(), g['infer_alignments'])
-    assert r1 < 1e-4 and m1 < 1e-3 and r2 < 1e-4 and m2 < 1e-3 and m3 < 1e-5
+    assert r1 < 1e-5 and m1 < 5e-5 and r2 < 1e-5 and m2 < 5e-5 and m3 < 1e-6
 
 
-def check_grads(R, ref_grads, tol=1e-3):
+def check_grads(R, ref_grads, tol=2e-4):
     got = R.pb.to_dict(R.grads)
     gmax = max(np.linalg.norm(v) for v in ref_grads.values())
     bad = []
@@ -193,9 +194,9 @@ def test_backward_without_masks_and_ragged_lengths(built_lib):
     R.forward()
     R.backward()
     lt, s2, o2, a2, ref = ot.loss_and_grads(p, f64(inp), r, Td, None)
-    assert report('s2s', R.s2s.cpu().numpy(), s2)[0] < 1e-4
-    assert report('out', R.out.cpu().numpy(), o2)[0] < 1e-4
-    assert report('align', R.al.cpu().numpy(), a2)[1] < 1e-5
+    assert report('s2s', R.s2s.cpu().numpy(), s2)[0] < 1e-5
+    assert report('out', R.out.cpu().numpy(), o2)[0] < 1e-5
+    assert report('align', R.al.cpu().numpy(), a2)[1] < 1e-6
     assert abs(R.loss[0].item() - lt) <= 1e-5 * lt
     bad = check_grads(R, ref)
     assert not bad, bad
@@ -211,9 +212,9 @@ def test_medium_shape_forward_backward(built_lib):
     R.forward()
     R.backward()
     lt, s2, o2, a2, ref = ot.loss_and_grads(p, f64(inp), r, Td, f64(masks))
-    assert report('s2s', R.s2s.cpu().numpy(), s2)[0] < 1e-4
-    assert report('out', R.out.cpu().numpy(), o2)[0] < 1e-4
-    assert report('align', R.al.cpu().numpy(), a2)[1] < 1e-5
+    assert report('s2s', R.s2s.cpu().numpy(), s2)[0] < 1e-5
+    assert report('out', R.out.cpu().numpy(), o2)[0] < 1e-5
+    assert report('align', R.al.cpu().numpy(), a2)[1] < 1e-6
     assert abs(R.loss[0].item() - lt) <= 1e-5 * lt
     bad = check_grads(R, ref)
     assert not bad, bad
