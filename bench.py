@@ -141,7 +141,7 @@ def main():
         flops = decoder_flops(B, Tt, Td, c.r)
         achieved = flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc.json')
+        pmc = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
         if os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get(dom, {}).get('hbm_bytes_per_launch')
