@@ -2,13 +2,16 @@
 // with the TF-r1.2 AttentionWrapper / BahdanauAttention / GRUCell / projection-wrapper / helper semantics restated
 // in SURVEY.md §8a rows a11-a15).
 //
-// Design (round 1): ONE workgroup of 512 threads owns ONE batch row for ALL Td steps -- a single launch replaces
-// the reference's 180-iteration tf.while_loop (~13k op launches).  All recurrent state (3 GRU states, attention
-// vector, previous frame, alignments) stays in LDS across steps; per step the row streams the 1.59 M decoder weights
-// (6.35 MB, L2/MALL-resident and shared by all rows) through a split-K mat-vec (float4 loads, 8 waves in flight) and
-// its own keys/values (2 x Tt x 256 floats).  There is no inter-workgroup communication, hence no dispatch-order or
-// XCD-placement assumption.  Attention energies/softmax/context are a fused wave-reduction phase (one wave per
-// memory row, __shfl_xor reductions).
+// ONE launch replaces the reference's 180-iteration tf.while_loop (~13k op launches).  A CLUSTER of P workgroups
+// (512 threads each) owns ONE batch row for ALL Td steps; workgroup `peer` of the cluster computes the column slice
+// [peer*N/P, (peer+1)*N/P) of every mat-vec phase.  Block b -> (row = b / P, peer = b % P); the dispatcher places block b
+// on XCD b % 8 (a speed assumption only), so with P = 8 every XCD's L2 holds just its 1/8 slice (0.8 MB) of the
+// 6.35 MB decoder weight set, shared by all rows, instead of thrashing on the whole set (round-1 v0 measured
+// 10.5 GB/launch of L2 misses).  All recurrent state is replicated in each peer's LDS; after every phase the peers
+// all-gather the phase's output vector (<= 512 floats) through 8-byte {epoch tag, value} granules written with ONE
+// agent-scope store and polled with agent-scope loads (MI355X guide, Guideline 16 recipe R2: the data is the flag, no
+// fence, placement independent).  Every spin is bounded; a timeout raises `err` and the launch drains.
+// Attention energies/softmax/context are a fused wave-reduction phase (one wave per memory row, __shfl_xor).
 //
 // The backward kernel walks the steps in reverse with the same structure on pre-transposed weights and emits the
 // per-step pre-activation gradients ("gstash"); all weight gradients are then dense MFMA GEMMs over B*Td rows.
@@ -19,23 +22,62 @@ namespace {
 
 constexpr int NT = 512;
 constexpr int kPartFloats = NT * 4;
+constexpr int kMaxKG = 64;
 
-// y[n] = sum_k x[k] * W[k*ldw + n] for n < N; `fin(n, y)` is invoked by the owning thread(s) for every n.
-// x lives in LDS and must be readable up to K rounded up to 4.  N % 4 == 0.  Contains ONE __syncthreads(); the
-// caller must __syncthreads() after its epilogue before `part`/x are reused.
-template <class Fin>
-__device__ __forceinline__ void matvec(const float* __restrict__ W, int ldw, int K, int N, const float* x, float* part,
-                                       Fin fin) {
+typedef unsigned long long u64;
+typedef __attribute__((address_space(1))) u64 gu64;
+typedef __attribute__((address_space(1))) int gi32;
+
+struct Xchg {
+  u64* base;        // this row's granule area
+  unsigned epoch;   // step tag, never 0
+  int P, peer;
+  int* err;         // global error word
+  int* dead;        // LDS: set once this workgroup has given up polling
+};
+
+__device__ __forceinline__ void xput(const Xchg& X, int idx, float v) {
+  __hip_atomic_store((gu64*)(X.base + idx), ((u64)X.epoch << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float xget(const Xchg& X, int idx) {
+  if (*X.dead) return 0.f;
+  gu64* g = (gu64*)(X.base + idx);
+  for (unsigned spin = 0;; ++spin) {
+    const u64 x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)(x >> 32) == X.epoch) return __uint_as_float((unsigned)x);
+    if ((spin & 1023u) == 1023u) {
+      if (spin > (1u << 23) || __hip_atomic_load((gi32*)X.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        __hip_atomic_store((gi32*)X.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *X.dead = 1;
+        return 0.f;
+      }
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+// One mat-vec phase of the cluster:  y[n] = sum_k x[k] * W[k*ldw + n]  for this peer's column slice, then
+//   v = epi(n, y) (owner only: activation, stash writes), put(n, v) on EVERY peer (LDS state update) after the all-gather.
+// x lives in LDS and must be readable up to K rounded up to 4.  N % 4 == 0 and N/4 >= P.  Contains ONE __syncthreads();
+// the caller must __syncthreads() afterwards before `part`/x/the put() targets are reused.
+template <class Epi, class Put>
+__device__ __forceinline__ void phase(const float* __restrict__ W, int ldw, int K, int N, const float* x, float* part,
+                                      const Xchg& X, int reg, Epi epi, Put put) {
   const int tid = threadIdx.x;
   const int N4 = N >> 2;
-  const int KG = NT / N4;
-  const int kg = tid / N4, c4 = tid - kg * N4;
+  const int g0 = (X.peer * N4) / X.P, g1 = ((X.peer + 1) * N4) / X.P;
+  const int n4 = g1 - g0;
+  const int nloc = n4 * 4;
+  int KG = NT / n4;
+  KG = KG > kMaxKG ? kMaxKG : KG;
+  const int kg = tid / n4, c4 = tid - kg * n4;
   if (kg < KG) {
     const int Kc = (((K + KG - 1) / KG) + 3) & ~3;
     const int k0 = kg * Kc;
     const int k1 = min(K, k0 + Kc);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* wp = W + (int64_t)k0 * ldw + c4 * 4;
+    const float* wp = W + (int64_t)k0 * ldw + (g0 + c4) * 4;
     int k = k0;
 #pragma unroll 2
     for (; k + 3 < k1; k += 4) {
@@ -56,15 +98,33 @@ __device__ __forceinline__ void matvec(const float* __restrict__ W, int ldw, int
       wp += ldw;
       acc.x = fmaf(xs, w0.x, acc.x); acc.y = fmaf(xs, w0.y, acc.y); acc.z = fmaf(xs, w0.z, acc.z); acc.w = fmaf(xs, w0.w, acc.w);
     }
-    *reinterpret_cast<float4*>(part + kg * N + c4 * 4) = acc;
+    *reinterpret_cast<float4*>(part + kg * nloc + c4 * 4) = acc;
   }
   __syncthreads();
-  for (int n = tid; n < N; n += NT) {
+  const int nbeg = g0 * 4;
+  for (int i = tid; i < nloc; i += NT) {
     float y = 0.f;
-    for (int g = 0; g < KG; ++g) y += part[g * N + n];
-    fin(n, y);
+    for (int g = 0; g < KG; ++g) y += part[g * nloc + i];
+    const int n = nbeg + i;
+    const float v = epi(n, y);
+    put(n, v);
+    if (X.P > 1) xput(X, reg + n, v);
+  }
+  if (X.P > 1) {
+    for (int n = tid; n < N; n += NT) {
+      if (n >= nbeg && n < nbeg + nloc) continue;
+      put(n, xget(X, reg + n));
+    }
   }
 }
+
+// ---- forward exchange regions (granule indices within a row's area) ----
+constexpr int XF_P1 = 0, XF_P2 = 256, XF_X = 384, XF_G = 640 /* +l*768 */, XF_C = 1152 /* +l*768 */, XF_O = 2944,
+              XF_Q = 3344, XF_CTX = 3600, XF_ATT = 3856, XF_E = 4112;
+// ---- backward exchange regions ----
+constexpr int XB_ATT = 0, XB_DQP = 656, XB_Q = 2704, XB_OUT = 3104, XB_C = 3360 /* +l*1024 */, XB_G = 3872 /* +l*1024 */,
+              XB_IN = 6432, XB_P2 = 6816, XB_P1 = 7072, XB_DAL = 7200;
+constexpr int kXchgFixed = 7200;
 
 struct DecSmem {
   float* part;   // kPartFloats
@@ -80,6 +140,7 @@ struct DecSmem {
   float* qs;     // 256
   float* es;     // TtP energies
   float* als;    // TtP alignments
+  int* dead;
 };
 
 __device__ __forceinline__ DecSmem carve(float* base, int TtP) {
@@ -98,19 +159,29 @@ __device__ __forceinline__ DecSmem carve(float* base, int TtP) {
   s.qs = p; p += 256;
   s.es = p; p += TtP;
   s.als = p; p += TtP;
+  s.dead = reinterpret_cast<int*>(p); p += 4;
   return s;
 }
-constexpr int kFwdSmemFixed = kPartFloats + 80 + 256 + 384 + 256 + 3 * 512 + 512 + 256 + 256 + 656 + 256;
+constexpr int kFwdSmemFixed = kPartFloats + 80 + 256 + 384 + 256 + 3 * 512 + 512 + 256 + 256 + 656 + 256 + 4;
 
 __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.x;
+  const int P = a.P;
+  const int b = blockIdx.x / P;
   const int B = a.B, Tt = a.Tt, Td = a.Td, r = a.r;
   const int R80 = kMel * r;
   const int TtP = (Tt + 3) & ~3;
   DecSmem S = carve(smem, TtP);
   const DecWeights& w = a.w;
+  Xchg X;
+  X.P = P;
+  X.peer = blockIdx.x - b * P;
+  X.base = reinterpret_cast<u64*>(a.xchg) + (int64_t)b * (kXchgFixed + TtP);
+  X.err = a.err;
+  X.dead = S.dead;
+  X.epoch = 0;
+  const bool lead = X.peer == 0;
 
   int len = a.text_length[b];
   len = len < 1 ? 1 : (len > Tt ? Tt : len);
@@ -123,95 +194,123 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
   for (int i = tid; i < TtP; i += NT) { S.als[i] = 0.f; S.es[i] = 0.f; }
   for (int i = tid; i < 656; i += NT) S.octx[i] = 0.f;
   if (tid < kMel) S.fr[tid] = a.mel ? a.mel[((int64_t)b * Td) * R80 + kMel * (r - 1) + tid] : 0.f;
-  // per-thread constants
+  if (tid == 0) *S.dead = 0;
   const float4 v4 = reinterpret_cast<const float4*>(w.att_v)[lane];
   __syncthreads();
 
   for (int t = 0; t < Td; ++t) {
+    X.epoch = (unsigned)(t + 1);
     const int64_t bt = (int64_t)b * Td + t;
     float* st = a.stash ? a.stash + bt * kStRec : nullptr;
-    if (a.prein && tid < kMel) a.prein[bt * kMel + tid] = S.fr[tid];
+    if (a.prein && lead && tid < kMel) a.prein[bt * kMel + tid] = S.fr[tid];
 
     // ---- pre_net (tacotron.py:38-44, 64-71) ----
-    matvec(w.pre_w1, kPre1, kMel, kPre1, S.fr, S.part, [&](int n, float y) {
-      y = fmaxf(y + w.pre_b1[n], 0.f);
-      if (a.keep1) y = a.keep1[bt * kPre1 + n] ? 2.f * y : 0.f;
-      S.p1[n] = y;
-      if (st) st[kStP1 + n] = y;
-    });
+    phase(w.pre_w1, kPre1, kMel, kPre1, S.fr, S.part, X, XF_P1,
+          [&](int n, float y) {
+            y = fmaxf(y + w.pre_b1[n], 0.f);
+            if (a.keep1) y = a.keep1[bt * kPre1 + n] ? 2.f * y : 0.f;
+            if (st) st[kStP1 + n] = y;
+            return y;
+          },
+          [&](int n, float v) { S.p1[n] = v; });
     __syncthreads();
-    matvec(w.pre_w2, kPre2, kPre1, kPre2, S.p1, S.part, [&](int n, float y) {
-      y = fmaxf(y + w.pre_b2[n], 0.f);
-      if (a.keep2) y = a.keep2[bt * kPre2 + n] ? 2.f * y : 0.f;
-      S.xin[n] = y;
-      if (st) st[kStP2 + n] = y;
-    });
+    phase(w.pre_w2, kPre2, kPre1, kPre2, S.p1, S.part, X, XF_P2,
+          [&](int n, float y) {
+            y = fmaxf(y + w.pre_b2[n], 0.f);
+            if (a.keep2) y = a.keep2[bt * kPre2 + n] ? 2.f * y : 0.f;
+            if (st) st[kStP2 + n] = y;
+            return y;
+          },
+          [&](int n, float v) { S.xin[n] = v; });
     __syncthreads();
     // ---- InputProjectionWrapper: x = [pre_net ; attention] Wi + bi (tacotron.py:56-59) ----
-    matvec(w.in_w, kDec, kPre2 + kAtt, kDec, S.xin, S.part, [&](int n, float y) {
-      y += w.in_b[n];
-      S.xs[n] = y;
-      S.cat[n] = y;
-      S.catc[n] = y;
-      if (st) st[kStX + n] = y;
-    });
+    phase(w.in_w, kDec, kPre2 + kAtt, kDec, S.xin, S.part, X, XF_X,
+          [&](int n, float y) {
+            y += w.in_b[n];
+            if (st) st[kStX + n] = y;
+            return y;
+          },
+          [&](int n, float v) {
+            S.xs[n] = v;
+            S.cat[n] = v;
+            S.catc[n] = v;
+          });
     __syncthreads();
     // ---- MultiRNNCell[GRUCell(256) x3] inside ONE ResidualWrapper (tacotron.py:54-58) ----
     for (int l = 0; l < 3; ++l) {
       float* cl = S.cat + l * 512;
-      matvec(w.gw[l], 2 * kDec, 2 * kDec, 2 * kDec, cl, S.part, [&](int n, float y) {
-        const float g = sigmoid_f(y + w.gb[l][n]);
-        if (n < kDec) {
-          const float rh = g * cl[kDec + n];
-          S.catc[kDec + n] = rh;
-          if (st) { st[kStR + l * kDec + n] = g; st[kStRH + l * kDec + n] = rh; }
-        } else {
-          S.us[n - kDec] = g;
-          if (st) st[kStU + l * kDec + n - kDec] = g;
-        }
-      });
+      phase(w.gw[l], 2 * kDec, 2 * kDec, 2 * kDec, cl, S.part, X, XF_G + l * 768,
+            [&](int n, float y) {
+              const float g = sigmoid_f(y + w.gb[l][n]);
+              if (n < kDec) {
+                const float rh = g * cl[kDec + n];
+                if (st) { st[kStR + l * kDec + n] = g; st[kStRH + l * kDec + n] = rh; }
+                return rh;
+              }
+              if (st) st[kStU + l * kDec + n - kDec] = g;
+              return g;
+            },
+            [&](int n, float v) {
+              if (n < kDec) S.catc[kDec + n] = v;   // r * h
+              else S.us[n - kDec] = v;              // u
+            });
       __syncthreads();
-      matvec(w.cw[l], kDec, 2 * kDec, kDec, S.catc, S.part, [&](int n, float y) {
-        const float c = tanh_f(y + w.cb[l][n]);
-        const float u = S.us[n];
-        const float hn = u * cl[kDec + n] + (1.f - u) * c;
-        cl[kDec + n] = hn;
-        if (l < 2) {
-          S.cat[(l + 1) * 512 + n] = hn;
-          S.catc[n] = hn;
-        } else {
-          S.ys[n] = S.xs[n] + hn;
-        }
-        if (st) {
-          st[kStC + l * kDec + n] = c;
-          st[kStH + l * kDec + n] = hn;
-          if (l == 2) st[kStY + n] = S.xs[n] + hn;
-        }
-      });
+      phase(w.cw[l], kDec, 2 * kDec, kDec, S.catc, S.part, X, XF_C + l * 768,
+            [&](int n, float y) {
+              const float c = tanh_f(y + w.cb[l][n]);
+              const float u = S.us[n];
+              const float hn = u * cl[kDec + n] + (1.f - u) * c;
+              if (st) {
+                st[kStC + l * kDec + n] = c;
+                st[kStH + l * kDec + n] = hn;
+                if (l == 2) st[kStY + n] = S.xs[n] + hn;
+              }
+              return hn;
+            },
+            [&](int n, float hn) {
+              cl[kDec + n] = hn;
+              if (l < 2) {
+                S.cat[(l + 1) * 512 + n] = hn;
+                S.catc[n] = hn;
+              } else {
+                S.ys[n] = S.xs[n] + hn;
+              }
+            });
       __syncthreads();
     }
     // ---- OutputProjectionWrapper: cell_output = (x + h3) Wo + bo (tacotron.py:54-60) ----
-    matvec(w.out_w, R80, kDec, R80, S.ys, S.part, [&](int n, float y) {
-      y += w.out_b[n];
-      S.octx[n] = y;
-      a.out[bt * R80 + n] = y;
-    });
+    phase(w.out_w, R80, kDec, R80, S.ys, S.part, X, XF_O,
+          [&](int n, float y) {
+            y += w.out_b[n];
+            a.out[bt * R80 + n] = y;
+            return y;
+          },
+          [&](int n, float v) { S.octx[n] = v; });
     __syncthreads();
     // ---- BahdanauAttention: query layer (no bias) ----
-    matvec(w.q_w, kAtt, R80, kAtt, S.octx, S.part, [&](int n, float y) {
-      S.qs[n] = y;
-      if (st) st[kStQ + n] = y;
-    });
+    phase(w.q_w, kAtt, R80, kAtt, S.octx, S.part, X, XF_Q,
+          [&](int n, float y) {
+            if (st) st[kStQ + n] = y;
+            return y;
+          },
+          [&](int n, float v) { S.qs[n] = v; });
     __syncthreads();
-    // ---- energies e[s] = sum_u v_u tanh(keys[s,u] + q_u): one wave per memory row ----
+    // ---- energies e[s] = sum_u v_u tanh(keys[s,u] + q_u): one wave per memory row, rows dealt round-robin to peers ----
     {
       const float4 q4 = reinterpret_cast<const float4*>(S.qs)[lane];
-      for (int s = wave; s < len; s += NT / 64) {
+      for (int s = X.peer + P * wave; s < len; s += P * (NT / 64)) {
         const float4 k4 = reinterpret_cast<const float4*>(keys + (int64_t)s * kAtt)[lane];
         float e = v4.x * tanh_f(k4.x + q4.x) + v4.y * tanh_f(k4.y + q4.y) + v4.z * tanh_f(k4.z + q4.z) +
                   v4.w * tanh_f(k4.w + q4.w);
         e = wave_sum(e);
-        if (lane == 0) S.es[s] = e;
+        if (lane == 0) {
+          S.es[s] = e;
+          if (P > 1) xput(X, XF_E + s, e);
+        }
+      }
+      if (P > 1) {
+        for (int s = tid; s < len; s += NT)
+          if (s % P != X.peer) S.es[s] = xget(X, XF_E + s);
       }
     }
     __syncthreads();
@@ -227,21 +326,25 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
       for (int s = tid; s < Tt; s += NT) {
         const float al = s < len ? expf(S.es[s] - m) * inv : 0.f;
         S.als[s] = al;
-        a.align[bt * Tt + s] = al;
+        if (lead) a.align[bt * Tt + s] = al;
       }
     }
     __syncthreads();
     // ---- context = alignments . values ----
-    matvec(values, kAtt, len, kAtt, S.als, S.part, [&](int n, float y) {
-      S.octx[R80 + n] = y;
-      if (st) st[kStCtx + n] = y;
-    });
+    phase(values, kAtt, len, kAtt, S.als, S.part, X, XF_CTX,
+          [&](int n, float y) {
+            if (st) st[kStCtx + n] = y;
+            return y;
+          },
+          [&](int n, float v) { S.octx[R80 + n] = v; });
     __syncthreads();
     // ---- attention = [cell_output ; context] Wa (attention_layer_size=256, no bias; tacotron.py:76) ----
-    matvec(w.att_w, kAtt, R80 + kAtt, kAtt, S.octx, S.part, [&](int n, float y) {
-      S.xin[kPre2 + n] = y;
-      if (st) st[kStAtt + n] = y;
-    });
+    phase(w.att_w, kAtt, R80 + kAtt, kAtt, S.octx, S.part, X, XF_ATT,
+          [&](int n, float y) {
+            if (st) st[kStAtt + n] = y;
+            return y;
+          },
+          [&](int n, float v) { S.xin[kPre2 + n] = v; });
     // ---- helper.next_inputs: TrainingHelper / ScheduledOutputTrainingHelper / InferenceHelper ----
     if (tid < kMel && t + 1 < Td) {
       float nf;
@@ -270,16 +373,16 @@ struct DecBwdSmem {
   float* dgp;     // 512
   float* dinp;    // 256 gradient into the layer input
   float* dx;      // 256
-  float* dxin;    // 384
   float* dp2;     // 128
   float* dp1;     // 256
   float* qs;      // 256
+  float* red;     // 8*256 cross-wave dq reduction
   float* als;     // TtP
   float* des;     // TtP
-  float* red;     // 8*256 cross-wave dq reduction
+  int* dead;
 };
 constexpr int kBwdSmemFixed =
-    kPartFloats + 768 + 256 + 80 + 656 + 256 + 256 + 256 + 256 + 512 + 256 + 256 + 384 + 128 + 256 + 256 + 8 * 256;
+    kPartFloats + 768 + 256 + 80 + 656 + 256 + 256 + 256 + 256 + 512 + 256 + 256 + 128 + 256 + 256 + 8 * 256 + 4;
 
 __device__ __forceinline__ DecBwdSmem carve_bwd(float* base, int TtP) {
   DecBwdSmem s;
@@ -296,25 +399,34 @@ __device__ __forceinline__ DecBwdSmem carve_bwd(float* base, int TtP) {
   s.dgp = p; p += 512;
   s.dinp = p; p += 256;
   s.dx = p; p += 256;
-  s.dxin = p; p += 384;
   s.dp2 = p; p += 128;
   s.dp1 = p; p += 256;
   s.qs = p; p += 256;
   s.red = p; p += 8 * 256;
   s.als = p; p += TtP;
   s.des = p; p += TtP;
+  s.dead = reinterpret_cast<int*>(p); p += 4;
   return s;
 }
 
 __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.x;
+  const int P = a.P;
+  const int b = blockIdx.x / P;
   const int B = a.B, Tt = a.Tt, Td = a.Td, r = a.r;
   const int R80 = kMel * r;
   const int TtP = (Tt + 3) & ~3;
   DecBwdSmem S = carve_bwd(smem, TtP);
   const DecWeights& w = a.wT;
+  Xchg X;
+  X.P = P;
+  X.peer = blockIdx.x - b * P;
+  X.base = reinterpret_cast<u64*>(a.xchg) + (int64_t)b * (kXchgFixed + TtP);
+  X.err = a.err;
+  X.dead = S.dead;
+  X.epoch = 0;
+  const bool lead = X.peer == 0;
 
   int len = a.text_length[b];
   len = len < 1 ? 1 : (len > Tt ? Tt : len);
@@ -326,11 +438,13 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
   if (tid < 256) S.datt[tid] = 0.f;
   if (tid < 80) S.dfr[tid] = 0.f;
   for (int i = tid; i < TtP; i += NT) { S.als[i] = 0.f; S.des[i] = 0.f; }
+  if (tid == 0) *S.dead = 0;
   const float4 v4 = reinterpret_cast<const float4*>(a.att_v)[lane];
   float4 dv4 = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
 
   for (int t = Td - 1; t >= 0; --t) {
+    X.epoch = (unsigned)(Td - t);
     const int64_t bt = (int64_t)b * Td + t;
     const float* st = a.stash + bt * kStRec;
     const float* stp = t > 0 ? a.stash + (bt - 1) * kStRec : nullptr;
@@ -338,33 +452,40 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
     const bool next_from_out = (t + 1 < Td) && a.sample && a.sample[(int64_t)t * B + b];
     const bool this_from_out = (t > 0) && a.sample && a.sample[(int64_t)(t - 1) * B + b];
 
-    // 1. d cell_output: direct (loss + post-net) + sampled next-input path
+    // 1. d cell_output: direct (loss + post-net) + sampled next-input path (replicated on every peer)
     for (int n = tid; n < R80; n += NT) {
       float g = a.dout[bt * R80 + n];
       if (next_from_out && n >= kMel * (r - 1)) g += S.dfr[n - kMel * (r - 1)];
       S.dov[n] = g;
     }
-    if (tid < kAtt) gs[kGsAtt + tid] = S.datt[tid];
+    if (lead && tid < kAtt) gs[kGsAtt + tid] = S.datt[tid];
     for (int s = tid; s < Tt; s += NT) S.als[s] = a.align[bt * Tt + s];
     if (tid < kAtt) S.qs[tid] = st[kStQ + tid];
     __syncthreads();
     // 2. attention layer: d[o ; ctx] += datt . Wa^T      (wT.att_w is (256, 80r+256))
-    matvec(w.att_w, R80 + kAtt, kAtt, R80 + kAtt, S.datt, S.part, [&](int n, float y) {
-      if (n < R80) S.dov[n] += y;
-      else {
-        S.dov[n] = y;
-        gs[kGsCtx + n - R80] = y;
-      }
-    });
+    phase(w.att_w, R80 + kAtt, kAtt, R80 + kAtt, S.datt, S.part, X, XB_ATT,
+          [&](int n, float y) {
+            if (n < R80) return S.dov[n] + y;
+            gs[kGsCtx + n - R80] = y;
+            return y;
+          },
+          [&](int n, float v) { S.dov[n] = v; });
     __syncthreads();
-    // 3a. d alignments[s] = values[s] . dctx
+    // 3a. d alignments[s] = values[s] . dctx   (memory rows dealt round-robin to peers)
     {
       const float4 c4 = reinterpret_cast<const float4*>(S.dov + R80)[lane];
-      for (int s = wave; s < len; s += NT / 64) {
+      for (int s = X.peer + P * wave; s < len; s += P * (NT / 64)) {
         const float4 x4 = reinterpret_cast<const float4*>(values + (int64_t)s * kAtt)[lane];
         float d = x4.x * c4.x + x4.y * c4.y + x4.z * c4.z + x4.w * c4.w;
         d = wave_sum(d);
-        if (lane == 0) S.des[s] = d;
+        if (lane == 0) {
+          S.des[s] = d;
+          if (P > 1) xput(X, XB_DAL + s, d);
+        }
+      }
+      if (P > 1) {
+        for (int s = tid; s < len; s += NT)
+          if (s % P != X.peer) S.des[s] = xget(X, XB_DAL + s);
       }
     }
     __syncthreads();
@@ -377,11 +498,11 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
       for (int s = tid; s < len; s += NT) S.des[s] = S.als[s] * (S.des[s] - dot);
     }
     __syncthreads();
-    // 3c. energy backward: th = tanh(keys+q); dpre = de*v*(1-th^2); dq += dpre; dkeys += dpre; dv += de*th
+    // 3c. energy backward on this peer's rows: th = tanh(keys+q); dpre = de*v*(1-th^2); dq += dpre; dkeys += dpre; dv += de*th
     {
       const float4 q4 = reinterpret_cast<const float4*>(S.qs)[lane];
       float4 dq4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int s = wave; s < len; s += NT / 64) {
+      for (int s = X.peer + P * wave; s < len; s += P * (NT / 64)) {
         const float de = S.des[s];
         const float4 k4 = reinterpret_cast<const float4*>(keys + (int64_t)s * kAtt)[lane];
         float4 dk = reinterpret_cast<float4*>(dkeys + (int64_t)s * kAtt)[lane];
@@ -400,22 +521,30 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
       float d = 0.f;
 #pragma unroll
       for (int i = 0; i < NT / 64; ++i) d += S.red[i * 256 + tid];
+      if (P > 1) {
+        xput(X, XB_DQP + X.peer * 256 + tid, d);
+        for (int p = 0; p < P; ++p)
+          if (p != X.peer) d += xget(X, XB_DQP + p * 256 + tid);
+      }
       S.dq[tid] = d;
-      gs[kGsQ + tid] = d;
+      if (lead) gs[kGsQ + tid] = d;
     }
     __syncthreads();
     // 4. query layer: do += dq . Wq^T   (wT.q_w is (256, 80r))
-    matvec(w.q_w, R80, kAtt, R80, S.dq, S.part, [&](int n, float y) {
-      const float g = S.dov[n] + y;
-      S.dov[n] = g;
-      gs[kGsO + n] = g;
-    });
+    phase(w.q_w, R80, kAtt, R80, S.dq, S.part, X, XB_Q,
+          [&](int n, float y) {
+            const float g = S.dov[n] + y;
+            gs[kGsO + n] = g;
+            return g;
+          },
+          [&](int n, float v) { S.dov[n] = v; });
     __syncthreads();
     // 5. output projection: dy = do . Wo^T   (wT.out_w is (80r, 256))
-    matvec(w.out_w, kDec, R80, kDec, S.dov, S.part, [&](int n, float y) {
-      S.dy[n] = y;
-      S.dht[n] = S.dh[2 * kDec + n] + y;   // dL/dh3' = carried + residual path
-    });
+    phase(w.out_w, kDec, R80, kDec, S.dov, S.part, X, XB_OUT, [&](int n, float y) { return y; },
+          [&](int n, float v) {
+            S.dy[n] = v;
+            S.dht[n] = S.dh[2 * kDec + n] + v;   // dL/dh3' = carried + residual path
+          });
     __syncthreads();
     // 6. GRU layers, top down
     for (int l = 2; l >= 0; --l) {
@@ -427,64 +556,83 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
         const float du = dht * (hp - c);
         const float dc = dht * (1.f - u);
         const float dcp = dc * (1.f - c * c);
+        const float dup = du * u * (1.f - u);
         S.dcp[n] = dcp;
-        S.dgp[kDec + n] = du * u * (1.f - u);
-        gs[kGsC + l * kDec + n] = dcp;
-        gs[kGsG + l * 512 + kDec + n] = du * u * (1.f - u);
+        S.dgp[kDec + n] = dup;
+        if (lead) {
+          gs[kGsC + l * kDec + n] = dcp;
+          gs[kGsG + l * 512 + kDec + n] = dup;
+        }
       }
       __syncthreads();
       // [d inp ; d(r*h)] = dcp . Wc^T     (wT.cw[l] is (256, 512))
-      matvec(w.cw[l], 2 * kDec, kDec, 2 * kDec, S.dcp, S.part, [&](int n, float y) {
-        if (n < kDec) {
-          S.dinp[n] = y;
-        } else {
-          const int i = n - kDec;
-          const float rr = st[kStR + l * kDec + i];
-          const float hp = stp ? stp[kStH + l * kDec + i] : 0.f;
-          const float drp = y * hp * rr * (1.f - rr);
-          S.dgp[i] = drp;
-          gs[kGsG + l * 512 + i] = drp;
-          // partial new carry: dht*u + d(rh)*r
-          S.dh[l * kDec + i] = S.dht[i] * st[kStU + l * kDec + i] + y * rr;
-        }
-      });
+      phase(w.cw[l], 2 * kDec, kDec, 2 * kDec, S.dcp, S.part, X, XB_C + l * 1024,
+            [&](int n, float y) {
+              if (n >= kDec) {
+                const int i = n - kDec;
+                const float rr = st[kStR + l * kDec + i];
+                const float hp = stp ? stp[kStH + l * kDec + i] : 0.f;
+                gs[kGsG + l * 512 + i] = y * hp * rr * (1.f - rr);
+              }
+              return y;
+            },
+            [&](int n, float y) {
+              if (n < kDec) {
+                S.dinp[n] = y;
+              } else {
+                const int i = n - kDec;
+                const float rr = st[kStR + l * kDec + i];
+                const float hp = stp ? stp[kStH + l * kDec + i] : 0.f;
+                S.dgp[i] = y * hp * rr * (1.f - rr);
+                // partial new carry: dht*u + d(rh)*r
+                S.dh[l * kDec + i] = S.dht[i] * st[kStU + l * kDec + i] + y * rr;
+              }
+            });
       __syncthreads();
       // [d inp ; d h] += dgp . Wg^T       (wT.gw[l] is (512, 512))
-      matvec(w.gw[l], 2 * kDec, 2 * kDec, 2 * kDec, S.dgp, S.part, [&](int n, float y) {
-        if (n < kDec) {
-          const float di = S.dinp[n] + y;
-          if (l > 0) S.dht[n] = S.dh[(l - 1) * kDec + n] + di;   // next layer down: carried + input path
-          else S.dx[n] = S.dy[n] + di;                            // x feeds GRU1 and the residual
-        } else {
-          S.dh[l * kDec + n - kDec] += y;
-        }
-      });
+      phase(w.gw[l], 2 * kDec, 2 * kDec, 2 * kDec, S.dgp, S.part, X, XB_G + l * 1024, [&](int n, float y) { return y; },
+            [&](int n, float y) {
+              if (n < kDec) {
+                const float di = S.dinp[n] + y;
+                if (l > 0) S.dht[n] = S.dh[(l - 1) * kDec + n] + di;   // next layer down: carried + input path
+                else S.dx[n] = S.dy[n] + di;                            // x feeds GRU1 and the residual
+              } else {
+                S.dh[l * kDec + n - kDec] += y;
+              }
+            });
       __syncthreads();
     }
-    if (tid < kDec) gs[kGsX + tid] = S.dx[tid];
+    if (lead && tid < kDec) gs[kGsX + tid] = S.dx[tid];
     // 7. input projection: d[p2 ; att_{t-1}] = dx . Wi^T   (wT.in_w is (256, 384))
-    matvec(w.in_w, kPre2 + kAtt, kDec, kPre2 + kAtt, S.dx, S.part, [&](int n, float y) {
-      if (n < kPre2) {
-        const float p2 = st[kStP2 + n];
-        const float g = p2 > 0.f ? (a.keep2 ? 2.f * y : y) : 0.f;
-        S.dp2[n] = g;
-        gs[kGsP2 + n] = g;
-      } else {
-        S.datt[n - kPre2] = y;
-      }
-    });
+    phase(w.in_w, kPre2 + kAtt, kDec, kPre2 + kAtt, S.dx, S.part, X, XB_IN,
+          [&](int n, float y) {
+            if (n < kPre2) {
+              const float p2 = st[kStP2 + n];
+              const float g = p2 > 0.f ? (a.keep2 ? 2.f * y : y) : 0.f;
+              gs[kGsP2 + n] = g;
+              return g;
+            }
+            return y;
+          },
+          [&](int n, float v) {
+            if (n < kPre2) S.dp2[n] = v;
+            else S.datt[n - kPre2] = v;
+          });
     __syncthreads();
     // 8. pre-net layer 2: dp1 = dp2pre . W2^T   (wT.pre_w2 is (128, 256))
-    matvec(w.pre_w2, kPre1, kPre2, kPre1, S.dp2, S.part, [&](int n, float y) {
-      const float p1 = st[kStP1 + n];
-      const float g = p1 > 0.f ? (a.keep1 ? 2.f * y : y) : 0.f;
-      S.dp1[n] = g;
-      gs[kGsP1 + n] = g;
-    });
+    phase(w.pre_w2, kPre1, kPre2, kPre1, S.dp2, S.part, X, XB_P2,
+          [&](int n, float y) {
+            const float p1 = st[kStP1 + n];
+            const float g = p1 > 0.f ? (a.keep1 ? 2.f * y : y) : 0.f;
+            gs[kGsP1 + n] = g;
+            return g;
+          },
+          [&](int n, float v) { S.dp1[n] = v; });
     __syncthreads();
     // 9. pre-net layer 1 input gradient, only when this step's input was the previous cell_output
     if (this_from_out) {
-      matvec(w.pre_w1, kMel, kPre1, kMel, S.dp1, S.part, [&](int n, float y) { S.dfr[n] = y; });
+      phase(w.pre_w1, kMel, kPre1, kMel, S.dp1, S.part, X, XB_P1, [&](int n, float y) { return y; },
+            [&](int n, float v) { S.dfr[n] = v; });
       __syncthreads();
     }
   }
@@ -499,11 +647,37 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
   }
 }
 
+// Largest cluster width in {8,4,2,1} whose B*P workgroups are all co-resident (the all-gather needs every peer running).
+template <class K>
+int pick_cluster(K kernel, size_t smem, int B, int want) {
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 1;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, NT, smem) != hipSuccess) return 1;
+  const int64_t cap = (int64_t)cus * per_cu;
+  for (int p = 8; p >= 2; p >>= 1)
+    if (p <= want && (int64_t)B * p <= cap) return p;
+  return 1;
+}
+
+int env_cluster() {
+  const char* e = getenv("TACO_DEC_CLUSTER");
+  if (!e) return 8;
+  const int v = atoi(e);
+  return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 8;
+}
+
 }  // namespace
 
-int launch_decoder_fwd(const DecFwdArgs& a, hipStream_t s) {
+int64_t decoder_xchg_bytes(int B, int Tt) {
+  const int TtP = (Tt + 3) & ~3;
+  return (int64_t)B * (kXchgFixed + TtP) * 8;
+}
+
+int launch_decoder_fwd(DecFwdArgs a, hipStream_t s) {
   TACO_REQUIRE(a.B > 0 && a.Tt > 0 && a.Td > 0 && a.r >= 1 && a.r <= 5, "decoder_fwd: bad dims B=%d Tt=%d Td=%d r=%d", a.B,
                a.Tt, a.Td, a.r);
+  TACO_REQUIRE(a.xchg && a.err, "decoder_fwd: exchange area missing");
   const int TtP = (a.Tt + 3) & ~3;
   const size_t smem = (size_t)(kFwdSmemFixed + 2 * TtP) * sizeof(float);
   TACO_REQUIRE(smem <= 160 * 1024, "decoder_fwd: Tt=%d needs %zu bytes of LDS (> 160 KiB)", a.Tt, smem);
@@ -515,13 +689,22 @@ int launch_decoder_fwd(const DecFwdArgs& a, hipStream_t s) {
       return TACO_ELAUNCH;
     }
   }
-  hipLaunchKernelGGL(decoder_fwd_kernel, dim3(a.B), dim3(NT), smem, s, a);
+  a.P = pick_cluster(decoder_fwd_kernel, smem, a.B, env_cluster());
+  if (a.P > 1) {
+    hipError_t e = hipMemsetAsync(a.xchg, 0, (size_t)decoder_xchg_bytes(a.B, a.Tt), s);
+    if (e != hipSuccess) {
+      taco_set_error("decoder_fwd: memset: %s", hipGetErrorString(e));
+      return TACO_ELAUNCH;
+    }
+  }
+  hipLaunchKernelGGL(decoder_fwd_kernel, dim3(a.B * a.P), dim3(NT), smem, s, a);
   TACO_LAUNCH_CHECK("decoder_fwd");
   return TACO_OK;
 }
 
-int launch_decoder_bwd(const DecBwdArgs& a, hipStream_t s) {
+int launch_decoder_bwd(DecBwdArgs a, hipStream_t s) {
   TACO_REQUIRE(a.B > 0 && a.Tt > 0 && a.Td > 0 && a.r >= 1 && a.r <= 5, "decoder_bwd: bad dims");
+  TACO_REQUIRE(a.xchg && a.err, "decoder_bwd: exchange area missing");
   const int TtP = (a.Tt + 3) & ~3;
   const size_t smem = (size_t)(kBwdSmemFixed + 2 * TtP) * sizeof(float);
   TACO_REQUIRE(smem <= 160 * 1024, "decoder_bwd: Tt=%d needs %zu bytes of LDS (> 160 KiB)", a.Tt, smem);
@@ -533,7 +716,15 @@ int launch_decoder_bwd(const DecBwdArgs& a, hipStream_t s) {
       return TACO_ELAUNCH;
     }
   }
-  hipLaunchKernelGGL(decoder_bwd_kernel, dim3(a.B), dim3(NT), smem, s, a);
+  a.P = pick_cluster(decoder_bwd_kernel, smem, a.B, env_cluster());
+  if (a.P > 1) {
+    hipError_t e = hipMemsetAsync(a.xchg, 0, (size_t)decoder_xchg_bytes(a.B, a.Tt), s);
+    if (e != hipSuccess) {
+      taco_set_error("decoder_bwd: memset: %s", hipGetErrorString(e));
+      return TACO_ELAUNCH;
+    }
+  }
+  hipLaunchKernelGGL(decoder_bwd_kernel, dim3(a.B * a.P), dim3(NT), smem, s, a);
   TACO_LAUNCH_CHECK("decoder_bwd");
   return TACO_OK;
 }

@@ -142,9 +142,13 @@ struct DecFwdArgs {
   float* align;          // (B,Td,Tt)
   float* stash;          // (B,Td,kStRec) or null
   float* prein;          // (B,Td,80) pre-net input frames actually used (train stash) or null
+  void* xchg;            // decoder_xchg_bytes(B,Tt): granule area for the in-launch all-gathers
+  int* err;              // set to 1 by the kernel if a bounded spin timed out
   int B, Tt, Td, r;
+  int P;                 // cluster width (workgroups per row); chosen by launch_decoder_fwd
 };
-int launch_decoder_fwd(const DecFwdArgs& a, hipStream_t s);
+int64_t decoder_xchg_bytes(int B, int Tt);
+int launch_decoder_fwd(DecFwdArgs a, hipStream_t s);
 
 struct DecBwdArgs {
   DecWeights wT;         // every matrix TRANSPOSED (out,in); biases unused
@@ -162,6 +166,9 @@ struct DecBwdArgs {
   float* gstash;         // (B,Td,kGsRec)
   float* dkeys;          // (B,Tt,256) zero-initialised, accumulated
   float* datt_v;         // (256) accumulated (atomics)
+  void* xchg;
+  int* err;
   int B, Tt, Td, r;
+  int P;
 };
-int launch_decoder_bwd(const DecBwdArgs& a, hipStream_t s);
+int launch_decoder_bwd(DecBwdArgs a, hipStream_t s);

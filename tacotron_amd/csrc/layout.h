@@ -73,7 +73,7 @@ struct WsLayout {
   int64_t emb, p1, p2;
   CbhgWs enc;
   int64_t values, keys;
-  int64_t stash, prein;
+  int64_t stash, prein, xchg, err;
   CbhgWs post;
   int64_t loss;  // 4 floats
   // backward

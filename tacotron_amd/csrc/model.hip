@@ -208,7 +208,15 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
   da.out = s2s; da.align = align;
   da.stash = train ? ws + W.stash : nullptr;
   da.prein = train ? ws + W.prein : nullptr;
-  da.B = B; da.Tt = Tt; da.Td = Td; da.r = r;
+  da.xchg = ws + W.xchg; da.err = reinterpret_cast<int*>(ws + W.err);
+  da.B = B; da.Tt = Tt; da.Td = Td; da.r = r; da.P = 1;
+  {
+    hipError_t e = hipMemsetAsync(ws + W.err, 0, 64 * sizeof(float), s);
+    if (e != hipSuccess) {
+      taco_set_error("forward: memset: %s", hipGetErrorString(e));
+      return TACO_ELAUNCH;
+    }
+  }
   {
     const int slot = prof_begin(0, s);
     TACO_TRY(launch_decoder_fwd(da, s));
@@ -520,7 +528,8 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     a.keep1 = dec_keep1; a.keep2 = dec_keep2; a.sample = sample;
     a.dout = dS2S; a.out = seq2seq_output; a.align = alignments; a.stash = st; a.gstash = gs;
     a.dkeys = ws + W.dkeys; a.datt_v = G + PL.att_v;
-    a.B = B; a.Tt = Tt; a.Td = Td; a.r = r;
+    a.xchg = ws + W.xchg; a.err = reinterpret_cast<int*>(ws + W.err) + 1;
+    a.B = B; a.Tt = Tt; a.Td = Td; a.r = r; a.P = 1;
     const int slot = prof_begin(1, s);
     TACO_TRY(launch_decoder_bwd(a, s));
     prof_end(1, slot, s);

@@ -48,14 +48,22 @@ class Runner:
         self.lib.forward(self.shape, self.pb.flat, self.text, self.tl, self.mel, self.stft, self.masks, self.s2s, self.out,
                          self.al, self.loss, self.ws)
         torch.cuda.synchronize()
+        self.check_err()
 
     def backward(self):
         self.lib.backward(self.shape, self.pb.flat, self.text, self.tl, self.s2s, self.al, self.masks, self.grads, self.ws)
         torch.cuda.synchronize()
+        self.check_err()
 
     def infer(self):
         self.lib.infer(self.shape, self.pb.flat, self.text, self.tl, self.s2s, self.out, self.al, self.ws)
         torch.cuda.synchronize()
+        self.check_err()
+
+    def check_err(self):
+        o, s, d = self.wtab['dec.err']
+        flags = self.ws[o:o + 2].view(torch.int32).cpu().numpy()
+        assert flags[0] == 0 and flags[1] == 0, 'decoder cluster exchange timed out: %s' % flags
 
     def wsget(self, name):
         o, s, d = self.wtab[name]
