@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256, 1) void bigru_fwd_kernel(const float* __restri
     for (int k = 0; k < H / 2; ++k) wch[k] = wc[(int64_t)k * H];
   }
   if (j < H) hs[j] = 0.f;
-  __syncthreads();
+  lds_barrier();
 
   const int64_t row0 = (int64_t)b * T;
   const int tstart = d == 0 ? 0 : T - 1, tstep = d == 0 ? 1 : -1;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256, 1) void bigru_fwd_kernel(const float* __restri
     const float hprev = hs[col];
     if (half == 0) rhs[col] = g * hprev;   // r * h
     else us[col] = g;                      // u
-    __syncthreads();
+    lds_barrier();
     // ---- candidate: thread (col, half) reduces its half of r*h ----
     float p0 = 0.f, p1 = 0.f;
 #pragma unroll
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, 1) void bigru_fwd_kernel(const float* __restri
       p1 = fmaf(rv.w, wch[4 * k4 + 3], p1);
     }
     if (half == 1) cpart[col] = p0 + p1;
-    __syncthreads();
+    lds_barrier();
     if (half == 0) {
       const float c = tanh_f(xg_c + p0 + p1 + cpart[col]);
       const float u = us[col];
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256, 1) void bigru_fwd_kernel(const float* __restri
     }
     xg_g = nxg_g;
     xg_c = nxg_c;
-    __syncthreads();
+    lds_barrier();
   }
 }
 
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256, 1) void bigru_bwd_kernel(const float* __restri
       xo[H + col] = dup;
       rh_out[(row0 + t) * (2 * H) + d * H + col] = r * hp;
     }
-    __syncthreads();
+    lds_barrier();
     // d(rh)[col] partial
     float p0 = 0.f, p1 = 0.f;
 #pragma unroll
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, 1) void bigru_bwd_kernel(const float* __restri
       p1 = fmaf(v.w, wc_r[4 * i4 + 3], p1);
     }
     if (half == 1) part_s[0][col] = p0 + p1;
-    __syncthreads();
+    lds_barrier();
     float dh_acc = 0.f;
     if (half == 0) {
       const float drh = p0 + p1 + part_s[0][col];
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256, 1) void bigru_bwd_kernel(const float* __restri
       dxg[(row0 + t) * (6 * H) + d * 3 * H + col] = drp;
       dh_acc = dht * u + drh * r;
     }
-    __syncthreads();
+    lds_barrier();
     float q0 = 0.f, q1 = 0.f;
 #pragma unroll
     for (int i4 = 0; i4 < H / 4; ++i4) {
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256, 1) void bigru_bwd_kernel(const float* __restri
       q1 = fmaf(v.w, wg_r[4 * i4 + 3], q1);
     }
     if (half == 1) part_s[1][col] = q0 + q1;
-    __syncthreads();
+    lds_barrier();
     if (half == 0) dh = dh_acc + q0 + q1 + part_s[1][col];
   }
 }

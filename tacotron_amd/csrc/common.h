@@ -64,6 +64,10 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Workgroup barrier for LDS-only communication: waits for this wave's LDS traffic (lgkmcnt) but NOT for its outstanding
+// global loads/stores (vmcnt), unlike __syncthreads(), so prefetch loads and stash stores stay in flight across it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ float apply_act(float x, int act) {
   switch (act) {
     case TACO_ACT_RELU: return fmaxf(x, 0.0f);

@@ -34,7 +34,14 @@ struct Xchg {
   int P, peer;
   int* err;         // global error word
   int* dead;        // LDS: set once this workgroup has given up polling
+  long long* trace; // optional: 4 wall_clock64 stamps per phase (enabled for one workgroup at one step), else null
+  int tslot;
 };
+
+// stamp k (0 entry, 1 partials done, 2 own slice published, 3 gather done) of the current phase
+__device__ __forceinline__ void tstamp(const Xchg& X, int k) {
+  if (X.trace && threadIdx.x == 0) X.trace[X.tslot * 4 + k] = wall_clock64();
+}
 
 __device__ __forceinline__ void xput(const Xchg& X, int idx, float v) {
   __hip_atomic_store((gu64*)(X.base + idx), ((u64)X.epoch << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED,
@@ -59,24 +66,28 @@ __device__ __forceinline__ float xget(const Xchg& X, int idx) {
 
 // One mat-vec phase of the cluster:  y[n] = sum_k x[k] * W[k*ldw + n]  for this peer's column slice, then
 //   v = epi(n, y) (owner only: activation, stash writes), put(n, v) on EVERY peer (LDS state update) after the all-gather.
-// x lives in LDS and must be readable up to K rounded up to 4.  N % 4 == 0 and N/4 >= P.  Contains ONE __syncthreads();
+// x lives in LDS and must be readable up to K rounded up to 4.  N % 4 == 0 and N/4 >= P.  Contains ONE lds_barrier();
 // the caller must __syncthreads() afterwards before `part`/x/the put() targets are reused.
 template <class Epi, class Put>
 __device__ __forceinline__ void phase(const float* __restrict__ W, int ldw, int K, int N, const float* x, float* part,
                                       const Xchg& X, int reg, Epi epi, Put put) {
   const int tid = threadIdx.x;
+  tstamp(X, 0);
   const int N4 = N >> 2;
   const int g0 = (X.peer * N4) / X.P, g1 = ((X.peer + 1) * N4) / X.P;
   const int n4 = g1 - g0;
   const int nloc = n4 * 4;
+  // k-groups: threads with equal c4 split K.  When n4 divides 64 the lanes of a wave that share c4 are reduced with
+  // __shfl_xor and only 8 per-wave partials reach LDS; otherwise up to kMaxKG partial rows go through LDS.
+  const bool shfl = (64 % n4) == 0;
   int KG = NT / n4;
-  KG = KG > kMaxKG ? kMaxKG : KG;
+  if (!shfl && KG > kMaxKG) KG = kMaxKG;
   const int kg = tid / n4, c4 = tid - kg * n4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (kg < KG) {
     const int Kc = (((K + KG - 1) / KG) + 3) & ~3;
     const int k0 = kg * Kc;
     const int k1 = min(K, k0 + Kc);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* wp = W + (int64_t)k0 * ldw + (g0 + c4) * 4;
     int k = k0;
 #pragma unroll 2
@@ -98,24 +109,49 @@ __device__ __forceinline__ void phase(const float* __restrict__ W, int ldw, int 
       wp += ldw;
       acc.x = fmaf(xs, w0.x, acc.x); acc.y = fmaf(xs, w0.y, acc.y); acc.z = fmaf(xs, w0.z, acc.z); acc.w = fmaf(xs, w0.w, acc.w);
     }
-    *reinterpret_cast<float4*>(part + kg * nloc + c4 * 4) = acc;
   }
-  __syncthreads();
+  int rows;  // partial rows in LDS
+  if (shfl) {
+    for (int off = n4; off < 64; off <<= 1) {
+      acc.x += __shfl_xor(acc.x, off, 64);
+      acc.y += __shfl_xor(acc.y, off, 64);
+      acc.z += __shfl_xor(acc.z, off, 64);
+      acc.w += __shfl_xor(acc.w, off, 64);
+    }
+    if ((tid & 63) < n4) *reinterpret_cast<float4*>(part + (tid >> 6) * nloc + c4 * 4) = acc;
+    rows = NT / 64;
+  } else {
+    if (kg < KG) *reinterpret_cast<float4*>(part + kg * nloc + c4 * 4) = acc;
+    rows = KG;
+  }
+  tstamp(X, 1);
+  lds_barrier();
   const int nbeg = g0 * 4;
   for (int i = tid; i < nloc; i += NT) {
-    float y = 0.f;
-    for (int g = 0; g < KG; ++g) y += part[g * nloc + i];
+    float y0 = 0.f, y1 = 0.f, y2 = 0.f, y3 = 0.f;
+    int g = 0;
+#pragma unroll 2
+    for (; g + 3 < rows; g += 4) {
+      y0 += part[g * nloc + i];
+      y1 += part[(g + 1) * nloc + i];
+      y2 += part[(g + 2) * nloc + i];
+      y3 += part[(g + 3) * nloc + i];
+    }
+    for (; g < rows; ++g) y0 += part[g * nloc + i];
     const int n = nbeg + i;
-    const float v = epi(n, y);
+    const float v = epi(n, (y0 + y1) + (y2 + y3));
     put(n, v);
     if (X.P > 1) xput(X, reg + n, v);
   }
+  tstamp(X, 2);
   if (X.P > 1) {
     for (int n = tid; n < N; n += NT) {
       if (n >= nbeg && n < nbeg + nloc) continue;
       put(n, xget(X, reg + n));
     }
   }
+  tstamp(X, 3);
+  const_cast<Xchg&>(X).tslot++;
 }
 
 // ---- forward exchange regions (granule indices within a row's area) ----
@@ -140,8 +176,14 @@ struct DecSmem {
   float* qs;     // 256
   float* es;     // TtP energies
   float* als;    // TtP alignments
+  float* bias;   // kBiasFloats: every decoder bias, staged once
+  float* km1;    // 256 pre-net dropout multipliers (2 / 0, or 1 without dropout) of the current step
+  float* km2;    // 128
   int* dead;
 };
+// bias staging offsets
+constexpr int BO_P1 = 0, BO_P2 = 256, BO_IN = 384, BO_G = 640 /* +l*768 */, BO_C = 1152 /* +l*768 */, BO_O = 2944;
+constexpr int kBiasFloats = 3344;
 
 __device__ __forceinline__ DecSmem carve(float* base, int TtP) {
   DecSmem s;
@@ -159,10 +201,14 @@ __device__ __forceinline__ DecSmem carve(float* base, int TtP) {
   s.qs = p; p += 256;
   s.es = p; p += TtP;
   s.als = p; p += TtP;
+  s.bias = p; p += kBiasFloats;
+  s.km1 = p; p += 256;
+  s.km2 = p; p += 128;
   s.dead = reinterpret_cast<int*>(p); p += 4;
   return s;
 }
-constexpr int kFwdSmemFixed = kPartFloats + 80 + 256 + 384 + 256 + 3 * 512 + 512 + 256 + 256 + 656 + 256 + 4;
+constexpr int kFwdSmemFixed =
+    kPartFloats + 80 + 256 + 384 + 256 + 3 * 512 + 512 + 256 + 256 + 656 + 256 + kBiasFloats + 256 + 128 + 4;
 
 __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -181,6 +227,8 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
   X.err = a.err;
   X.dead = S.dead;
   X.epoch = 0;
+  X.trace = nullptr;
+  X.tslot = 0;
   const bool lead = X.peer == 0;
 
   int len = a.text_length[b];
@@ -195,11 +243,29 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
   for (int i = tid; i < 656; i += NT) S.octx[i] = 0.f;
   if (tid < kMel) S.fr[tid] = a.mel ? a.mel[((int64_t)b * Td) * R80 + kMel * (r - 1) + tid] : 0.f;
   if (tid == 0) *S.dead = 0;
+  for (int i = tid; i < kPre1; i += NT) S.bias[BO_P1 + i] = w.pre_b1[i];
+  for (int i = tid; i < kPre2; i += NT) S.bias[BO_P2 + i] = w.pre_b2[i];
+  for (int i = tid; i < kDec; i += NT) S.bias[BO_IN + i] = w.in_b[i];
+  for (int l = 0; l < 3; ++l) {
+    for (int i = tid; i < 2 * kDec; i += NT) S.bias[BO_G + l * 768 + i] = w.gb[l][i];
+    for (int i = tid; i < kDec; i += NT) S.bias[BO_C + l * 768 + i] = w.cb[l][i];
+  }
+  for (int i = tid; i < R80; i += NT) S.bias[BO_O + i] = w.out_b[i];
+  if (tid < kPre1) S.km1[tid] = a.keep1 ? (a.keep1[((int64_t)b * Td) * kPre1 + tid] ? 2.f : 0.f) : 1.f;
+  if (tid < kPre2) S.km2[tid] = a.keep2 ? (a.keep2[((int64_t)b * Td) * kPre2 + tid] ? 2.f : 0.f) : 1.f;
   const float4 v4 = reinterpret_cast<const float4*>(w.att_v)[lane];
-  __syncthreads();
+  lds_barrier();
 
   for (int t = 0; t < Td; ++t) {
     X.epoch = (unsigned)(t + 1);
+    // dropout multipliers of the NEXT step: issued now, parked in a register, written to LDS at the end of this step
+    float km1n = 1.f, km2n = 1.f;
+    if (t + 1 < Td) {
+      if (a.keep1 && tid < kPre1) km1n = a.keep1[((int64_t)b * Td + t + 1) * kPre1 + tid] ? 2.f : 0.f;
+      if (a.keep2 && tid < kPre2) km2n = a.keep2[((int64_t)b * Td + t + 1) * kPre2 + tid] ? 2.f : 0.f;
+    }
+    X.trace = (a.trace && blockIdx.x == 0 && t == Td / 2) ? a.trace : nullptr;
+    X.tslot = 0;
     const int64_t bt = (int64_t)b * Td + t;
     float* st = a.stash ? a.stash + bt * kStRec : nullptr;
     if (a.prein && lead && tid < kMel) a.prein[bt * kMel + tid] = S.fr[tid];
@@ -207,26 +273,24 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
     // ---- pre_net (tacotron.py:38-44, 64-71) ----
     phase(w.pre_w1, kPre1, kMel, kPre1, S.fr, S.part, X, XF_P1,
           [&](int n, float y) {
-            y = fmaxf(y + w.pre_b1[n], 0.f);
-            if (a.keep1) y = a.keep1[bt * kPre1 + n] ? 2.f * y : 0.f;
+            y = fmaxf(y + S.bias[BO_P1 + n], 0.f) * S.km1[n];
             if (st) st[kStP1 + n] = y;
             return y;
           },
           [&](int n, float v) { S.p1[n] = v; });
-    __syncthreads();
+    lds_barrier();
     phase(w.pre_w2, kPre2, kPre1, kPre2, S.p1, S.part, X, XF_P2,
           [&](int n, float y) {
-            y = fmaxf(y + w.pre_b2[n], 0.f);
-            if (a.keep2) y = a.keep2[bt * kPre2 + n] ? 2.f * y : 0.f;
+            y = fmaxf(y + S.bias[BO_P2 + n], 0.f) * S.km2[n];
             if (st) st[kStP2 + n] = y;
             return y;
           },
           [&](int n, float v) { S.xin[n] = v; });
-    __syncthreads();
+    lds_barrier();
     // ---- InputProjectionWrapper: x = [pre_net ; attention] Wi + bi (tacotron.py:56-59) ----
     phase(w.in_w, kDec, kPre2 + kAtt, kDec, S.xin, S.part, X, XF_X,
           [&](int n, float y) {
-            y += w.in_b[n];
+            y += S.bias[BO_IN + n];
             if (st) st[kStX + n] = y;
             return y;
           },
@@ -235,13 +299,13 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
             S.cat[n] = v;
             S.catc[n] = v;
           });
-    __syncthreads();
+    lds_barrier();
     // ---- MultiRNNCell[GRUCell(256) x3] inside ONE ResidualWrapper (tacotron.py:54-58) ----
     for (int l = 0; l < 3; ++l) {
       float* cl = S.cat + l * 512;
       phase(w.gw[l], 2 * kDec, 2 * kDec, 2 * kDec, cl, S.part, X, XF_G + l * 768,
             [&](int n, float y) {
-              const float g = sigmoid_f(y + w.gb[l][n]);
+              const float g = sigmoid_f(y + S.bias[BO_G + l * 768 + n]);
               if (n < kDec) {
                 const float rh = g * cl[kDec + n];
                 if (st) { st[kStR + l * kDec + n] = g; st[kStRH + l * kDec + n] = rh; }
@@ -254,10 +318,10 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
               if (n < kDec) S.catc[kDec + n] = v;   // r * h
               else S.us[n - kDec] = v;              // u
             });
-      __syncthreads();
+      lds_barrier();
       phase(w.cw[l], kDec, 2 * kDec, kDec, S.catc, S.part, X, XF_C + l * 768,
             [&](int n, float y) {
-              const float c = tanh_f(y + w.cb[l][n]);
+              const float c = tanh_f(y + S.bias[BO_C + l * 768 + n]);
               const float u = S.us[n];
               const float hn = u * cl[kDec + n] + (1.f - u) * c;
               if (st) {
@@ -276,17 +340,17 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
                 S.ys[n] = S.xs[n] + hn;
               }
             });
-      __syncthreads();
+      lds_barrier();
     }
     // ---- OutputProjectionWrapper: cell_output = (x + h3) Wo + bo (tacotron.py:54-60) ----
     phase(w.out_w, R80, kDec, R80, S.ys, S.part, X, XF_O,
           [&](int n, float y) {
-            y += w.out_b[n];
+            y += S.bias[BO_O + n];
             a.out[bt * R80 + n] = y;
             return y;
           },
           [&](int n, float v) { S.octx[n] = v; });
-    __syncthreads();
+    lds_barrier();
     // ---- BahdanauAttention: query layer (no bias) ----
     phase(w.q_w, kAtt, R80, kAtt, S.octx, S.part, X, XF_Q,
           [&](int n, float y) {
@@ -294,9 +358,10 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
             return y;
           },
           [&](int n, float v) { S.qs[n] = v; });
-    __syncthreads();
+    lds_barrier();
     // ---- energies e[s] = sum_u v_u tanh(keys[s,u] + q_u): one wave per memory row, rows dealt round-robin to peers ----
     {
+      tstamp(X, 0);
       const float4 q4 = reinterpret_cast<const float4*>(S.qs)[lane];
       for (int s = X.peer + P * wave; s < len; s += P * (NT / 64)) {
         const float4 k4 = reinterpret_cast<const float4*>(keys + (int64_t)s * kAtt)[lane];
@@ -308,12 +373,15 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
           if (P > 1) xput(X, XF_E + s, e);
         }
       }
+      tstamp(X, 2);
       if (P > 1) {
         for (int s = tid; s < len; s += NT)
           if (s % P != X.peer) S.es[s] = xget(X, XF_E + s);
       }
+      tstamp(X, 3);
+      X.tslot++;
     }
-    __syncthreads();
+    lds_barrier();
     // ---- masked softmax over s < len (score_mask_value = -inf => alignment 0 past text_length) ----
     {
       float m = -INFINITY;
@@ -329,15 +397,16 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
         if (lead) a.align[bt * Tt + s] = al;
       }
     }
-    __syncthreads();
+    lds_barrier();
     // ---- context = alignments . values ----
+    tstamp(X, 1);   // (slot of the ctx phase, stamp 1 is overwritten; the softmax end shows as stamp 0 of ctx)
     phase(values, kAtt, len, kAtt, S.als, S.part, X, XF_CTX,
           [&](int n, float y) {
             if (st) st[kStCtx + n] = y;
             return y;
           },
           [&](int n, float v) { S.octx[R80 + n] = v; });
-    __syncthreads();
+    lds_barrier();
     // ---- attention = [cell_output ; context] Wa (attention_layer_size=256, no bias; tacotron.py:76) ----
     phase(w.att_w, kAtt, R80 + kAtt, kAtt, S.octx, S.part, X, XF_ATT,
           [&](int n, float y) {
@@ -353,7 +422,9 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
       else nf = a.mel[(bt + 1) * R80 + kMel * (r - 1) + tid];
       S.fr[tid] = nf;
     }
-    __syncthreads();
+    if (tid < kPre1) S.km1[tid] = km1n;
+    if (tid < kPre2) S.km2[tid] = km2n;
+    lds_barrier();
   }
 }
 
@@ -426,6 +497,8 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
   X.err = a.err;
   X.dead = S.dead;
   X.epoch = 0;
+  X.trace = nullptr;
+  X.tslot = 0;
   const bool lead = X.peer == 0;
 
   int len = a.text_length[b];
@@ -441,7 +514,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
   if (tid == 0) *S.dead = 0;
   const float4 v4 = reinterpret_cast<const float4*>(a.att_v)[lane];
   float4 dv4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  __syncthreads();
+  lds_barrier();
 
   for (int t = Td - 1; t >= 0; --t) {
     X.epoch = (unsigned)(Td - t);
@@ -461,7 +534,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
     if (lead && tid < kAtt) gs[kGsAtt + tid] = S.datt[tid];
     for (int s = tid; s < Tt; s += NT) S.als[s] = a.align[bt * Tt + s];
     if (tid < kAtt) S.qs[tid] = st[kStQ + tid];
-    __syncthreads();
+    lds_barrier();
     // 2. attention layer: d[o ; ctx] += datt . Wa^T      (wT.att_w is (256, 80r+256))
     phase(w.att_w, R80 + kAtt, kAtt, R80 + kAtt, S.datt, S.part, X, XB_ATT,
           [&](int n, float y) {
@@ -470,7 +543,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
             return y;
           },
           [&](int n, float v) { S.dov[n] = v; });
-    __syncthreads();
+    lds_barrier();
     // 3a. d alignments[s] = values[s] . dctx   (memory rows dealt round-robin to peers)
     {
       const float4 c4 = reinterpret_cast<const float4*>(S.dov + R80)[lane];
@@ -488,16 +561,16 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
           if (s % P != X.peer) S.des[s] = xget(X, XB_DAL + s);
       }
     }
-    __syncthreads();
+    lds_barrier();
     // 3b. softmax backward: de = al * (dal - sum al*dal)   (every wave computes the dot redundantly)
     {
       float dot = 0.f;
       for (int s = lane; s < len; s += 64) dot += S.als[s] * S.des[s];
       dot = wave_sum(dot);
-      __syncthreads();
+      lds_barrier();
       for (int s = tid; s < len; s += NT) S.des[s] = S.als[s] * (S.des[s] - dot);
     }
-    __syncthreads();
+    lds_barrier();
     // 3c. energy backward on this peer's rows: th = tanh(keys+q); dpre = de*v*(1-th^2); dq += dpre; dkeys += dpre; dv += de*th
     {
       const float4 q4 = reinterpret_cast<const float4*>(S.qs)[lane];
@@ -516,7 +589,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
       }
       reinterpret_cast<float4*>(S.red + wave * 256)[lane] = dq4;
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < kAtt) {
       float d = 0.f;
 #pragma unroll
@@ -529,7 +602,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
       S.dq[tid] = d;
       if (lead) gs[kGsQ + tid] = d;
     }
-    __syncthreads();
+    lds_barrier();
     // 4. query layer: do += dq . Wq^T   (wT.q_w is (256, 80r))
     phase(w.q_w, R80, kAtt, R80, S.dq, S.part, X, XB_Q,
           [&](int n, float y) {
@@ -538,14 +611,14 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
             return g;
           },
           [&](int n, float v) { S.dov[n] = v; });
-    __syncthreads();
+    lds_barrier();
     // 5. output projection: dy = do . Wo^T   (wT.out_w is (80r, 256))
     phase(w.out_w, kDec, R80, kDec, S.dov, S.part, X, XB_OUT, [&](int n, float y) { return y; },
           [&](int n, float v) {
             S.dy[n] = v;
             S.dht[n] = S.dh[2 * kDec + n] + v;   // dL/dh3' = carried + residual path
           });
-    __syncthreads();
+    lds_barrier();
     // 6. GRU layers, top down
     for (int l = 2; l >= 0; --l) {
       if (tid < kDec) {
@@ -564,7 +637,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
           gs[kGsG + l * 512 + kDec + n] = dup;
         }
       }
-      __syncthreads();
+      lds_barrier();
       // [d inp ; d(r*h)] = dcp . Wc^T     (wT.cw[l] is (256, 512))
       phase(w.cw[l], 2 * kDec, kDec, 2 * kDec, S.dcp, S.part, X, XB_C + l * 1024,
             [&](int n, float y) {
@@ -588,7 +661,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
                 S.dh[l * kDec + i] = S.dht[i] * st[kStU + l * kDec + i] + y * rr;
               }
             });
-      __syncthreads();
+      lds_barrier();
       // [d inp ; d h] += dgp . Wg^T       (wT.gw[l] is (512, 512))
       phase(w.gw[l], 2 * kDec, 2 * kDec, 2 * kDec, S.dgp, S.part, X, XB_G + l * 1024, [&](int n, float y) { return y; },
             [&](int n, float y) {
@@ -600,7 +673,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
                 S.dh[l * kDec + n - kDec] += y;
               }
             });
-      __syncthreads();
+      lds_barrier();
     }
     if (lead && tid < kDec) gs[kGsX + tid] = S.dx[tid];
     // 7. input projection: d[p2 ; att_{t-1}] = dx . Wi^T   (wT.in_w is (256, 384))
@@ -618,7 +691,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
             if (n < kPre2) S.dp2[n] = v;
             else S.datt[n - kPre2] = v;
           });
-    __syncthreads();
+    lds_barrier();
     // 8. pre-net layer 2: dp1 = dp2pre . W2^T   (wT.pre_w2 is (128, 256))
     phase(w.pre_w2, kPre1, kPre2, kPre1, S.dp2, S.part, X, XB_P2,
           [&](int n, float y) {
@@ -628,17 +701,17 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
             return g;
           },
           [&](int n, float v) { S.dp1[n] = v; });
-    __syncthreads();
+    lds_barrier();
     // 9. pre-net layer 1 input gradient, only when this step's input was the previous cell_output
     if (this_from_out) {
       phase(w.pre_w1, kMel, kPre1, kMel, S.dp1, S.part, X, XB_P1, [&](int n, float y) { return y; },
             [&](int n, float v) { S.dfr[n] = v; });
-      __syncthreads();
+      lds_barrier();
     }
   }
   // attention_v gradient: reduce per-lane partials across waves, then one atomic per element
   reinterpret_cast<float4*>(S.red + wave * 256)[lane] = dv4;
-  __syncthreads();
+  lds_barrier();
   if (tid < kAtt) {
     float d = 0.f;
 #pragma unroll

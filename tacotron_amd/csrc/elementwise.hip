@@ -284,6 +284,33 @@ __global__ void transpose_flip_kernel(const float* __restrict__ in, float* __res
   }
 }
 
+// Batched transposes: block -> job by linear tile index (jobs sorted by tile0).  block = (32, 8)
+__global__ void transpose_batch_kernel(TransposeBatch b) {
+  __shared__ float tile[32][33];
+  const int t = blockIdx.x;
+  int ji = 0;
+  for (int i = 1; i < b.n; ++i)
+    if (t >= b.j[i].tile0) ji = i;
+  const TransposeJob& J = b.j[ji];
+  int rel = t - J.tile0;
+  const int tn = (J.N + 31) / 32, tk = (J.K + 31) / 32;
+  const int tp = rel / (tn * tk);
+  rel -= tp * tn * tk;
+  const int by = rel / tn, bx = rel - by * tn;
+  const float* src = J.in + (int64_t)(J.taps - 1 - tp) * J.K * J.N;
+  float* dst = J.out + (int64_t)tp * J.K * J.N;
+  const int n0 = bx * 32, k0 = by * 32;
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    const int k = k0 + j, n = n0 + threadIdx.x;
+    tile[j][threadIdx.x] = (k < J.K && n < J.N) ? src[(int64_t)k * J.N + n] : 0.f;
+  }
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    const int n = n0 + j, k = k0 + threadIdx.x;
+    if (n < J.N && k < J.K) dst[(int64_t)n * J.K + k] = tile[threadIdx.x][j];
+  }
+}
+
 __global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
   __shared__ float red[8];
   float acc = 0.f;
@@ -431,6 +458,17 @@ int launch_transpose_flip(const float* in, float* out, int taps, int K, int N, h
   dim3 grid((N + 31) / 32, (K + 31) / 32, taps);
   hipLaunchKernelGGL(transpose_flip_kernel, grid, dim3(32, 8), 0, s, in, out, taps, K, N);
   TACO_LAUNCH_CHECK("transpose_flip");
+  return TACO_OK;
+}
+int launch_transpose_batch(TransposeBatch& b, hipStream_t s) {
+  TACO_REQUIRE(b.n >= 1 && b.n <= kMaxTransposeBatch, "transpose_batch: %d jobs out of range", b.n);
+  int tiles = 0;
+  for (int i = 0; i < b.n; ++i) {
+    b.j[i].tile0 = tiles;
+    tiles += b.j[i].taps * ((b.j[i].N + 31) / 32) * ((b.j[i].K + 31) / 32);
+  }
+  hipLaunchKernelGGL(transpose_batch_kernel, dim3(tiles), dim3(32, 8), 0, s, b);
+  TACO_LAUNCH_CHECK("transpose_batch");
   return TACO_OK;
 }
 int launch_sumsq(const float* x, int64_t n, float* out, hipStream_t s) {

@@ -170,7 +170,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmBatch batch) {
         if (P.Cpre) P.Cpre[(int64_t)m * P.ldc + n] = v;
         if (P.scale || P.shift) v = v * sc + sf;
         if (P.residual) v += P.residual[(int64_t)m * P.ldr + n];
-        P.C[(int64_t)m * P.ldc + n] = v;
+        if (P.atomic_out) atomicAdd(&P.C[(int64_t)m * P.ldc + n], v);
+        else P.C[(int64_t)m * P.ldc + n] = v;
       }
     }
   }
@@ -211,6 +212,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs P) {
   if (nit <= 0) return;
 
   float4 ra[A_PER], rb[B_PER];
+  const bool do_bias = P.dbias != nullptr && blockIdx.x == 0 && tap == 0;
+  float4 bsum[B_PER];
+#pragma unroll
+  for (int i = 0; i < B_PER; ++i) bsum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   auto load_tile = [&](int it) {
     const int mm0 = m_begin + it * BK;
 #pragma unroll
@@ -253,6 +258,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs P) {
         }
       }
       rb[i] = v;
+      if (do_bias) { bsum[i].x += v.x; bsum[i].y += v.y; bsum[i].z += v.z; bsum[i].w += v.w; }
     }
   };
   auto store_tile = [&](int buf) {
@@ -313,6 +319,23 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs P) {
         atomicAdd(&W[(int64_t)k * P.ldw + n], acc[i][j][e]);
       }
     }
+  }
+  if (do_bias) {
+    // column sums of this block's Y rows: reduce the per-thread partials through LDS (As is free after the last barrier)
+    float* cs = &As[0][0][0];
+    for (int i = tid; i < BN; i += 256) cs[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      atomicAdd(&cs[b_c4 * 4 + 0], bsum[i].x);
+      atomicAdd(&cs[b_c4 * 4 + 1], bsum[i].y);
+      atomicAdd(&cs[b_c4 * 4 + 2], bsum[i].z);
+      atomicAdd(&cs[b_c4 * 4 + 3], bsum[i].w);
+    }
+    __syncthreads();
+    float* db = P.dbias + (int64_t)bz * P.N;
+    for (int i = tid; i < BN; i += 256)
+      if (n0 + i < P.N) atomicAdd(&db[n0 + i], cs[i]);
   }
 }
 

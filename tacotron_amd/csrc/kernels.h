@@ -17,6 +17,7 @@ struct ConvGemmProblem {
   float* Cpre = nullptr;
   int lda = 0, ldw = 0, ldr = 0, ldc = 0;
   int M = 0, N = 0, K = 0, taps = 1, T = 1, pad_l = 0, act = 0, flags = 0;
+  int atomic_out = 0;  // C += result with fp32 atomics (C pre-zeroed by the caller); several problems may share C
 };
 struct ConvGemmBatch {
   ConvGemmProblem p[kMaxGemmBatch];
@@ -26,6 +27,7 @@ struct GemmTnArgs {
   const float* A = nullptr;
   const float* Y = nullptr;
   float* W = nullptr;
+  float* dbias = nullptr;  // optional: dbias[n] += sum_m Y[m][n] (bias gradient), accumulated by the k-tile-0 / tap-0 blocks
   int lda = 0, ldy = 0, ldw = 0;
   int M = 0, N = 0, K = 0, taps = 1, T = 1, pad_l = 0;
   int batch = 1;
@@ -69,6 +71,18 @@ int launch_finish_loss(float* loss, hipStream_t s);  // loss[0] = loss[1] + loss
 int launch_bn_fold(const float* gamma, float* scale, int n, hipStream_t s);
 // transposes: out[tap'][n][k] = in[taps-1-tap'][k][n]
 int launch_transpose_flip(const float* in, float* out, int taps, int K, int N, hipStream_t s);
+// Batched form: up to kMaxTransposeBatch (in, out, taps, K, N) jobs in ONE launch.
+constexpr int kMaxTransposeBatch = 96;
+struct TransposeJob {
+  const float* in;
+  float* out;
+  int taps, K, N, tile0;   // tile0 = first linear tile index of this job (filled by the launcher)
+};
+struct TransposeBatch {
+  TransposeJob j[kMaxTransposeBatch];
+  int n = 0;
+};
+int launch_transpose_batch(TransposeBatch& b, hipStream_t s);
 int launch_sumsq(const float* x, int64_t n, float* out, hipStream_t s);  // out[0] += sum x^2 (double-free, fp32 tree)
 int launch_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float cap, int64_t step,
                      const float* sumsq, float* gnorm_out, hipStream_t s);
@@ -144,6 +158,7 @@ struct DecFwdArgs {
   float* prein;          // (B,Td,80) pre-net input frames actually used (train stash) or null
   void* xchg;            // decoder_xchg_bytes(B,Tt): granule area for the in-launch all-gathers
   int* err;              // set to 1 by the kernel if a bounded spin timed out
+  long long* trace;      // optional (TACO_DEC_TRACE=1): per-phase wall_clock64 stamps of block 0 at step Td/2
   int B, Tt, Td, r;
   int P;                 // cluster width (workgroups per row); chosen by launch_decoder_fwd
 };

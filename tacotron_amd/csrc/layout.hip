@@ -190,7 +190,7 @@ void build_ws_layout(const TacoShape& s, bool train, const TransLayout& T, WsLay
   W.stash = train ? a.add("dec.stash", {MD, kStRec}) : -1;
   W.prein = train ? a.add("dec.prein", {MD, kMel}) : -1;
   W.xchg = a.add("dec.xchg", {decoder_xchg_bytes(s.B, s.Tt) / 4});
-  W.err = a.add("dec.err", {64});
+  W.err = a.add("dec.err", {512});   // [0],[1] error words; floats 16.. = optional phase trace
   ws_cbhg(a, "post.", P.post, M2, train, W.post);
   W.loss = a.add("loss", {4});
   if (train) {

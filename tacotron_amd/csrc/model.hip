@@ -105,7 +105,7 @@ int cbhg_fwd(const float* P, const CbhgP& c, const float* x, int B, int T, const
     ConvGemmBatch batch;
     batch.n = c.K;
     for (int k = 1; k <= c.K; ++k) {
-      ConvGemmProblem& p = batch.p[k - 1];
+      ConvGemmProblem& p = batch.p[c.K - k];   // widest kernel first: its blocks are the longest-running
       p = ConvGemmProblem();
       p.A = x; p.lda = c.cin; p.W = P + c.bank_w[k - 1]; p.ldw = kCb; p.bias = P + c.bank_b[k - 1];
       p.C = w.bank + (k - 1) * kCb; p.ldc = KC; p.M = M; p.N = kCb; p.K = c.cin; p.taps = k; p.T = T;
@@ -209,6 +209,7 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
   da.stash = train ? ws + W.stash : nullptr;
   da.prein = train ? ws + W.prein : nullptr;
   da.xchg = ws + W.xchg; da.err = reinterpret_cast<int*>(ws + W.err);
+  da.trace = getenv("TACO_DEC_TRACE") ? reinterpret_cast<long long*>(ws + W.err + 16) : nullptr;
   da.B = B; da.Tt = Tt; da.Td = Td; da.r = r; da.P = 1;
   {
     hipError_t e = hipMemsetAsync(ws + W.err, 0, 64 * sizeof(float), s);
@@ -232,8 +233,9 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
 }
 
 int tn(const float* A, int lda, int K, const float* Y, int ldy, int N, float* W, int ldw, int M, int T, int pad_l,
-       hipStream_t s, int taps = 1) {
+       hipStream_t s, int taps = 1, float* dbias = nullptr) {
   GemmTnArgs a;
+  a.dbias = dbias;
   a.A = A; a.lda = lda; a.Y = Y; a.ldy = ldy; a.W = W; a.ldw = ldw; a.M = M; a.N = N; a.K = K; a.taps = taps; a.T = T;
   a.pad_l = pad_l;
   return launch_gemm_tn(a, false, s);
@@ -242,7 +244,13 @@ int tn(const float* A, int lda, int K, const float* Y, int ldy, int N, float* W,
 // Builds every transposed / flipped weight copy the backward pass needs.
 int prepare_transposes(const float* P, const ParamLayout& L, const TransLayout& T, float* PT, int r, hipStream_t s) {
   const int R80 = kMel * r;
-  auto tr = [&](int64_t src, int64_t dst, int taps, int K, int N) { return launch_transpose_flip(P + src, PT + dst, taps, K, N, s); };
+  TransposeBatch tb;
+  auto tr = [&](int64_t src, int64_t dst, int taps, int K, int N) {
+    TACO_REQUIRE(tb.n < kMaxTransposeBatch, "prepare_transposes: too many jobs");
+    TransposeJob& j = tb.j[tb.n++];
+    j.in = P + src; j.out = PT + dst; j.taps = taps; j.K = K; j.N = N; j.tile0 = 0;
+    return TACO_OK;
+  };
   TACO_TRY(tr(L.enc_pre1.w, T.enc_pre1, 1, kEmbed, kPre1));
   TACO_TRY(tr(L.enc_pre2.w, T.enc_pre2, 1, kPre1, kPre2));
   const CbhgP* cp[2] = {&L.enc, &L.post};
@@ -280,7 +288,7 @@ int prepare_transposes(const float* P, const ParamLayout& L, const TransLayout& 
   TACO_TRY(tr(L.q_w, T.q_w, 1, R80, kAtt));
   TACO_TRY(tr(L.att_w, T.att_w, 1, R80 + kAtt, kAtt));
   TACO_TRY(tr(L.post_dense.w, T.post_dense, 1, 2 * kCb, kFft));
-  return TACO_OK;
+  return launch_transpose_batch(tb, s);
 }
 
 struct BwdScratch {
@@ -305,13 +313,11 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
   for (int d = 0; d < 2; ++d) {
     const float* dG = dxg + d * 3 * kCb;
     const float* dC = dG + 2 * kCb;
-    TACO_TRY(tn(w.h[4], kCb, kCb, dG, 6 * kCb, 2 * kCb, G + g[d]->wg, 2 * kCb, M, T, 0, s));
+    TACO_TRY(tn(w.h[4], kCb, kCb, dG, 6 * kCb, 2 * kCb, G + g[d]->wg, 2 * kCb, M, T, 0, s, 1, G + g[d]->bg));
     TACO_TRY(tn(w.out + d * kCb, 2 * kCb, kCb, dG, 6 * kCb, 2 * kCb, G + g[d]->wg + (int64_t)kCb * 2 * kCb, 2 * kCb, M, T,
                 d == 0 ? 1 : -1, s));
-    TACO_TRY(tn(w.h[4], kCb, kCb, dC, 6 * kCb, kCb, G + g[d]->wc, kCb, M, T, 0, s));
+    TACO_TRY(tn(w.h[4], kCb, kCb, dC, 6 * kCb, kCb, G + g[d]->wc, kCb, M, T, 0, s, 1, G + g[d]->bc));
     TACO_TRY(tn(rh + d * kCb, 2 * kCb, kCb, dC, 6 * kCb, kCb, G + g[d]->wc + (int64_t)kCb * kCb, kCb, M, T, 0, s));
-    TACO_TRY(launch_colsum(dG, 6 * kCb, G + g[d]->bg, M, 2 * kCb, s));
-    TACO_TRY(launch_colsum(dC, 6 * kCb, G + g[d]->bc, M, kCb, s));
   }
   float* gh = sc.gE;     // (M,128) gradient wrt current highway output
   float* gh2 = sc.gF;    // ping-pong
@@ -321,10 +327,8 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
   float* dxd = sc.gG;    // (M,128)
   for (int l = 3; l >= 0; --l) {
     TACO_TRY(launch_highway_combine_bwd(w.th[l], w.h[l], gh, dth, dxd, M, s));
-    TACO_TRY(tn(w.h[l], kCb, kCb, dth, 2 * kCb, kCb, G + c.hwT[l].w, kCb, M, M, 0, s));
-    TACO_TRY(tn(w.h[l], kCb, kCb, dth + kCb, 2 * kCb, kCb, G + c.hwH[l].w, kCb, M, M, 0, s));
-    TACO_TRY(launch_colsum(dth, 2 * kCb, G + c.hwT[l].b, M, kCb, s));
-    TACO_TRY(launch_colsum(dth + kCb, 2 * kCb, G + c.hwH[l].b, M, kCb, s));
+    TACO_TRY(tn(w.h[l], kCb, kCb, dth, 2 * kCb, kCb, G + c.hwT[l].w, kCb, M, M, 0, s, 1, G + c.hwT[l].b));
+    TACO_TRY(tn(w.h[l], kCb, kCb, dth + kCb, 2 * kCb, kCb, G + c.hwH[l].w, kCb, M, M, 0, s, 1, G + c.hwH[l].b));
     ConvGemmProblem p = dense_problem(dth, 2 * kCb, PT + t.hw[l], kCb, nullptr, gh2, kCb, M, kCb, 2 * kCb, TACO_ACT_NONE);
     p.residual = dxd;
     p.ldr = kCb;
@@ -334,16 +338,14 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
   // ---- adapt dense (post-net only) ----
   float* dres = gh;      // (M, c2) gradient wrt `res`
   if (c.has_adapt) {
-    TACO_TRY(tn(w.res, c.c2, c.c2, gh, kCb, kCb, G + c.adapt.w, kCb, M, M, 0, s));
-    TACO_TRY(launch_colsum(gh, kCb, G + c.adapt.b, M, kCb, s));
+    TACO_TRY(tn(w.res, c.c2, c.c2, gh, kCb, kCb, G + c.adapt.w, kCb, M, M, 0, s, 1, G + c.adapt.b));
     TACO_TRY(launch_conv_gemm(dense_problem(gh, kCb, PT + t.adapt, c.c2, nullptr, gh2, c.c2, M, c.c2, kCb, TACO_ACT_NONE), s));
     dres = gh2;
   }
   // ---- res = bn(conv(pj1)) + x ----
   float* dz2 = sc.gG;    // (M,c2)
   TACO_TRY(launch_affine_act_bwd(w.pj2pre, P + c.p2_g, dres, dz2, G + c.p2_g, G + c.p2_be, M, c.c2, TACO_ACT_NONE, s));
-  TACO_TRY(tn(w.pj1, c.c1, c.c1, dz2, c.c2, c.c2, G + c.p2_w, c.c2, M, T, 1, s, 3));
-  TACO_TRY(launch_colsum(dz2, c.c2, G + c.p2_b, M, c.c2, s));
+  TACO_TRY(tn(w.pj1, c.c1, c.c1, dz2, c.c2, c.c2, G + c.p2_w, c.c2, M, T, 1, s, 3, G + c.p2_b));
   float* dpj1 = sc.gD;   // (M,c1)
   {
     ConvGemmProblem p;
@@ -353,8 +355,7 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
   }
   float* dz1 = sc.gC;    // (M,c1)  (dxg no longer needed)
   TACO_TRY(launch_affine_act_bwd(w.pj1pre, P + c.p1_g, dpj1, dz1, G + c.p1_g, G + c.p1_be, M, c.c1, TACO_ACT_RELU, s));
-  TACO_TRY(tn(w.pool, KC, KC, dz1, c.c1, c.c1, G + c.p1_w, c.c1, M, T, 1, s, 3));
-  TACO_TRY(launch_colsum(dz1, c.c1, G + c.p1_b, M, c.c1, s));
+  TACO_TRY(tn(w.pool, KC, KC, dz1, c.c1, c.c1, G + c.p1_w, c.c1, M, T, 1, s, 3, G + c.p1_b));
   float* dpool = sc.gA;  // (M,KC)
   {
     ConvGemmProblem p;
@@ -365,26 +366,29 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
   float* dbank = sc.gB;  // (M,KC)
   TACO_TRY(launch_bn_maxpool_bwd(w.bank, P + c.bank_g, P + c.bank_be, dpool, dbank, G + c.bank_g, G + c.bank_be, B, T, KC, s));
   TACO_TRY(launch_act_bwd(w.bank, dbank, nullptr, dbank, (int64_t)M * KC, TACO_ACT_RELU, s));
-  // ---- conv bank: weight/bias grads per width, input grad chained through `residual` ----
-  const float* acc = dres;  // residual connection: d res / d x = identity (c2 == cin)
-  int ldacc = c.c2;
-  float* pp[2] = {sc.gE, sc.gF};
-  // dres may live in gE or gF; ping-pong between the other one and gD
-  float* o0 = (dres == sc.gE) ? sc.gF : sc.gE;
-  float* o1 = sc.gD;
-  (void)pp;
-  for (int k = 1; k <= c.K; ++k) {
-    const float* dzk = dbank + (k - 1) * kCb;
-    TACO_TRY(tn(x, c.cin, c.cin, dzk, KC, kCb, G + c.bank_w[k - 1], kCb, M, T, (k - 1) / 2, s, k));
-    TACO_TRY(launch_colsum(dzk, KC, G + c.bank_b[k - 1], M, kCb, s));
-    ConvGemmProblem p;
-    float* outk = (k == c.K) ? dx_out : ((k & 1) ? o0 : o1);
-    p.A = dzk; p.lda = KC; p.W = PT + t.bank[k - 1]; p.ldw = c.cin; p.C = outk; p.ldc = c.cin; p.M = M; p.N = c.cin; p.K = kCb;
-    p.taps = k; p.T = T; p.pad_l = (k - 1) - (k - 1) / 2; p.act = TACO_ACT_NONE;
-    p.residual = acc; p.ldr = ldacc;
-    TACO_TRY(launch_conv_gemm(p, s));
-    acc = outk;
-    ldacc = c.cin;
+  // ---- conv bank: weight/bias grads per width; input grad = residual path + sum over widths, accumulated with fp32
+  //      atomics by ONE batched launch (all K transposed convolutions run concurrently instead of as a dependent chain) ----
+  {
+    hipError_t e = hipMemsetAsync(dx_out, 0, (size_t)M * c.cin * sizeof(float), s);
+    if (e != hipSuccess) {
+      taco_set_error("cbhg_bwd: memset: %s", hipGetErrorString(e));
+      return TACO_ELAUNCH;
+    }
+    ConvGemmBatch batch;
+    batch.n = c.K;
+    for (int k = 1; k <= c.K; ++k) {
+      const float* dzk = dbank + (k - 1) * kCb;
+      TACO_TRY(tn(x, c.cin, c.cin, dzk, KC, kCb, G + c.bank_w[k - 1], kCb, M, T, (k - 1) / 2, s, k, G + c.bank_b[k - 1]));
+      ConvGemmProblem& p = batch.p[c.K - k];
+      p = ConvGemmProblem();
+      p.A = dzk; p.lda = KC; p.W = PT + t.bank[k - 1]; p.ldw = c.cin; p.C = dx_out; p.ldc = c.cin; p.M = M; p.N = c.cin;
+      p.K = kCb; p.taps = k; p.T = T; p.pad_l = (k - 1) - (k - 1) / 2; p.act = TACO_ACT_NONE; p.atomic_out = 1;
+      if (k == 1) {   // the residual connection (d res / d x = identity, c2 == cin) rides on the cheapest problem
+        p.residual = dres;
+        p.ldr = c.c2;
+      }
+    }
+    TACO_TRY(launch_conv_gemm_batch(batch, s));
   }
   return TACO_OK;
 }
@@ -499,8 +503,7 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
 
   // ---- final dense (tacotron.py:148): output = post_out . Wd + bd ----
   const float* dOutPad = ws + W.dout_pad;  // (M2, 1028) = sign(output - stft), written by taco_forward
-  TACO_TRY(tn(pb.out, 2 * kCb, 2 * kCb, dOutPad, 1028, kFft, G + PL.post_dense.w, kFft, M2, M2, 0, s));
-  TACO_TRY(launch_colsum(dOutPad, 1028, G + PL.post_dense.b, M2, kFft, s));
+  TACO_TRY(tn(pb.out, 2 * kCb, 2 * kCb, dOutPad, 1028, kFft, G + PL.post_dense.w, kFft, M2, M2, 0, s, 1, G + PL.post_dense.b));
   float* dPostOut = sc.gG;  // (M2,256); consumed by the bi-GRU backward before gG is reused
   TACO_TRY(launch_conv_gemm(dense_problem(dOutPad, 1028, PT + TL.post_dense, 2 * kCb, nullptr, dPostOut, 2 * kCb, M2, 2 * kCb,
                                           kFft, TACO_ACT_NONE), s));
@@ -537,28 +540,22 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
   // ---- decoder weight gradients: dense GEMMs over the B*Td stashed rows ----
   {
     const float* prein = ws + W.prein;
-    TACO_TRY(tn(prein, kMel, kMel, gs + kGsP1, kGsRec, kPre1, G + PL.dec_pre1.w, kPre1, MD, Td, 0, s));
-    TACO_TRY(launch_colsum(gs + kGsP1, kGsRec, G + PL.dec_pre1.b, MD, kPre1, s));
-    TACO_TRY(tn(st + kStP1, kStRec, kPre1, gs + kGsP2, kGsRec, kPre2, G + PL.dec_pre2.w, kPre2, MD, Td, 0, s));
-    TACO_TRY(launch_colsum(gs + kGsP2, kGsRec, G + PL.dec_pre2.b, MD, kPre2, s));
+    TACO_TRY(tn(prein, kMel, kMel, gs + kGsP1, kGsRec, kPre1, G + PL.dec_pre1.w, kPre1, MD, Td, 0, s, 1, G + PL.dec_pre1.b));
+    TACO_TRY(tn(st + kStP1, kStRec, kPre1, gs + kGsP2, kGsRec, kPre2, G + PL.dec_pre2.w, kPre2, MD, Td, 0, s, 1, G + PL.dec_pre2.b));
     // in-proj: rows [0,128) pre-net output of step t, rows [128,384) attention of step t-1
-    TACO_TRY(tn(st + kStP2, kStRec, kPre2, gs + kGsX, kGsRec, kDec, G + PL.in_proj.w, kDec, MD, Td, 0, s));
+    TACO_TRY(tn(st + kStP2, kStRec, kPre2, gs + kGsX, kGsRec, kDec, G + PL.in_proj.w, kDec, MD, Td, 0, s, 1, G + PL.in_proj.b));
     TACO_TRY(tn(st + kStAtt, kStRec, kAtt, gs + kGsX, kGsRec, kDec, G + PL.in_proj.w + (int64_t)kPre2 * kDec, kDec, MD, Td, 1, s));
-    TACO_TRY(launch_colsum(gs + kGsX, kGsRec, G + PL.in_proj.b, MD, kDec, s));
     for (int l = 0; l < 3; ++l) {
       const float* inp = l == 0 ? st + kStX : st + kStH + (l - 1) * kDec;
       const float* dG = gs + kGsG + l * 512;
       const float* dC = gs + kGsC + l * kDec;
-      TACO_TRY(tn(inp, kStRec, kDec, dG, kGsRec, 2 * kDec, G + PL.gru[l].wg, 2 * kDec, MD, Td, 0, s));
+      TACO_TRY(tn(inp, kStRec, kDec, dG, kGsRec, 2 * kDec, G + PL.gru[l].wg, 2 * kDec, MD, Td, 0, s, 1, G + PL.gru[l].bg));
       TACO_TRY(tn(st + kStH + l * kDec, kStRec, kDec, dG, kGsRec, 2 * kDec, G + PL.gru[l].wg + (int64_t)kDec * 2 * kDec, 2 * kDec,
                   MD, Td, 1, s));
-      TACO_TRY(tn(inp, kStRec, kDec, dC, kGsRec, kDec, G + PL.gru[l].wc, kDec, MD, Td, 0, s));
+      TACO_TRY(tn(inp, kStRec, kDec, dC, kGsRec, kDec, G + PL.gru[l].wc, kDec, MD, Td, 0, s, 1, G + PL.gru[l].bc));
       TACO_TRY(tn(st + kStRH + l * kDec, kStRec, kDec, dC, kGsRec, kDec, G + PL.gru[l].wc + (int64_t)kDec * kDec, kDec, MD, Td, 0, s));
-      TACO_TRY(launch_colsum(dG, kGsRec, G + PL.gru[l].bg, MD, 2 * kDec, s));
-      TACO_TRY(launch_colsum(dC, kGsRec, G + PL.gru[l].bc, MD, kDec, s));
     }
-    TACO_TRY(tn(st + kStY, kStRec, kDec, gs + kGsO, kGsRec, R80, G + PL.out_proj.w, R80, MD, Td, 0, s));
-    TACO_TRY(launch_colsum(gs + kGsO, kGsRec, G + PL.out_proj.b, MD, R80, s));
+    TACO_TRY(tn(st + kStY, kStRec, kDec, gs + kGsO, kGsRec, R80, G + PL.out_proj.w, R80, MD, Td, 0, s, 1, G + PL.out_proj.b));
     TACO_TRY(tn(seq2seq_output, R80, R80, gs + kGsQ, kGsRec, kAtt, G + PL.q_w, kAtt, MD, Td, 0, s));
     TACO_TRY(tn(seq2seq_output, R80, R80, gs + kGsAtt, kGsRec, kAtt, G + PL.att_w, kAtt, MD, Td, 0, s));
     TACO_TRY(tn(st + kStCtx, kStRec, kAtt, gs + kGsAtt, kGsRec, kAtt, G + PL.att_w + (int64_t)R80 * kAtt, kAtt, MD, Td, 0, s));
@@ -588,14 +585,12 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
   // ---- encoder pre_net + embedding ----
   float* dz2 = sc.gD;
   TACO_TRY(launch_act_bwd(ws + W.p2, dP2, enc_keep2, dz2, (int64_t)M1 * kPre2, TACO_ACT_RELU, s));
-  TACO_TRY(tn(ws + W.p1, kPre1, kPre1, dz2, kPre2, kPre2, G + PL.enc_pre2.w, kPre2, M1, M1, 0, s));
-  TACO_TRY(launch_colsum(dz2, kPre2, G + PL.enc_pre2.b, M1, kPre2, s));
+  TACO_TRY(tn(ws + W.p1, kPre1, kPre1, dz2, kPre2, kPre2, G + PL.enc_pre2.w, kPre2, M1, M1, 0, s, 1, G + PL.enc_pre2.b));
   float* dz1 = sc.gE;
   TACO_TRY(launch_conv_gemm(dense_problem(dz2, kPre2, PT + TL.enc_pre2, kPre1, nullptr, dz1, kPre1, M1, kPre1, kPre2,
                                           TACO_ACT_NONE), s));
   TACO_TRY(launch_act_bwd(ws + W.p1, dz1, enc_keep1, dz1, (int64_t)M1 * kPre1, TACO_ACT_RELU, s));
-  TACO_TRY(tn(ws + W.emb, kEmbed, kEmbed, dz1, kPre1, kPre1, G + PL.enc_pre1.w, kPre1, M1, M1, 0, s));
-  TACO_TRY(launch_colsum(dz1, kPre1, G + PL.enc_pre1.b, M1, kPre1, s));
+  TACO_TRY(tn(ws + W.emb, kEmbed, kEmbed, dz1, kPre1, kPre1, G + PL.enc_pre1.w, kPre1, M1, M1, 0, s, 1, G + PL.enc_pre1.b));
   float* dEmb = sc.gF;
   TACO_TRY(launch_conv_gemm(dense_problem(dz1, kPre1, PT + TL.enc_pre1, kEmbed, nullptr, dEmb, kEmbed, M1, kEmbed, kPre1,
                                           TACO_ACT_NONE), s));
