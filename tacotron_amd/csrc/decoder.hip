@@ -23,6 +23,7 @@ namespace {
 constexpr int NT = 512;
 constexpr int kPartFloats = NT * 4;
 constexpr int kMaxKG = 64;
+constexpr int kAR = 4;   // attention memory rows kept register-resident per wave
 
 typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) u64 gu64;
@@ -70,7 +71,7 @@ __device__ __forceinline__ float xget(const Xchg& X, int idx) {
 // the caller must __syncthreads() afterwards before `part`/x/the put() targets are reused.
 template <class Epi, class Put>
 __device__ __forceinline__ void phase(const float* __restrict__ W, int ldw, int K, int N, const float* x, float* part,
-                                      const Xchg& X, int reg, Epi epi, Put put) {
+                                      Xchg& X, int reg, Epi epi, Put put) {
   const int tid = threadIdx.x;
   tstamp(X, 0);
   const int N4 = N >> 2;
@@ -151,7 +152,7 @@ __device__ __forceinline__ void phase(const float* __restrict__ W, int ldw, int 
     }
   }
   tstamp(X, 3);
-  const_cast<Xchg&>(X).tslot++;
+  X.tslot++;
 }
 
 // ---- forward exchange regions (granule indices within a row's area) ----
@@ -254,6 +255,15 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
   if (tid < kPre1) S.km1[tid] = a.keep1 ? (a.keep1[((int64_t)b * Td) * kPre1 + tid] ? 2.f : 0.f) : 1.f;
   if (tid < kPre2) S.km2[tid] = a.keep2 ? (a.keep2[((int64_t)b * Td) * kPre2 + tid] ? 2.f : 0.f) : 1.f;
   const float4 v4 = reinterpret_cast<const float4*>(w.att_v)[lane];
+  // This wave always scores the same memory rows s = peer + P*wave + i*P*8: keep the first kAR of them in registers
+  // for the whole launch (Tt <= kAR*8*P rows are fully resident); further rows are streamed.
+  const int s_first = X.peer + P * wave, s_stride = P * (NT / 64);
+  float4 kres[kAR];
+#pragma unroll
+  for (int i = 0; i < kAR; ++i) {
+    const int s = s_first + i * s_stride;
+    kres[i] = s < len ? reinterpret_cast<const float4*>(keys + (int64_t)s * kAtt)[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   lds_barrier();
 
   for (int t = 0; t < Td; ++t) {
@@ -363,8 +373,7 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
     {
       tstamp(X, 0);
       const float4 q4 = reinterpret_cast<const float4*>(S.qs)[lane];
-      for (int s = X.peer + P * wave; s < len; s += P * (NT / 64)) {
-        const float4 k4 = reinterpret_cast<const float4*>(keys + (int64_t)s * kAtt)[lane];
+      auto score = [&](int s, float4 k4) {
         float e = v4.x * tanh_f(k4.x + q4.x) + v4.y * tanh_f(k4.y + q4.y) + v4.z * tanh_f(k4.z + q4.z) +
                   v4.w * tanh_f(k4.w + q4.w);
         e = wave_sum(e);
@@ -372,7 +381,14 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
           S.es[s] = e;
           if (P > 1) xput(X, XF_E + s, e);
         }
+      };
+#pragma unroll
+      for (int i = 0; i < kAR; ++i) {
+        const int s = s_first + i * s_stride;
+        if (s < len) score(s, kres[i]);
       }
+      for (int s = s_first + kAR * s_stride; s < len; s += s_stride)
+        score(s, reinterpret_cast<const float4*>(keys + (int64_t)s * kAtt)[lane]);
       tstamp(X, 2);
       if (P > 1) {
         for (int s = tid; s < len; s += NT)
@@ -446,14 +462,17 @@ struct DecBwdSmem {
   float* dx;      // 256
   float* dp2;     // 128
   float* dp1;     // 256
-  float* qs;      // 256
   float* red;     // 8*256 cross-wave dq reduction
+  float* rec;     // kRecFloats: this step's forward stash pieces (prefetched one step ahead)
   float* als;     // TtP
   float* des;     // TtP
   int* dead;
 };
-constexpr int kBwdSmemFixed =
-    kPartFloats + 768 + 256 + 80 + 656 + 256 + 256 + 256 + 256 + 512 + 256 + 256 + 128 + 256 + 256 + 8 * 256 + 4;
+// LDS copy of the forward stash record of step t (+ h of step t-1):
+constexpr int RL_P1 = 0, RL_P2 = 256, RL_R = 384, RL_U = 1152, RL_C = 1920, RL_Q = 2688, RL_HP = 2944, kRecFloats = 3712;
+constexpr int kRecRegs = (kRecFloats + NT - 1) / NT;   // 8 registers per thread hold the next record in flight
+constexpr int kBwdSmemFixed = kPartFloats + 768 + 256 + 80 + 656 + 256 + 256 + 256 + 256 + 512 + 256 + 256 + 128 + 256 +
+                              8 * 256 + kRecFloats + 4;
 
 __device__ __forceinline__ DecBwdSmem carve_bwd(float* base, int TtP) {
   DecBwdSmem s;
@@ -472,12 +491,22 @@ __device__ __forceinline__ DecBwdSmem carve_bwd(float* base, int TtP) {
   s.dx = p; p += 256;
   s.dp2 = p; p += 128;
   s.dp1 = p; p += 256;
-  s.qs = p; p += 256;
   s.red = p; p += 8 * 256;
+  s.rec = p; p += kRecFloats;
   s.als = p; p += TtP;
   s.des = p; p += TtP;
   s.dead = reinterpret_cast<int*>(p); p += 4;
   return s;
+}
+
+// Source address of element j of the LDS record for step (b,t): four contiguous runs of the forward stash.
+__device__ __forceinline__ float rec_load(const float* stash, int64_t bt, int t, int j) {
+  if (j >= kRecFloats) return 0.f;
+  const float* st = stash + bt * kStRec;
+  if (j < 384) return st[j];                                   // P1 | P2
+  if (j < 2688) return st[kStR + (j - 384)];                   // R | U | C  (contiguous in the stash)
+  if (j < 2944) return st[kStQ + (j - 2688)];                  // Q
+  return t > 0 ? (st - kStRec)[kStH + (j - 2944)] : 0.f;       // H of the previous step
 }
 
 __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
@@ -514,26 +543,57 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
   if (tid == 0) *S.dead = 0;
   const float4 v4 = reinterpret_cast<const float4*>(a.att_v)[lane];
   float4 dv4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // Register-resident memory rows of this wave (see the forward kernel): keys, values and the dkeys accumulators.
+  const int s_first = X.peer + P * wave, s_stride = P * (NT / 64);
+  float4 kres[kAR], vres[kAR], dkacc[kAR];
+#pragma unroll
+  for (int i = 0; i < kAR; ++i) {
+    const int s = s_first + i * s_stride;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    kres[i] = s < len ? reinterpret_cast<const float4*>(keys + (int64_t)s * kAtt)[lane] : z;
+    vres[i] = s < len ? reinterpret_cast<const float4*>(values + (int64_t)s * kAtt)[lane] : z;
+    dkacc[i] = z;
+  }
+  // Prefetch registers: the record / output gradient / alignment row of the step about to be processed.
+  float pre[kRecRegs];
+  float pre_dout = 0.f, pre_al = 0.f;
+  {
+    const int t = Td - 1;
+    const int64_t bt = (int64_t)b * Td + t;
+#pragma unroll
+    for (int i = 0; i < kRecRegs; ++i) pre[i] = rec_load(a.stash, bt, t, tid + i * NT);
+    if (tid < R80) pre_dout = a.dout[bt * R80 + tid];
+    if (tid < Tt) pre_al = a.align[bt * Tt + tid];
+  }
   lds_barrier();
 
   for (int t = Td - 1; t >= 0; --t) {
     X.epoch = (unsigned)(Td - t);
     const int64_t bt = (int64_t)b * Td + t;
-    const float* st = a.stash + bt * kStRec;
-    const float* stp = t > 0 ? a.stash + (bt - 1) * kStRec : nullptr;
     float* gs = a.gstash + bt * kGsRec;
     const bool next_from_out = (t + 1 < Td) && a.sample && a.sample[(int64_t)t * B + b];
     const bool this_from_out = (t > 0) && a.sample && a.sample[(int64_t)(t - 1) * B + b];
+    const float km1 = a.keep1 ? 2.f : 1.f, km2 = a.keep2 ? 2.f : 1.f;
 
+    // 0. land the prefetched record in LDS, start fetching the one for step t-1
+#pragma unroll
+    for (int i = 0; i < kRecRegs; ++i)
+      if (tid + i * NT < kRecFloats) S.rec[tid + i * NT] = pre[i];
     // 1. d cell_output: direct (loss + post-net) + sampled next-input path (replicated on every peer)
-    for (int n = tid; n < R80; n += NT) {
-      float g = a.dout[bt * R80 + n];
-      if (next_from_out && n >= kMel * (r - 1)) g += S.dfr[n - kMel * (r - 1)];
-      S.dov[n] = g;
+    if (tid < R80) {
+      float g = pre_dout;
+      if (next_from_out && tid >= kMel * (r - 1)) g += S.dfr[tid - kMel * (r - 1)];
+      S.dov[tid] = g;
     }
+    if (tid < Tt) S.als[tid] = pre_al;
+    for (int s = tid + NT; s < Tt; s += NT) S.als[s] = a.align[bt * Tt + s];
     if (lead && tid < kAtt) gs[kGsAtt + tid] = S.datt[tid];
-    for (int s = tid; s < Tt; s += NT) S.als[s] = a.align[bt * Tt + s];
-    if (tid < kAtt) S.qs[tid] = st[kStQ + tid];
+    if (t > 0) {
+#pragma unroll
+      for (int i = 0; i < kRecRegs; ++i) pre[i] = rec_load(a.stash, bt - 1, t - 1, tid + i * NT);
+      if (tid < R80) pre_dout = a.dout[(bt - 1) * R80 + tid];
+      if (tid < Tt) pre_al = a.align[(bt - 1) * Tt + tid];
+    }
     lds_barrier();
     // 2. attention layer: d[o ; ctx] += datt . Wa^T      (wT.att_w is (256, 80r+256))
     phase(w.att_w, R80 + kAtt, kAtt, R80 + kAtt, S.datt, S.part, X, XB_ATT,
@@ -547,15 +607,21 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
     // 3a. d alignments[s] = values[s] . dctx   (memory rows dealt round-robin to peers)
     {
       const float4 c4 = reinterpret_cast<const float4*>(S.dov + R80)[lane];
-      for (int s = X.peer + P * wave; s < len; s += P * (NT / 64)) {
-        const float4 x4 = reinterpret_cast<const float4*>(values + (int64_t)s * kAtt)[lane];
+      auto dal = [&](int s, float4 x4) {
         float d = x4.x * c4.x + x4.y * c4.y + x4.z * c4.z + x4.w * c4.w;
         d = wave_sum(d);
         if (lane == 0) {
           S.des[s] = d;
           if (P > 1) xput(X, XB_DAL + s, d);
         }
+      };
+#pragma unroll
+      for (int i = 0; i < kAR; ++i) {
+        const int s = s_first + i * s_stride;
+        if (s < len) dal(s, vres[i]);
       }
+      for (int s = s_first + kAR * s_stride; s < len; s += s_stride)
+        dal(s, reinterpret_cast<const float4*>(values + (int64_t)s * kAtt)[lane]);
       if (P > 1) {
         for (int s = tid; s < len; s += NT)
           if (s % P != X.peer) S.des[s] = xget(X, XB_DAL + s);
@@ -573,19 +639,27 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
     lds_barrier();
     // 3c. energy backward on this peer's rows: th = tanh(keys+q); dpre = de*v*(1-th^2); dq += dpre; dkeys += dpre; dv += de*th
     {
-      const float4 q4 = reinterpret_cast<const float4*>(S.qs)[lane];
+      const float4 q4 = reinterpret_cast<const float4*>(S.rec + RL_Q)[lane];
       float4 dq4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int s = X.peer + P * wave; s < len; s += P * (NT / 64)) {
+      auto ebwd = [&](int s, float4 k4, float4 dk) {
         const float de = S.des[s];
-        const float4 k4 = reinterpret_cast<const float4*>(keys + (int64_t)s * kAtt)[lane];
-        float4 dk = reinterpret_cast<float4*>(dkeys + (int64_t)s * kAtt)[lane];
         const float t0 = tanh_f(k4.x + q4.x), t1 = tanh_f(k4.y + q4.y), t2 = tanh_f(k4.z + q4.z), t3 = tanh_f(k4.w + q4.w);
         const float p0 = de * v4.x * (1.f - t0 * t0), p1 = de * v4.y * (1.f - t1 * t1);
         const float p2 = de * v4.z * (1.f - t2 * t2), p3 = de * v4.w * (1.f - t3 * t3);
         dq4.x += p0; dq4.y += p1; dq4.z += p2; dq4.w += p3;
         dk.x += p0; dk.y += p1; dk.z += p2; dk.w += p3;
-        reinterpret_cast<float4*>(dkeys + (int64_t)s * kAtt)[lane] = dk;
         dv4.x += de * t0; dv4.y += de * t1; dv4.z += de * t2; dv4.w += de * t3;
+        return dk;
+      };
+#pragma unroll
+      for (int i = 0; i < kAR; ++i) {
+        const int s = s_first + i * s_stride;
+        if (s < len) dkacc[i] = ebwd(s, kres[i], dkacc[i]);
+      }
+      for (int s = s_first + kAR * s_stride; s < len; s += s_stride) {   // rows beyond the resident set: RMW in memory
+        float4 dk = reinterpret_cast<float4*>(dkeys + (int64_t)s * kAtt)[lane];
+        dk = ebwd(s, reinterpret_cast<const float4*>(keys + (int64_t)s * kAtt)[lane], dk);
+        reinterpret_cast<float4*>(dkeys + (int64_t)s * kAtt)[lane] = dk;
       }
       reinterpret_cast<float4*>(S.red + wave * 256)[lane] = dq4;
     }
@@ -621,10 +695,13 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
     lds_barrier();
     // 6. GRU layers, top down
     for (int l = 2; l >= 0; --l) {
+      const float* Rl = S.rec + RL_R + l * kDec;
+      const float* Ul = S.rec + RL_U + l * kDec;
+      const float* Cl = S.rec + RL_C + l * kDec;
+      const float* HPl = S.rec + RL_HP + l * kDec;
       if (tid < kDec) {
         const int n = tid;
-        const float u = st[kStU + l * kDec + n], c = st[kStC + l * kDec + n];
-        const float hp = stp ? stp[kStH + l * kDec + n] : 0.f;
+        const float u = Ul[n], c = Cl[n], hp = HPl[n];
         const float dht = S.dht[n];
         const float du = dht * (hp - c);
         const float dc = dht * (1.f - u);
@@ -643,9 +720,8 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
             [&](int n, float y) {
               if (n >= kDec) {
                 const int i = n - kDec;
-                const float rr = st[kStR + l * kDec + i];
-                const float hp = stp ? stp[kStH + l * kDec + i] : 0.f;
-                gs[kGsG + l * 512 + i] = y * hp * rr * (1.f - rr);
+                const float rr = Rl[i];
+                gs[kGsG + l * 512 + i] = y * HPl[i] * rr * (1.f - rr);
               }
               return y;
             },
@@ -654,11 +730,9 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
                 S.dinp[n] = y;
               } else {
                 const int i = n - kDec;
-                const float rr = st[kStR + l * kDec + i];
-                const float hp = stp ? stp[kStH + l * kDec + i] : 0.f;
-                S.dgp[i] = y * hp * rr * (1.f - rr);
-                // partial new carry: dht*u + d(rh)*r
-                S.dh[l * kDec + i] = S.dht[i] * st[kStU + l * kDec + i] + y * rr;
+                const float rr = Rl[i];
+                S.dgp[i] = y * HPl[i] * rr * (1.f - rr);
+                S.dh[l * kDec + i] = S.dht[i] * Ul[i] + y * rr;   // partial new carry: dht*u + d(rh)*r
               }
             });
       lds_barrier();
@@ -680,8 +754,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
     phase(w.in_w, kPre2 + kAtt, kDec, kPre2 + kAtt, S.dx, S.part, X, XB_IN,
           [&](int n, float y) {
             if (n < kPre2) {
-              const float p2 = st[kStP2 + n];
-              const float g = p2 > 0.f ? (a.keep2 ? 2.f * y : y) : 0.f;
+              const float g = S.rec[RL_P2 + n] > 0.f ? km2 * y : 0.f;
               gs[kGsP2 + n] = g;
               return g;
             }
@@ -695,8 +768,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
     // 8. pre-net layer 2: dp1 = dp2pre . W2^T   (wT.pre_w2 is (128, 256))
     phase(w.pre_w2, kPre1, kPre2, kPre1, S.dp2, S.part, X, XB_P2,
           [&](int n, float y) {
-            const float p1 = st[kStP1 + n];
-            const float g = p1 > 0.f ? (a.keep1 ? 2.f * y : y) : 0.f;
+            const float g = S.rec[RL_P1 + n] > 0.f ? km1 * y : 0.f;
             gs[kGsP1 + n] = g;
             return g;
           },
@@ -708,6 +780,12 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
             [&](int n, float v) { S.dfr[n] = v; });
       lds_barrier();
     }
+  }
+  // resident dkeys accumulators -> memory (each row is owned by exactly one wave of one peer)
+#pragma unroll
+  for (int i = 0; i < kAR; ++i) {
+    const int s = s_first + i * s_stride;
+    if (s < len) reinterpret_cast<float4*>(dkeys + (int64_t)s * kAtt)[lane] = dkacc[i];
   }
   // attention_v gradient: reduce per-lane partials across waves, then one atomic per element
   reinterpret_cast<float4*>(S.red + wave * 256)[lane] = dv4;
