@@ -16,13 +16,21 @@ namespace {
 
 constexpr int BK = 16;
 
+// component-wise select (a struct-level `ok ? t : zero` is lowered through scratch memory by hipcc)
+__device__ __forceinline__ float4 sel4(bool ok, const float4 t) {
+  return make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+}
+
 struct RowInfo {
   int m;      // global output row
   int t;      // position inside its sequence
   bool ok;    // m < M
 };
 
-template <int WM, int WN>
+// VA / VB: the A / W operand satisfies the vector-load contract (16-byte aligned base and leading dimension, K resp.
+// N a multiple of 4, or padded storage declared through Kld / Nld) -> branch-free float4 loads whose waits the
+// compiler can sink below the MFMA block.  The scalar fallback keeps exact bounds checks for odd test shapes.
+template <int WM, int WN, bool VA, bool VB>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmBatch batch) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr int LDS_A = BM + 4, LDS_B = BN + 4;
@@ -37,7 +45,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmBatch batch) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const bool vecA = P.flags & 1, vecB = P.flags & 2;
 
   // --- loader mapping ---
   const int a_kq = tid & 3;          // which float4 along k (4 per row)
@@ -59,6 +66,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmBatch batch) {
   const int nit = P.taps * ktiles;
 
   float4 ra[A_PER], rb[B_PER];
+  bool oka[A_PER], okb[B_PER];   // VEC paths: validity of the raw float4 in flight; applied when it is written to LDS
 
   auto load_tile = [&](int it) {
     const int tap = it / ktiles;
@@ -68,17 +76,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmBatch batch) {
     for (int i = 0; i < A_PER; ++i) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       const int st = ar[i].t + sh;
-      if (ar[i].ok && st >= 0 && st < P.T) {
-        const int k = k0 + a_kq * 4;
+      const int k = k0 + a_kq * 4;
+      if constexpr (VA) {
+        const bool ok = ar[i].ok && (unsigned)st < (unsigned)P.T && k < P.K;
+        const int64_t off = (int64_t)ok * ((int64_t)(ar[i].m + sh) * P.lda + k);
+        v = *reinterpret_cast<const float4*>(P.A + off);
+        oka[i] = ok;
+      } else if (ar[i].ok && st >= 0 && st < P.T) {
         const float* p = P.A + (int64_t)(ar[i].m + sh) * P.lda + k;
-        if (vecA && k + 3 < P.K) {
-          v = *reinterpret_cast<const float4*>(p);
-        } else {
-          if (k < P.K) v.x = p[0];
-          if (k + 1 < P.K) v.y = p[1];
-          if (k + 2 < P.K) v.z = p[2];
-          if (k + 3 < P.K) v.w = p[3];
-        }
+        if (k < P.K) v.x = p[0];
+        if (k + 1 < P.K) v.y = p[1];
+        if (k + 2 < P.K) v.z = p[2];
+        if (k + 3 < P.K) v.w = p[3];
       }
       ra[i] = v;
     }
@@ -88,16 +97,17 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmBatch batch) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       const int k = k0 + b_k + i * B_KSTEP;
       const int n = n0 + b_c4 * 4;
-      if (k < P.K && (B_PER * B_KSTEP == BK || b_k + i * B_KSTEP < BK)) {
+      if constexpr (VB) {
+        const bool ok = k < P.K && n < P.Nld;
+        const int64_t off = (int64_t)ok * ((int64_t)k * P.ldw + n);
+        v = *reinterpret_cast<const float4*>(Wt + off);
+        okb[i] = ok;
+      } else if (k < P.K) {
         const float* p = Wt + (int64_t)k * P.ldw + n;
-        if (vecB && n + 3 < P.N) {
-          v = *reinterpret_cast<const float4*>(p);
-        } else {
-          if (n < P.N) v.x = p[0];
-          if (n + 1 < P.N) v.y = p[1];
-          if (n + 2 < P.N) v.z = p[2];
-          if (n + 3 < P.N) v.w = p[3];
-        }
+        if (n < P.N) v.x = p[0];
+        if (n + 1 < P.N) v.y = p[1];
+        if (n + 2 < P.N) v.z = p[2];
+        if (n + 3 < P.N) v.w = p[3];
       }
       rb[i] = v;
     }
@@ -106,15 +116,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmBatch batch) {
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
       const int r = a_row + 64 * i;
-      As[buf][a_kq * 4 + 0][r] = ra[i].x;
-      As[buf][a_kq * 4 + 1][r] = ra[i].y;
-      As[buf][a_kq * 4 + 2][r] = ra[i].z;
-      As[buf][a_kq * 4 + 3][r] = ra[i].w;
+      const float4 v = VA ? sel4(oka[i], ra[i]) : ra[i];
+      As[buf][a_kq * 4 + 0][r] = v.x;
+      As[buf][a_kq * 4 + 1][r] = v.y;
+      As[buf][a_kq * 4 + 2][r] = v.z;
+      As[buf][a_kq * 4 + 3][r] = v.w;
     }
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
       const int k = b_k + i * B_KSTEP;
-      if (k < BK) *reinterpret_cast<float4*>(&Bs[buf][k][b_c4 * 4]) = rb[i];
+      if (k < BK) *reinterpret_cast<float4*>(&Bs[buf][k][b_c4 * 4]) = VB ? sel4(okb[i], rb[i]) : rb[i];
     }
   };
 
@@ -134,18 +145,26 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmBatch batch) {
   for (int it = 0; it < nit; ++it) {
     const int buf = it & 1;
     if (it + 1 < nit) load_tile(it + 1);
+    // LDS operands are fetched one k-pair ahead of the MFMAs that consume them
+    float a[2][WM], b[2][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) a[0][i] = As[buf][lk][wm * (32 * WM) + i * 32 + li];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) b[0][j] = Bs[buf][lk][wn * (32 * WN) + j * 32 + li];
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
-      float a[WM], b[WN];
+      const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+      if (kk + 2 < BK) {
 #pragma unroll
-      for (int i = 0; i < WM; ++i) a[i] = As[buf][kk + lk][wm * (32 * WM) + i * 32 + li];
+        for (int i = 0; i < WM; ++i) a[nxt][i] = As[buf][kk + 2 + lk][wm * (32 * WM) + i * 32 + li];
 #pragma unroll
-      for (int j = 0; j < WN; ++j) b[j] = Bs[buf][kk + lk][wn * (32 * WN) + j * 32 + li];
+        for (int j = 0; j < WN; ++j) b[nxt][j] = Bs[buf][kk + 2 + lk][wn * (32 * WN) + j * 32 + li];
+      }
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
     }
     if (it + 1 < nit) store_tile(buf ^ 1);
     __syncthreads();
@@ -178,7 +197,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmBatch batch) {
 }
 
 // dW[z][tap][k][n] += sum_m A[z][row(m,tap)][k] * dY[z][m][n]; reduction over m split across blockIdx.z slices.
-template <int WM, int WN>
+template <int WM, int WN, bool VA, bool VB>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs P) {
   constexpr int BM = 64 * WM, BN = 64 * WN;   // BM tiles the k (output row) dimension
   constexpr int LDS_A = BM + 4, LDS_B = BN + 4;
@@ -198,7 +217,6 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs P) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const bool vecA = P.flags & 1, vecB = P.flags & 2;
   const int sh = tap - P.pad_l;
 
   constexpr int A_COLS4 = BM / 4, B_COLS4 = BN / 4;
@@ -212,6 +230,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs P) {
   if (nit <= 0) return;
 
   float4 ra[A_PER], rb[B_PER];
+  bool oka[A_PER], okb[B_PER];
   const bool do_bias = P.dbias != nullptr && blockIdx.x == 0 && tap == 0;
   float4 bsum[B_PER];
 #pragma unroll
@@ -223,19 +242,21 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs P) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       const int r = a_r + i * A_RSTEP;
       const int m = mm0 + r;
-      if (r < BK && m < m_end) {
+      const int k = k0 + a_c4 * 4;
+      if constexpr (VA) {
+        const int st = (m % P.T) + sh;
+        const bool ok = r < BK && m < m_end && (unsigned)st < (unsigned)P.T && k < P.K;
+        const int64_t off = (int64_t)ok * ((int64_t)(m + sh) * P.lda + k);
+        v = *reinterpret_cast<const float4*>(A + off);
+        oka[i] = ok;
+      } else if (r < BK && m < m_end) {
         const int st = (m % P.T) + sh;
         if (st >= 0 && st < P.T) {
-          const int k = k0 + a_c4 * 4;
           const float* p = A + (int64_t)(m + sh) * P.lda + k;
-          if (vecA && k + 3 < P.K) {
-            v = *reinterpret_cast<const float4*>(p);
-          } else {
-            if (k < P.K) v.x = p[0];
-            if (k + 1 < P.K) v.y = p[1];
-            if (k + 2 < P.K) v.z = p[2];
-            if (k + 3 < P.K) v.w = p[3];
-          }
+          if (k < P.K) v.x = p[0];
+          if (k + 1 < P.K) v.y = p[1];
+          if (k + 2 < P.K) v.z = p[2];
+          if (k + 3 < P.K) v.w = p[3];
         }
       }
       ra[i] = v;
@@ -245,32 +266,34 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs P) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       const int r = b_r + i * B_RSTEP;
       const int m = mm0 + r;
-      if (r < BK && m < m_end) {
-        const int n = n0 + b_c4 * 4;
+      const int n = n0 + b_c4 * 4;
+      if constexpr (VB) {
+        const bool ok = r < BK && m < m_end && n < P.Nld;
+        const int64_t off = (int64_t)ok * ((int64_t)m * P.ldy + n);
+        v = *reinterpret_cast<const float4*>(Y + off);
+        okb[i] = ok;
+      } else if (r < BK && m < m_end) {
         const float* p = Y + (int64_t)m * P.ldy + n;
-        if (vecB && n + 3 < P.N) {
-          v = *reinterpret_cast<const float4*>(p);
-        } else {
-          if (n < P.N) v.x = p[0];
-          if (n + 1 < P.N) v.y = p[1];
-          if (n + 2 < P.N) v.z = p[2];
-          if (n + 3 < P.N) v.w = p[3];
-        }
+        if (n < P.N) v.x = p[0];
+        if (n + 1 < P.N) v.y = p[1];
+        if (n + 2 < P.N) v.z = p[2];
+        if (n + 3 < P.N) v.w = p[3];
       }
       rb[i] = v;
-      if (do_bias) { bsum[i].x += v.x; bsum[i].y += v.y; bsum[i].z += v.z; bsum[i].w += v.w; }
     }
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
       const int r = a_r + i * A_RSTEP;
-      if (r < BK) *reinterpret_cast<float4*>(&As[buf][r][a_c4 * 4]) = ra[i];
+      if (r < BK) *reinterpret_cast<float4*>(&As[buf][r][a_c4 * 4]) = VA ? sel4(oka[i], ra[i]) : ra[i];
     }
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
       const int r = b_r + i * B_RSTEP;
-      if (r < BK) *reinterpret_cast<float4*>(&Bs[buf][r][b_c4 * 4]) = rb[i];
+      const float4 v = VB ? sel4(okb[i], rb[i]) : rb[i];
+      if (r < BK) *reinterpret_cast<float4*>(&Bs[buf][r][b_c4 * 4]) = v;
+      if (do_bias) { bsum[i].x += v.x; bsum[i].y += v.y; bsum[i].z += v.z; bsum[i].w += v.w; }
     }
   };
 
@@ -289,18 +312,26 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs P) {
   for (int it = 0; it < nit; ++it) {
     const int buf = it & 1;
     if (it + 1 < nit) load_tile(it + 1);
+    // LDS operands are fetched one k-pair ahead of the MFMAs that consume them
+    float a[2][WM], b[2][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) a[0][i] = As[buf][lk][wm * (32 * WM) + i * 32 + li];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) b[0][j] = Bs[buf][lk][wn * (32 * WN) + j * 32 + li];
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
-      float a[WM], b[WN];
+      const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+      if (kk + 2 < BK) {
 #pragma unroll
-      for (int i = 0; i < WM; ++i) a[i] = As[buf][kk + lk][wm * (32 * WM) + i * 32 + li];
+        for (int i = 0; i < WM; ++i) a[nxt][i] = As[buf][kk + 2 + lk][wm * (32 * WM) + i * 32 + li];
 #pragma unroll
-      for (int j = 0; j < WN; ++j) b[j] = Bs[buf][kk + lk][wn * (32 * WN) + j * 32 + li];
+        for (int j = 0; j < WN; ++j) b[nxt][j] = Bs[buf][kk + 2 + lk][wn * (32 * WN) + j * 32 + li];
+      }
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
     }
     if (it + 1 < nit) store_tile(buf ^ 1);
     __syncthreads();
@@ -362,13 +393,25 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 void conv_gemm_set_flags(ConvGemmProblem& p) {
   p.flags = 0;
-  if (p.lda % 4 == 0 && aligned16(p.A)) p.flags |= 1;
-  if (p.ldw % 4 == 0 && aligned16(p.W) && ((int64_t)p.K * p.ldw) % 4 == 0) p.flags |= 2;
+  if (p.Nld <= 0) p.Nld = (p.N % 4 == 0) ? p.N : 0;   // loadable W columns (multiple of 4); 0 = no vector contract
+  if (p.lda % 4 == 0 && aligned16(p.A) && p.K % 4 == 0) p.flags |= 1;
+  if (p.ldw % 4 == 0 && aligned16(p.W) && ((int64_t)p.K * p.ldw) % 4 == 0 && p.Nld > 0 && p.Nld % 4 == 0 && p.Nld <= p.ldw)
+    p.flags |= 2;
+}
+
+template <int WM, int WN>
+static void dispatch_nn(int flags, dim3 grid, hipStream_t s, ConvGemmBatch& batch) {
+  switch (flags & 3) {
+    case 3: hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, true, true>), grid, dim3(256), 0, s, batch); break;
+    case 1: hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, true, false>), grid, dim3(256), 0, s, batch); break;
+    case 2: hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, false, true>), grid, dim3(256), 0, s, batch); break;
+    default: hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, false, false>), grid, dim3(256), 0, s, batch); break;
+  }
 }
 
 int launch_conv_gemm_batch(ConvGemmBatch& batch, hipStream_t stream) {
   TACO_REQUIRE(batch.n >= 1 && batch.n <= kMaxGemmBatch, "conv_gemm: batch size %d out of range", batch.n);
-  int maxM = 0, maxN = 0;
+  int maxM = 0, maxN = 0, flags = 3;
   double work = 0;
   for (int i = 0; i < batch.n; ++i) {
     ConvGemmProblem& p = batch.p[i];
@@ -377,17 +420,16 @@ int launch_conv_gemm_batch(ConvGemmBatch& batch, hipStream_t stream) {
                  p.M, p.N, p.K, p.taps, p.T);
     TACO_REQUIRE(p.M % p.T == 0, "conv_gemm: M (%d) must be a multiple of T (%d)", p.M, p.T);
     conv_gemm_set_flags(p);
+    flags &= p.flags;   // one kernel variant per launch: every problem of the batch must meet the contract
     maxM = p.M > maxM ? p.M : maxM;
     maxN = p.N > maxN ? p.N : maxN;
     work += (double)cdiv(p.M, 128) * cdiv(p.N, 128);
   }
   // Big tiles only when they still fill the chip (256 CUs); otherwise 64x64 tiles for more workgroups.
   if (work >= 384) {
-    dim3 grid(cdiv(maxM, 128), cdiv(maxN, 128), batch.n);
-    hipLaunchKernelGGL((conv_gemm_kernel<2, 2>), grid, dim3(256), 0, stream, batch);
+    dispatch_nn<2, 2>(flags, dim3(cdiv(maxM, 128), cdiv(maxN, 128), batch.n), stream, batch);
   } else {
-    dim3 grid(cdiv(maxM, 64), cdiv(maxN, 64), batch.n);
-    hipLaunchKernelGGL((conv_gemm_kernel<1, 1>), grid, dim3(256), 0, stream, batch);
+    dispatch_nn<1, 1>(flags, dim3(cdiv(maxM, 64), cdiv(maxN, 64), batch.n), stream, batch);
   }
   TACO_LAUNCH_CHECK("conv_gemm");
   return TACO_OK;
@@ -400,13 +442,24 @@ int launch_conv_gemm(const ConvGemmProblem& p, hipStream_t stream) {
   return launch_conv_gemm_batch(b, stream);
 }
 
+template <int WM, int WN>
+static void dispatch_tn(int flags, dim3 grid, hipStream_t s, const GemmTnArgs& a) {
+  switch (flags & 3) {
+    case 3: hipLaunchKernelGGL((gemm_tn_kernel<WM, WN, true, true>), grid, dim3(256), 0, s, a); break;
+    case 1: hipLaunchKernelGGL((gemm_tn_kernel<WM, WN, true, false>), grid, dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((gemm_tn_kernel<WM, WN, false, true>), grid, dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL((gemm_tn_kernel<WM, WN, false, false>), grid, dim3(256), 0, s, a); break;
+  }
+}
+
 int launch_gemm_tn(GemmTnArgs a, bool zero_first, hipStream_t stream) {
   TACO_REQUIRE(a.A && a.Y && a.W, "gemm_tn: null operand");
   TACO_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.taps > 0 && a.T > 0 && a.batch > 0, "gemm_tn: bad dims");
   TACO_REQUIRE(a.M % a.T == 0, "gemm_tn: M (%d) must be a multiple of T (%d)", a.M, a.T);
   a.flags = 0;
-  if (a.lda % 4 == 0 && aligned16(a.A) && a.strideA % 4 == 0) a.flags |= 1;
-  if (a.ldy % 4 == 0 && aligned16(a.Y) && a.strideY % 4 == 0) a.flags |= 2;
+  if (a.Nld <= 0) a.Nld = (a.N % 4 == 0) ? a.N : 0;
+  if (a.lda % 4 == 0 && aligned16(a.A) && a.strideA % 4 == 0 && a.K % 4 == 0) a.flags |= 1;
+  if (a.ldy % 4 == 0 && aligned16(a.Y) && a.strideY % 4 == 0 && a.Nld > 0 && a.Nld % 4 == 0 && a.Nld <= a.ldy) a.flags |= 2;
   if (zero_first) {
     for (int b = 0; b < a.batch; ++b) {
       hipError_t e = hipMemset2DAsync(a.W + (int64_t)b * a.strideW, (size_t)a.ldw * 4, 0, (size_t)a.N * 4,
@@ -431,9 +484,9 @@ int launch_gemm_tn(GemmTnArgs a, bool zero_first, hipStream_t stream) {
   a.chunk = chunk;
   dim3 grid(cdiv(a.K, bm), cdiv(a.N, bm), a.batch * a.taps * splits);
   if (big)
-    hipLaunchKernelGGL((gemm_tn_kernel<2, 2>), grid, dim3(256), 0, stream, a);
+    dispatch_tn<2, 2>(a.flags, grid, stream, a);
   else
-    hipLaunchKernelGGL((gemm_tn_kernel<1, 1>), grid, dim3(256), 0, stream, a);
+    dispatch_tn<1, 1>(a.flags, grid, stream, a);
   TACO_LAUNCH_CHECK("gemm_tn");
   return TACO_OK;
 }

@@ -17,6 +17,7 @@ struct ConvGemmProblem {
   float* Cpre = nullptr;
   int lda = 0, ldw = 0, ldr = 0, ldc = 0;
   int M = 0, N = 0, K = 0, taps = 1, T = 1, pad_l = 0, act = 0, flags = 0;
+  int Nld = 0;         // loadable W columns (>= N, multiple of 4, <= ldw) when the storage is padded; 0 = derive from N
   int atomic_out = 0;  // C += result with fp32 atomics (C pre-zeroed by the caller); several problems may share C
 };
 struct ConvGemmBatch {
@@ -33,6 +34,7 @@ struct GemmTnArgs {
   int batch = 1;
   int64_t strideA = 0, strideY = 0, strideW = 0;
   int splits = 1, chunk = 0, flags = 0;
+  int Nld = 0;   // loadable Y columns (>= N, multiple of 4, <= ldy) when Y rows are zero-padded; 0 = derive from N
 };
 
 int launch_conv_gemm_batch(ConvGemmBatch& batch, hipStream_t stream);

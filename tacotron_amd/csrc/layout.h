@@ -75,6 +75,7 @@ struct WsLayout {
   int64_t values, keys;
   int64_t stash, prein, xchg, err;
   CbhgWs post;
+  int64_t wd_pad;
   int64_t loss;  // 4 floats
   // backward
   int64_t ds2s, dout_pad, paramsT, gstash, dkeys, dvalues, ds2s_tot;

@@ -149,7 +149,7 @@ void build_trans_layout(const TacoShape& s, const ParamLayout& P, TransLayout& T
   T.q_w = a.add("", {kAtt, R80});
   T.att_w = a.add("", {kAtt, R80 + kAtt});
   trans_cbhg(a, P.post, T.post);
-  T.post_dense = a.add("", {kFft, 2 * kCb});
+  T.post_dense = a.add("", {1028, 2 * kCb});   // 1025 rows + 3 zero rows: the backward GEMM runs with K padded to 1028
   T.total = a.off;
 }
 
@@ -192,6 +192,7 @@ void build_ws_layout(const TacoShape& s, bool train, const TransLayout& T, WsLay
   W.xchg = a.add("dec.xchg", {decoder_xchg_bytes(s.B, s.Tt) / 4});
   W.err = a.add("dec.err", {512});   // [0],[1] error words; floats 16.. = optional phase trace
   ws_cbhg(a, "post.", P.post, M2, train, W.post);
+  W.wd_pad = a.add("post.wd_pad", {2 * kCb, 1028});   // post/dense kernel re-pitched to a 16-byte-aligned leading dimension
   W.loss = a.add("loss", {4});
   if (train) {
     const int64_t Mx = M1 > M2 ? M1 : M2;

@@ -226,16 +226,28 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
   // post-net (tacotron.py:142-152): (B,Td,80r) reinterpreted as (B, Td*r, 80)
   CbhgBufs pb = cbhg_bufs(ws, W.post);
   TACO_TRY(cbhg_fwd(P, PL.post, s2s, B, Td * r, pb, train, s));
-  TACO_TRY(launch_conv_gemm(dense_problem(pb.out, 2 * kCb, P + PL.post_dense.w, kFft, P + PL.post_dense.b, output, kFft, M2,
-                                          kFft, 2 * kCb, TACO_ACT_NONE), s));
+  {
+    // (256, 1025) kernel -> pitch 1028 so the W tile loads are 16-byte aligned float4 (pad columns are never stored)
+    hipError_t e = hipMemcpy2DAsync(ws + W.wd_pad, 1028 * sizeof(float), P + PL.post_dense.w, kFft * sizeof(float),
+                                    kFft * sizeof(float), 2 * kCb, hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) {
+      taco_set_error("forward: memcpy2D: %s", hipGetErrorString(e));
+      return TACO_ELAUNCH;
+    }
+    ConvGemmProblem p = dense_problem(pb.out, 2 * kCb, ws + W.wd_pad, 1028, P + PL.post_dense.b, output, kFft, M2, kFft,
+                                      2 * kCb, TACO_ACT_NONE);
+    p.Nld = 1028;
+    TACO_TRY(launch_conv_gemm(p, s));
+  }
   (void)R80;
   return TACO_OK;
 }
 
 int tn(const float* A, int lda, int K, const float* Y, int ldy, int N, float* W, int ldw, int M, int T, int pad_l,
-       hipStream_t s, int taps = 1, float* dbias = nullptr) {
+       hipStream_t s, int taps = 1, float* dbias = nullptr, int Nld = 0) {
   GemmTnArgs a;
   a.dbias = dbias;
+  a.Nld = Nld;
   a.A = A; a.lda = lda; a.Y = Y; a.ldy = ldy; a.W = W; a.ldw = ldw; a.M = M; a.N = N; a.K = K; a.taps = taps; a.T = T;
   a.pad_l = pad_l;
   return launch_gemm_tn(a, false, s);
@@ -288,6 +300,11 @@ int prepare_transposes(const float* P, const ParamLayout& L, const TransLayout& 
   TACO_TRY(tr(L.q_w, T.q_w, 1, R80, kAtt));
   TACO_TRY(tr(L.att_w, T.att_w, 1, R80 + kAtt, kAtt));
   TACO_TRY(tr(L.post_dense.w, T.post_dense, 1, 2 * kCb, kFft));
+  hipError_t e = hipMemsetAsync(PT + T.post_dense + (int64_t)kFft * 2 * kCb, 0, (size_t)3 * 2 * kCb * sizeof(float), s);
+  if (e != hipSuccess) {
+    taco_set_error("prepare_transposes: memset: %s", hipGetErrorString(e));
+    return TACO_ELAUNCH;
+  }
   return launch_transpose_batch(tb, s);
 }
 
@@ -503,10 +520,10 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
 
   // ---- final dense (tacotron.py:148): output = post_out . Wd + bd ----
   const float* dOutPad = ws + W.dout_pad;  // (M2, 1028) = sign(output - stft), written by taco_forward
-  TACO_TRY(tn(pb.out, 2 * kCb, 2 * kCb, dOutPad, 1028, kFft, G + PL.post_dense.w, kFft, M2, M2, 0, s, 1, G + PL.post_dense.b));
+  TACO_TRY(tn(pb.out, 2 * kCb, 2 * kCb, dOutPad, 1028, kFft, G + PL.post_dense.w, kFft, M2, M2, 0, s, 1, G + PL.post_dense.b, 1028));
   float* dPostOut = sc.gG;  // (M2,256); consumed by the bi-GRU backward before gG is reused
   TACO_TRY(launch_conv_gemm(dense_problem(dOutPad, 1028, PT + TL.post_dense, 2 * kCb, nullptr, dPostOut, 2 * kCb, M2, 2 * kCb,
-                                          kFft, TACO_ACT_NONE), s));
+                                          1028 /* K padded: dOutPad pad columns and WdT pad rows are zero */, TACO_ACT_NONE), s));
   // ---- post-net CBHG (input = seq2seq_output viewed as (B, Td*r, 80)) ----
   float* dPostIn = sc.gC;   // (M2, 80)
   TACO_TRY(cbhg_bwd(P, PT, G, PL.post, TL.post, seq2seq_output, dPostOut, B, F, pb, sc, dPostIn, s));
