@@ -84,6 +84,7 @@ def main():
     ap.add_argument('--text-len', type=int, default=200)
     ap.add_argument('--dec-steps', type=int, default=180)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--speakers', type=int, default=1, help='>1: VCTK-shaped multi-speaker model (BASELINE configs[4])')
     args = ap.parse_args()
 
     from tacotron_amd import lib
@@ -98,9 +99,9 @@ def main():
     torch.cuda.set_device(local)
 
     c = Config()
-    c.r, c.vocab_size = 2, 60
+    c.r, c.vocab_size, c.num_speakers = 2, 60, args.speakers
     B, Tt, Td = args.batch, args.text_len, args.dec_steps
-    batch = synthetic_batch(B, Tt, Td, c.r, c.vocab_size, seed=1234, rank=rank)
+    batch = synthetic_batch(B, Tt, Td, c.r, c.vocab_size, seed=1234, rank=rank, num_speakers=args.speakers)
     reducer = GradReducer() if world > 1 else None
     model = Tacotron(c, batch, train=True, seed=0, reducer=reducer)   # same init on every rank (seed 0)
     model._seed += rank * 7919                                        # per-rank dropout / sampling streams
@@ -152,8 +153,8 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': sec_per_step * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'Nancy-shaped train step (BASELINE configs[1]): B=%d/GPU, r=%d, Tt=%d chars, Td=%d steps '
-                                   '(%d mel frames/utt), sched-sampling 0.5, dropout 0.5, V=60, fwd+bwd+clip+Adam'
-                                   % (B, c.r, Tt, Td, Td * c.r),
+                                   '(%d mel frames/utt), sched-sampling 0.5, dropout 0.5, V=60, speakers=%d, fwd+bwd+clip+Adam'
+                                   % (B, c.r, Tt, Td, Td * c.r, args.speakers),
                        'global_batch': world * B, 'parallelism': 'dp%d' % world},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': 157.3, 'unit': 'TFLOP/s',
                          'frac': achieved / 157.3, 'traffic': traffic, 'kernel': dom, 'avg_ms': dom_ms,

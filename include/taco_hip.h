@@ -44,6 +44,7 @@ typedef struct TacoShape {
   int32_t Td;  /* decoder steps = Config.max_decode_iter (tacotron.py:13)          */
   int32_t r;   /* mel frames per decoder step (audio.r, audio.py:15-17)            */
   int32_t V;   /* vocab_size (train.py:22)                                         */
+  int32_t S;   /* num_speakers (tacotron.py:23); <= 1 = single speaker, no speaker path */
 } TacoShape;
 
 /* One row of the parameter / workspace tables. */
@@ -98,13 +99,14 @@ int taco_bigru_fwd(const float* x, const float* wg_fw, const float* bg_fw, const
 /* ---- model level ---------------------------------------------------------------------------------------- */
 /* Tacotron.inference with train=True (tacotron.py:107-154) + add_loss_op (tacotron.py:156-165).
  *   text (B,Tt) int32; text_length (B) int32; mel (B,Td,80r); stft (B,Td,1025r);
+ *   speaker (B) int32 speaker ids, used (and required) only when shape->S > 1 (tacotron.py:117-124, ops.py:101-115);
  *   masks (uint8 0/1, nullable = no dropout / no sampling):
  *     enc_keep1 (B,Tt,256), enc_keep2 (B,Tt,128)  encoder pre_net dropout keep masks (tacotron.py:128)
  *     dec_keep1 (B,Td,256), dec_keep2 (B,Td,128)  decoder pre_net dropout keep masks (tacotron.py:64-71)
  *     sample (Td,B): 1 => step t+1 of row b is fed cell_output[t] (ScheduledOutputTrainingHelper, tacotron.py:84-85)
  *   outputs: seq2seq_output (B,Td,80r), output (B,Td,1025r), alignments (B,Td,Tt), loss[3] = {total, seq2seq, output}. */
 int taco_forward(const TacoShape* shape, const float* params, const int32_t* text, const int32_t* text_length,
-                 const float* mel, const float* stft, const uint8_t* enc_keep1, const uint8_t* enc_keep2,
+                 const int32_t* speaker, const float* mel, const float* stft, const uint8_t* enc_keep1, const uint8_t* enc_keep2,
                  const uint8_t* dec_keep1, const uint8_t* dec_keep2, const uint8_t* sample, float* seq2seq_output,
                  float* output, float* alignments, float* loss, void* workspace, void* stream);
 
@@ -112,13 +114,14 @@ int taco_forward(const TacoShape* shape, const float* params, const int32_t* tex
  * workspace with the same inputs / masks.  seq2seq_output and alignments are the tensors taco_forward produced.
  * grads has taco_param_count floats and is overwritten. */
 int taco_backward(const TacoShape* shape, const float* params, const int32_t* text, const int32_t* text_length,
-                  const float* seq2seq_output, const float* alignments, const uint8_t* enc_keep1,
+                  const int32_t* speaker, const float* seq2seq_output, const float* alignments, const uint8_t* enc_keep1,
                   const uint8_t* enc_keep2, const uint8_t* dec_keep1, const uint8_t* dec_keep2, const uint8_t* sample,
                   float* grads, void* workspace, void* stream);
 
 /* Tacotron.inference with train=False (test.py:29, ops.InferenceHelper ops.py:5-25): zeros first frame, feeds back
  * its own output, always Td steps, no dropout.  mel/stft/loss absent. */
 int taco_infer(const TacoShape* shape, const float* params, const int32_t* text, const int32_t* text_length,
+               const int32_t* speaker,
                float* seq2seq_output, float* output, float* alignments, void* workspace, void* stream);
 
 /* add_train_op (tacotron.py:167-185): global-norm clip (cap_grads) then TF-form Adam, in place.

@@ -17,9 +17,9 @@ from oracle import taco_torch as ot
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
 
 
-def make_case(r, V=20, B=2, Tt=9, Td=5, seed=0):
-    rng = np.random.default_rng(100 + r)
-    p = on.init_params(V, r, seed=seed, perturb=0.3)
+def make_case(r, V=20, B=2, Tt=9, Td=5, seed=0, num_speakers=1):
+    rng = np.random.default_rng(100 + r + 1000 * (num_speakers > 1))
+    p = on.init_params(V, r, seed=seed, perturb=0.3, num_speakers=num_speakers)
     text = rng.integers(1, V, size=(B, Tt)).astype(np.int32)
     tl = np.array([Tt, max(2, Tt - 3)], dtype=np.int32)[:B]
     for b in range(B):
@@ -34,6 +34,8 @@ def make_case(r, V=20, B=2, Tt=9, Td=5, seed=0):
         'sample': rng.integers(0, 2, (Td, B)).astype(np.uint8),
     }
     inp = {'text': text, 'text_length': tl, 'mel': mel, 'stft': stft}
+    if num_speakers > 1:
+        inp['speaker'] = rng.integers(0, num_speakers, size=B).astype(np.int32)
     fm = {k: v.astype(np.float64) for k, v in masks.items()}
     s2s, out, al, enc = on.forward(p, inp, r, Td, True, fm)
     loss = on.loss_fn(s2s, out, mel, stft)
@@ -43,9 +45,10 @@ def make_case(r, V=20, B=2, Tt=9, Td=5, seed=0):
     # attention argmax margins
     srt = np.sort(al, -1)
     margin = srt[..., -1] - srt[..., -2]
-    flat = on.flatten_params(p, V, r, np.float64)
+    flat = on.flatten_params(p, V, r, np.float64, num_speakers)
     d = dict(
         r=r, V=V, B=B, Tt=Tt, Td=Td, seed=seed, perturb=0.3, param_checksum=float(np.abs(flat).sum()),
+        num_speakers=num_speakers, speaker=inp.get('speaker', np.zeros(B, np.int32)),
         text=text, text_length=tl, mel=mel.astype(np.float32), stft=stft.astype(np.float32),
         seq2seq_output=s2s, output=out, alignments=al, encoded=enc, loss=loss, argmax_margin=margin,
         infer_seq2seq_output=is2s, infer_output=iout, infer_alignments=ial,
@@ -63,9 +66,9 @@ def make_case(r, V=20, B=2, Tt=9, Td=5, seed=0):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    for r in (2, 5):
-        d = make_case(r)
-        path = os.path.join(OUT, 'model_r%d.npz' % r)
+    for r, ns in ((2, 1), (5, 1), (2, 7)):
+        d = make_case(r, num_speakers=ns)
+        path = os.path.join(OUT, 'model_r%d%s.npz' % (r, '_spk' if ns > 1 else ''))
         np.savez_compressed(path, **d)
         print(path, os.path.getsize(path) // 1024, 'KiB', 'loss', d['loss'], 'min margin', d['argmax_margin'].min())
 

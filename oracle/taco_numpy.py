@@ -39,6 +39,9 @@ ASSUMPTIONS = [
     "                                                                  (ops.py:5-25)",
     "A10 dropout(rate=0.5, training): keep mask * 2 (inverted dropout) (tacotron.py:41-43)",
     "A11 loss = sum|seq2seq_output-mel| + sum|output-stft| (no mask)    (tacotron.py:158-160)",
+    "A13 multi-speaker (num_speakers>1): speaker table glorot-init; encoder CBHG only: per highway layer "
+    "s=relu(dense(spk,128)) concatenated to h (highway adapts 256->128), GRU h0=relu(dense(spk,128)) for both "
+    "directions; post-net CBHG and decoder get no speaker input      (ops.py:101-127, tacotron.py:96-97,131,147)",
     "A12 Adam TF form: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t*m/(sqrt(v)+eps); "
     "clip_by_global_norm(5): g *= 5/max(||g||,5)                      (tacotron.py:170-184)",
 ]
@@ -100,15 +103,16 @@ def gru_cell(x, h, wg, bg, wc, bc):
     return u * h + (1 - u) * c, r, u, c
 
 
-def bigru(x, p, prefix):
-    """tf.nn.bidirectional_dynamic_rnn(GRUCell, GRUCell, x) without sequence_length (ops.py:117-128)."""
+def bigru(x, p, prefix, h0=None):
+    """tf.nn.bidirectional_dynamic_rnn(GRUCell, GRUCell, x) without sequence_length (ops.py:117-128).
+    h0 (B,H): initial state of BOTH directions (ops.py:123-124, the speaker site), default zeros."""
     B, T, _ = x.shape
     H = p[prefix + 'fw/gates/bias'].shape[0] // 2
     out = np.zeros((B, T, 2 * H), dtype=x.dtype)
     for d, name in enumerate(('fw', 'bw')):
         wg, bg = p[prefix + name + '/gates/kernel'], p[prefix + name + '/gates/bias']
         wc, bc = p[prefix + name + '/candidate/kernel'], p[prefix + name + '/candidate/bias']
-        h = np.zeros((B, H), dtype=x.dtype)
+        h = np.zeros((B, H), dtype=x.dtype) if h0 is None else h0.copy()
         ts = range(T) if d == 0 else range(T - 1, -1, -1)
         for t in ts:
             h, _, _, _ = gru_cell(x[:, t, :], h, wg, bg, wc, bc)
@@ -125,8 +129,10 @@ def highway(x, p, prefix):
     return h * t + x * (1 - t)
 
 
-def cbhg(x, p, prefix, K):
-    """ops.CBHG (ops.py:48-132), single-speaker path."""
+def cbhg(x, p, prefix, K, speaker_embed=None):
+    """ops.CBHG (ops.py:48-132).  speaker_embed (B,16) enables the Deep-Voice-2 style sites (ops.py:101-115): per highway
+    layer s = relu(dense(spk, C)) tiled over T and concatenated to h (so highway() adapts 2C -> 128), and the bi-GRU
+    initial state s = relu(dense(spk, 128)) shared by both directions."""
     bank = [relu(conv1d_same(x, p[prefix + 'bank_%d/kernel' % k], p[prefix + 'bank_%d/bias' % k]))
             for k in range(1, K + 1)]
     y = np.concatenate(bank, -1)
@@ -138,8 +144,15 @@ def cbhg(x, p, prefix, K):
     y = bn_affine(y, p[prefix + 'proj2_bn/gamma'], p[prefix + 'proj2_bn/beta'])
     h = y + x
     for l in range(4):
-        h = highway(h, p, prefix + 'highway_%d/' % l)
-    return bigru(h, p, prefix + 'bigru/')
+        hp = prefix + 'highway_%d/' % l
+        if speaker_embed is not None:
+            sv = relu(dense(speaker_embed, p[hp + 'spk/kernel'], p[hp + 'spk/bias']))
+            h = np.concatenate([h, np.repeat(sv[:, None, :], h.shape[1], axis=1)], -1)
+        h = highway(h, p, hp)
+    h0 = None
+    if speaker_embed is not None:
+        h0 = relu(dense(speaker_embed, p[prefix + 'gru_init/kernel'], p[prefix + 'gru_init/bias']))
+    return bigru(h, p, prefix + 'bigru/', h0)
 
 
 def pre_net(x, p, prefix, keep1=None, keep2=None):
@@ -156,11 +169,12 @@ def pre_net(x, p, prefix, keep1=None, keep2=None):
 # ----------------------------------------------------------------------------------------------
 # model
 # ----------------------------------------------------------------------------------------------
-def encoder(p, text, keep1=None, keep2=None):
-    """embedding + encoder pre_net + CBHG(K=16) (tacotron.py:111-131)."""
+def encoder(p, text, keep1=None, keep2=None, speaker=None):
+    """embedding + (speaker embedding, tacotron.py:117-124) + encoder pre_net + CBHG(K=16) (tacotron.py:111-131)."""
     emb = p['embedding'][text]
+    spk = p['speaker_embed'][speaker] if (speaker is not None and 'speaker_embed' in p) else None
     pre = pre_net(emb, p, 'encoder/pre_net/', keep1, keep2)
-    return cbhg(pre, p, 'encoder/cbhg/', 16)
+    return cbhg(pre, p, 'encoder/cbhg/', 16, spk)
 
 
 def attention_memory(p, encoded, text_length):
@@ -236,7 +250,7 @@ def forward(p, inputs, r, n_steps, train, masks=None):
     dec_keep2, sample (any may be absent)."""
     masks = masks or {}
     enc = encoder(p, inputs['text'], masks.get('enc_keep1') if train else None,
-                  masks.get('enc_keep2') if train else None)
+                  masks.get('enc_keep2') if train else None, inputs.get('speaker'))
     if train:
         s2s, al = decoder(p, enc, inputs['text_length'], r, n_steps, mel=inputs['mel'],
                           sample_mask=masks.get('sample'), keep1=masks.get('dec_keep1'),
@@ -269,10 +283,14 @@ def clip_adam_step(params, grads, m, v, step, lr, cap=5.0, b1=0.9, b2=0.999, eps
 # ----------------------------------------------------------------------------------------------
 # parameters
 # ----------------------------------------------------------------------------------------------
-def param_spec(vocab_size, r):
-    """Ordered list of (name, shape, init) -- the same order/layout as csrc/model.hip's table.
-    init in {'glorot', 'zeros', 'ones'}.  TF-r1.2 default initialisers (SURVEY §8a footer)."""
+def param_spec(vocab_size, r, num_speakers=1, speaker_dim=16):
+    """Ordered list of (name, shape, init) -- the same order/layout as csrc/layout.hip's table.
+    init in {'glorot', 'zeros', 'ones'}.  TF-r1.2 default initialisers (SURVEY §8a footer).
+    num_speakers > 1 adds the speaker table (tacotron.py:117-124) and the encoder CBHG speaker sites (ops.py:101-115)."""
     spec = [('embedding', (vocab_size, 256), 'glorot')]
+    multi = num_speakers > 1
+    if multi:
+        spec.append(('speaker_embed', (num_speakers, speaker_dim), 'glorot'))
 
     def dense_(name, i, o, bias=True):
         spec.append((name + '/kernel', (i, o), 'glorot'))
@@ -285,7 +303,7 @@ def param_spec(vocab_size, r):
         spec.append((name + '/candidate/kernel', (cin + h, h), 'glorot'))
         spec.append((name + '/candidate/bias', (h,), 'zeros'))
 
-    def cbhg_(prefix, K, cin, c1, c2):
+    def cbhg_(prefix, K, cin, c1, c2, spk=False):
         for k in range(1, K + 1):
             spec.append((prefix + 'bank_%d/kernel' % k, (k, cin, 128), 'glorot'))
             spec.append((prefix + 'bank_%d/bias' % k, (128,), 'zeros'))
@@ -301,16 +319,21 @@ def param_spec(vocab_size, r):
         spec.append((prefix + 'proj2_bn/beta', (c2,), 'zeros'))
         for l in range(4):
             hp = prefix + 'highway_%d/' % l
-            if l == 0 and c2 != 128:
+            if spk:
+                dense_(hp + 'spk', speaker_dim, 128)
+                dense_(hp + 'adapt', 256, 128)
+            elif l == 0 and c2 != 128:
                 dense_(hp + 'adapt', c2, 128)
             dense_(hp + 'T', 128, 128)
             dense_(hp + 'H', 128, 128)
+        if spk:
+            dense_(prefix + 'gru_init', speaker_dim, 128)
         gru_(prefix + 'bigru/fw', 128, 128)
         gru_(prefix + 'bigru/bw', 128, 128)
 
     dense_('encoder/pre_net/dense', 256, 256)
     dense_('encoder/pre_net/dense_1', 256, 128)
-    cbhg_('encoder/cbhg/', 16, 128, 128, 128)
+    cbhg_('encoder/cbhg/', 16, 128, 128, 128, spk=multi)
     dense_('decoder/memory_layer', 256, 256, bias=False)
     dense_('decoder/pre_net/dense', 80, 256)
     dense_('decoder/pre_net/dense_1', 256, 128)
@@ -338,12 +361,12 @@ def glorot_limit(shape):
     return np.sqrt(6.0 / (fan_in + fan_out))
 
 
-def init_params(vocab_size, r, seed=0, dtype=np.float64, perturb=0.0):
+def init_params(vocab_size, r, seed=0, dtype=np.float64, perturb=0.0, num_speakers=1):
     """Seeded TF-default initialisation.  `perturb` > 0 additionally jitters biases / BN affine so that
     fixtures exercise them (all-zero biases would hide indexing bugs)."""
     rng = np.random.default_rng(seed)
     p = {}
-    for name, shape, init in param_spec(vocab_size, r):
+    for name, shape, init in param_spec(vocab_size, r, num_speakers):
         if init == 'glorot':
             lim = glorot_limit(shape)
             a = rng.uniform(-lim, lim, size=shape)
@@ -357,13 +380,13 @@ def init_params(vocab_size, r, seed=0, dtype=np.float64, perturb=0.0):
     return p
 
 
-def flatten_params(p, vocab_size, r, dtype=np.float32):
-    return np.concatenate([p[n].reshape(-1) for n, _, _ in param_spec(vocab_size, r)]).astype(dtype)
+def flatten_params(p, vocab_size, r, dtype=np.float32, num_speakers=1):
+    return np.concatenate([p[n].reshape(-1) for n, _, _ in param_spec(vocab_size, r, num_speakers)]).astype(dtype)
 
 
-def unflatten_params(flat, vocab_size, r):
+def unflatten_params(flat, vocab_size, r, num_speakers=1):
     p, o = {}, 0
-    for n, shape, _ in param_spec(vocab_size, r):
+    for n, shape, _ in param_spec(vocab_size, r, num_speakers):
         sz = int(np.prod(shape))
         p[n] = flat[o:o + sz].reshape(shape)
         o += sz

@@ -48,14 +48,14 @@ def _gru(x, h, wg, bg, wc, bc):
     return u * h + (1 - u) * c
 
 
-def _bigru(x, p, prefix):
+def _bigru(x, p, prefix, h0=None):
     B, T, _ = x.shape
     H = p[prefix + 'fw/gates/bias'].shape[0] // 2
     outs = []
     for name, order in (('fw', range(T)), ('bw', range(T - 1, -1, -1))):
         wg, bg = p[prefix + name + '/gates/kernel'], p[prefix + name + '/gates/bias']
         wc, bc = p[prefix + name + '/candidate/kernel'], p[prefix + name + '/candidate/bias']
-        h = x.new_zeros(B, H)
+        h = x.new_zeros(B, H) if h0 is None else h0
         seq = [None] * T
         for t in order:
             h = _gru(x[:, t], h, wg, bg, wc, bc)
@@ -72,7 +72,7 @@ def _highway(x, p, prefix):
     return h * t + x * (1 - t)
 
 
-def cbhg(x, p, prefix, K):
+def cbhg(x, p, prefix, K, spk=None):
     bank = torch.cat([torch.relu(_conv_same(x, p[prefix + 'bank_%d/kernel' % k], p[prefix + 'bank_%d/bias' % k]))
                       for k in range(1, K + 1)], 2)
     y = _maxpool(_bn(bank, p[prefix + 'bank_bn/gamma'], p[prefix + 'bank_bn/beta']))
@@ -82,8 +82,15 @@ def cbhg(x, p, prefix, K):
     y = _bn(y, p[prefix + 'proj2_bn/gamma'], p[prefix + 'proj2_bn/beta'])
     h = y + x
     for l in range(4):
-        h = _highway(h, p, prefix + 'highway_%d/' % l)
-    return _bigru(h, p, prefix + 'bigru/')
+        hp = prefix + 'highway_%d/' % l
+        if spk is not None:   # ops.py:101-105
+            sv = torch.relu(F.linear(spk, p[hp + 'spk/kernel'].t(), p[hp + 'spk/bias']))
+            h = torch.cat([h, sv[:, None, :].expand(-1, h.shape[1], -1)], 2)
+        h = _highway(h, p, hp)
+    h0 = None
+    if spk is not None:       # ops.py:111-115
+        h0 = torch.relu(F.linear(spk, p[prefix + 'gru_init/kernel'].t(), p[prefix + 'gru_init/bias']))
+    return _bigru(h, p, prefix + 'bigru/', h0)
 
 
 def _prenet(x, p, prefix, k1, k2):
@@ -104,7 +111,8 @@ def forward(p, inputs, r, n_steps, train, masks=None):
     text = inputs['text']
     B, Tt = text.shape
     emb = F.embedding(text, p['embedding'])
-    enc = cbhg(_prenet(emb, p, 'encoder/pre_net/', g('enc_keep1'), g('enc_keep2')), p, 'encoder/cbhg/', 16)
+    spk = F.embedding(inputs['speaker'], p['speaker_embed']) if ('speaker' in inputs and 'speaker_embed' in p) else None
+    enc = cbhg(_prenet(emb, p, 'encoder/pre_net/', g('enc_keep1'), g('enc_keep2')), p, 'encoder/cbhg/', 16, spk)
 
     # attention memory (tacotron.py:48-52)
     valid = torch.arange(Tt)[None, :] < inputs['text_length'][:, None]
@@ -167,6 +175,8 @@ def loss_and_grads(pnp, inputs_np, r, n_steps, masks_np=None, dtype=torch.float6
         'mel': torch.tensor(inputs_np['mel'], dtype=dtype),
         'stft': torch.tensor(inputs_np['stft'], dtype=dtype),
     }
+    if 'speaker' in inputs_np:
+        inputs['speaker'] = torch.tensor(inputs_np['speaker'], dtype=torch.int64)
     masks = {k: torch.tensor(v, dtype=dtype) for k, v in (masks_np or {}).items()}
     s2s, out, al, _ = forward(p, inputs, r, n_steps, True, masks)
     loss = loss_fn(s2s, out, inputs['mel'], inputs['stft'])

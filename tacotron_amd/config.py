@@ -57,8 +57,10 @@ class Config(object):
         for k, v in fixed.items():
             if getattr(self, k) != v:
                 raise ValueError('Config.%s=%r is not supported by libtaco_hip (compiled for %r)' % (k, getattr(self, k), v))
-        if self.num_speakers != 1:
-            raise NotImplementedError('multi-speaker (num_speakers > 1) path is not built yet (SURVEY §8 a4/a9)')
+        if self.num_speakers < 1:
+            raise ValueError('Config.num_speakers must be >= 1')
+        if self.num_speakers > 1 and self.speaker_embed_dim != 16:
+            raise ValueError('Config.speaker_embed_dim=%r is not supported by libtaco_hip (compiled for 16)' % self.speaker_embed_dim)
         if not (1 <= self.r <= 5):
             raise ValueError('Config.r must be in 1..5')
         for k in ('char_dropout_prob', 'audio_dropout_prob'):

@@ -17,8 +17,8 @@ constexpr int H = kCb;  // 128
 
 // grid = (B, 2 directions); block = 256
 __global__ __launch_bounds__(256, 1) void bigru_fwd_kernel(const float* __restrict__ xg, BiGruWeights w,
-                                                           float* __restrict__ out, float* __restrict__ ruc, int B,
-                                                           int T) {
+                                                           const float* __restrict__ h0, float* __restrict__ out,
+                                                           float* __restrict__ ruc, int B, int T) {
   const int b = blockIdx.x, d = blockIdx.y, j = threadIdx.x;
   const int col = j & (H - 1), half = j >> 7;
   __shared__ __attribute__((aligned(16))) float hs[H];
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256, 1) void bigru_fwd_kernel(const float* __restri
 #pragma unroll
     for (int k = 0; k < H / 2; ++k) wch[k] = wc[(int64_t)k * H];
   }
-  if (j < H) hs[j] = 0.f;
+  if (j < H) hs[j] = h0 ? h0[(int64_t)b * H + j] : 0.f;   // initial_state_fw = initial_state_bw = s (ops.py:123-124)
   lds_barrier();
 
   const int64_t row0 = (int64_t)b * T;
@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256, 1) void bigru_fwd_kernel(const float* __restri
 //   dr = d(rh)*h_prev; dgp = [dr*r(1-r), du*u(1-u)]; dh = dht*u + d(rh)*r + dgp . Wg_h^T
 __global__ __launch_bounds__(256, 1) void bigru_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                            const float* __restrict__ ruc, BiGruBwdWeights w,
-                                                           float* __restrict__ dxg, float* __restrict__ rh_out, int B,
+                                                           const float* __restrict__ h0, float* __restrict__ dxg,
+                                                           float* __restrict__ rh_out, float* __restrict__ dh0, int B,
                                                            int T) {
   const int b = blockIdx.x, d = blockIdx.y, j = threadIdx.x;
   const int col = j & (H - 1), half = j >> 7;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256, 1) void bigru_bwd_kernel(const float* __restri
       r = rp[col];
       u = rp[H + col];
       c = rp[2 * H + col];
-      hp = has_prev ? out[(row0 + tp) * (2 * H) + d * H + col] : 0.f;
+      hp = has_prev ? out[(row0 + tp) * (2 * H) + d * H + col] : (h0 ? h0[(int64_t)b * H + col] : 0.f);
       dht = dh + dout[(row0 + t) * (2 * H) + d * H + col];
       const float du = dht * (hp - c);
       const float dc = dht * (1.f - u);
@@ -189,21 +190,23 @@ __global__ __launch_bounds__(256, 1) void bigru_bwd_kernel(const float* __restri
     lds_barrier();
     if (half == 0) dh = dh_acc + q0 + q1 + part_s[1][col];
   }
+  if (dh0 && half == 0) dh0[((int64_t)d * B + b) * H + col] = dh;   // gradient w.r.t. the initial state
 }
 
 }  // namespace
 
-int launch_bigru_fwd(const float* xg, const BiGruWeights& w, float* out, float* ruc, int B, int T, hipStream_t s) {
+int launch_bigru_fwd(const float* xg, const BiGruWeights& w, const float* h0, float* out, float* ruc, int B, int T,
+                     hipStream_t s) {
   TACO_REQUIRE(B > 0 && T > 0, "bigru_fwd: bad dims");
-  hipLaunchKernelGGL(bigru_fwd_kernel, dim3(B, 2), dim3(256), 0, s, xg, w, out, ruc, B, T);
+  hipLaunchKernelGGL(bigru_fwd_kernel, dim3(B, 2), dim3(256), 0, s, xg, w, h0, out, ruc, B, T);
   TACO_LAUNCH_CHECK("bigru_fwd");
   return TACO_OK;
 }
 
-int launch_bigru_bwd(const float* dout, const float* out, const float* ruc, const BiGruBwdWeights& w, float* dxg,
-                     float* rh, int B, int T, hipStream_t s) {
+int launch_bigru_bwd(const float* dout, const float* out, const float* ruc, const BiGruBwdWeights& w, const float* h0,
+                     float* dxg, float* rh, float* dh0, int B, int T, hipStream_t s) {
   TACO_REQUIRE(B > 0 && T > 0, "bigru_bwd: bad dims");
-  hipLaunchKernelGGL(bigru_bwd_kernel, dim3(B, 2), dim3(256), 0, s, dout, out, ruc, w, dxg, rh, B, T);
+  hipLaunchKernelGGL(bigru_bwd_kernel, dim3(B, 2), dim3(256), 0, s, dout, out, ruc, w, h0, dxg, rh, dh0, B, T);
   TACO_LAUNCH_CHECK("bigru_bwd");
   return TACO_OK;
 }

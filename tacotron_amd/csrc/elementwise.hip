@@ -29,26 +29,27 @@ __device__ __forceinline__ float block_sum(float v, float* red /* >= 4 floats LD
 }
 
 __global__ void embedding_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids,
-                                 float* __restrict__ out, int64_t rows, int V) {
-  const int64_t total = rows * (kEmbed / 4);
+                                 float* __restrict__ out, int64_t rows, int V, int width) {
+  const int w4 = width / 4;
+  const int64_t total = rows * w4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = i / (kEmbed / 4);
-    const int c4 = (int)(i % (kEmbed / 4));
+    const int64_t row = i / w4;
+    const int c4 = (int)(i % w4);
     int id = ids[row];
     id = id < 0 ? 0 : (id >= V ? V - 1 : id);
-    reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(table + (int64_t)id * kEmbed)[c4];
+    reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(table + (int64_t)id * width)[c4];
   }
 }
 
 __global__ void embedding_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ ids,
-                                     float* __restrict__ dtable, int64_t rows, int V) {
-  const int64_t total = rows * kEmbed;
+                                     float* __restrict__ dtable, int64_t rows, int V, int width) {
+  const int64_t total = rows * width;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = i / kEmbed;
-    const int c = (int)(i % kEmbed);
+    const int64_t row = i / width;
+    const int c = (int)(i % width);
     int id = ids[row];
     id = id < 0 ? 0 : (id >= V ? V - 1 : id);
-    atomicAdd(&dtable[(int64_t)id * kEmbed + c], dout[i]);
+    atomicAdd(&dtable[(int64_t)id * width + c], dout[i]);
   }
 }
 
@@ -221,6 +222,20 @@ __global__ void colsum_kernel(const float* __restrict__ x, int ld, float* __rest
   if (threadIdx.y == 0 && c < N) atomicAdd(&out[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// grid = (N/64 ceil, B); block = (64, 4)
+__global__ void colsum_batched_kernel(const float* __restrict__ x, int ld, float* __restrict__ out, int T, int N) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  const int b = blockIdx.y;
+  float a = 0.f;
+  if (c < N)
+    for (int t = threadIdx.y; t < T; t += 4) a += x[((int64_t)b * T + t) * ld + c];
+  __shared__ float red[4][64];
+  red[threadIdx.y][threadIdx.x] = a;
+  __syncthreads();
+  if (threadIdx.y == 0 && c < N)
+    out[(int64_t)b * N + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
 __global__ void mask_rows_kernel(const float* __restrict__ x, const int32_t* __restrict__ len, float* __restrict__ y,
                                  int B, int T, int C) {
   const int C4 = C / 4;
@@ -370,12 +385,18 @@ __global__ void bernoulli_kernel(uint8_t* __restrict__ out, int64_t n, uint32_t 
     TACO_LAUNCH_CHECK(#kernel);                                                                        \
   } while (0)
 
-int launch_embedding(const float* table, const int32_t* ids, float* out, int64_t rows, int V, hipStream_t s) {
-  EW_LAUNCH(embedding_kernel, rows * (kEmbed / 4), s, table, ids, out, rows, V);
+int launch_embedding(const float* table, const int32_t* ids, float* out, int64_t rows, int V, hipStream_t s, int width) {
+  TACO_REQUIRE(width % 4 == 0, "embedding: width %% 4 != 0");
+  EW_LAUNCH(embedding_kernel, rows * (width / 4), s, table, ids, out, rows, V, width);
   return TACO_OK;
 }
-int launch_embedding_bwd(const float* dout, const int32_t* ids, float* dtable, int64_t rows, int V, hipStream_t s) {
-  EW_LAUNCH(embedding_bwd_kernel, rows * kEmbed, s, dout, ids, dtable, rows, V);
+int launch_embedding_bwd(const float* dout, const int32_t* ids, float* dtable, int64_t rows, int V, hipStream_t s, int width) {
+  EW_LAUNCH(embedding_bwd_kernel, rows * width, s, dout, ids, dtable, rows, V, width);
+  return TACO_OK;
+}
+int launch_colsum_batched(const float* x, int ld, float* out, int B, int T, int N, hipStream_t s) {
+  hipLaunchKernelGGL(colsum_batched_kernel, dim3((N + 63) / 64, B), dim3(64, 4), 0, s, x, ld, out, T, N);
+  TACO_LAUNCH_CHECK("colsum_batched");
   return TACO_OK;
 }
 int launch_bn_maxpool(const float* x, const float* gamma, const float* beta, float* y, int B, int T, int C, hipStream_t s) {

@@ -177,13 +177,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmBatch batch) {
     for (int j = 0; j < WN; ++j) {
       const int n = n0 + wn * (32 * WN) + j * 32 + li;
       if (n >= P.N) continue;
-      const float bias = P.bias ? P.bias[n] : 0.f;
+      const float bias0 = (P.bias && P.bias_stride == 0) ? P.bias[n] : 0.f;
       const float sc = P.scale ? P.scale[n] : 1.f;
       const float sf = P.shift ? P.shift[n] : 0.f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int m = m0 + wm * (32 * WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
         if (m >= P.M) continue;
+        const float bias = P.bias_stride ? P.bias[(int64_t)(m / P.T) * P.bias_stride + n] : bias0;
         float v = apply_act(acc[i][j][e] + bias, P.act);
         if (P.keep) v = P.keep[(int64_t)m * P.N + n] ? v * 2.0f : 0.0f;
         if (P.Cpre) P.Cpre[(int64_t)m * P.ldc + n] = v;

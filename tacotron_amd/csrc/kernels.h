@@ -17,6 +17,7 @@ struct ConvGemmProblem {
   float* Cpre = nullptr;
   int lda = 0, ldw = 0, ldr = 0, ldc = 0;
   int M = 0, N = 0, K = 0, taps = 1, T = 1, pad_l = 0, act = 0, flags = 0;
+  int bias_stride = 0; // 0: one bias vector; else bias[(m / T) * bias_stride + n] (per-sequence bias, e.g. speaker sites)
   int Nld = 0;         // loadable W columns (>= N, multiple of 4, <= ldw) when the storage is padded; 0 = derive from N
   int atomic_out = 0;  // C += result with fp32 atomics (C pre-zeroed by the caller); several problems may share C
 };
@@ -43,8 +44,8 @@ int launch_gemm_tn(GemmTnArgs a, bool zero_first, hipStream_t stream);
 int launch_gemm_naive(const ConvGemmProblem& p, hipStream_t stream);
 
 // ---------------------------------------------------------------- elementwise.hip
-int launch_embedding(const float* table, const int32_t* ids, float* out, int64_t rows, int V, hipStream_t s);
-int launch_embedding_bwd(const float* dout, const int32_t* ids, float* dtable, int64_t rows, int V, hipStream_t s);
+int launch_embedding(const float* table, const int32_t* ids, float* out, int64_t rows, int V, hipStream_t s, int width = kEmbed);
+int launch_embedding_bwd(const float* dout, const int32_t* ids, float* dtable, int64_t rows, int V, hipStream_t s, int width = kEmbed);
 // y = maxpool2_same(x*scale+shift) along T; x,y (B*T, C)
 int launch_bn_maxpool(const float* x, const float* gamma, const float* beta, float* y, int B, int T, int C, hipStream_t s);
 // dx, dgamma, dbeta of the op above (dgamma/dbeta accumulated with atomics)
@@ -63,6 +64,8 @@ int launch_affine_act_bwd(const float* pre, const float* gamma, const float* dy,
                           int64_t M, int N, int act, hipStream_t s);
 // out[n] += sum_m x[m*ld + n]
 int launch_colsum(const float* x, int ld, float* out, int64_t M, int N, hipStream_t s);
+// out[b*N + n] = sum_{t<T} x[(b*T + t)*ld + n]   (overwrites)
+int launch_colsum_batched(const float* x, int ld, float* out, int B, int T, int N, hipStream_t s);
 // values = enc * (t < len[b])
 int launch_mask_rows(const float* x, const int32_t* len, float* y, int B, int T, int C, hipStream_t s);
 int launch_add(const float* a, const float* b, float* y, int64_t n, hipStream_t s);  // y = a + b
@@ -98,7 +101,8 @@ struct BiGruWeights {
   const float* bc[2];  // (128)
 };
 // xg (B,T,768): per direction d: [d*384, d*384+256) gates x-proj (+bias), [d*384+256, d*384+384) candidate x-proj (+bias)
-int launch_bigru_fwd(const float* xg, const BiGruWeights& w, float* out, float* ruc, int B, int T, hipStream_t s);
+// h0 (B,128): initial state of both directions (nullable = zeros)
+int launch_bigru_fwd(const float* xg, const BiGruWeights& w, const float* h0, float* out, float* ruc, int B, int T, hipStream_t s);
 // Backward recurrence.  wgT/wcT: h-parts transposed: wghT (256,128) = Wg[128:,:]^T, wchT (128,128) = Wc[128:,:]^T.
 // dxg (B,T,768) receives pre-activation gradients [dgates | dcand] per direction.  rh (B,T,256) receives r*h_prev
 // per direction (for the candidate weight gradient).
@@ -106,8 +110,9 @@ struct BiGruBwdWeights {
   const float* wghT[2];
   const float* wchT[2];
 };
-int launch_bigru_bwd(const float* dout, const float* out, const float* ruc, const BiGruBwdWeights& w, float* dxg,
-                     float* rh, int B, int T, hipStream_t s);
+// dh0 (2,B,128), nullable: gradient w.r.t. the initial state per direction
+int launch_bigru_bwd(const float* dout, const float* out, const float* ruc, const BiGruBwdWeights& w, const float* h0,
+                     float* dxg, float* rh, float* dh0, int B, int T, hipStream_t s);
 
 // ---------------------------------------------------------------- decoder.hip
 struct DecWeights {

@@ -21,13 +21,17 @@ struct CbhgP {
   int64_t bank_g = -1, bank_be = -1;
   int64_t p1_w = -1, p1_b = -1, p1_g = -1, p1_be = -1;
   int64_t p2_w = -1, p2_b = -1, p2_g = -1, p2_be = -1;
-  bool has_adapt = false;
-  DenseP adapt;
+  bool spk = false;            // encoder CBHG of a multi-speaker model: speaker sites of ops.py:101-115
+  bool has_adapt[4] = {false, false, false, false};
+  DenseP adapt[4];             // highway() input adapter: post-net layer 0 (80->128); every layer (256->128) with speakers
+  DenseP spkd[4];              // per-layer speaker dense (16->128)
+  DenseP gru_init;             // speaker dense (16->128) -> bi-GRU initial state
   DenseP hwT[4], hwH[4];
   GruP fw, bw;
 };
 struct ParamLayout {
   int64_t emb = -1;
+  int64_t spk_embed = -1;  // (S,16) when S > 1
   DenseP enc_pre1, enc_pre2;
   CbhgP enc;
   int64_t mem_w = -1;
@@ -46,7 +50,10 @@ struct CbhgT {
   int64_t bank[16];      // (k, 128, cin)
   int64_t p1 = -1;       // (3, c1, K*128)
   int64_t p2 = -1;       // (3, c2, c1)
-  int64_t adapt = -1;    // (128, c2)
+  int64_t adapt[4];      // (128, cin_h): transposed rows [0, cin_h) of the adapter (cin_h = c2, or 128 with speakers)
+  int64_t adapt_s[4];    // (128, 128): transposed rows [128, 256) of the adapter (speaker half)
+  int64_t spkd[4];       // (128, 16)
+  int64_t gru_init = -1; // (128, 16)
   int64_t hw[4];         // (256, 128): rows [0,128) = Wt^T, [128,256) = Wh^T
   int64_t gru_x = -1;    // (768, 128): [Wg_fw[:128]^T ; Wc_fw[:128]^T ; Wg_bw[:128]^T ; Wc_bw[:128]^T]
   int64_t wghT[2];       // (256, 128) = Wg[128:]^T
@@ -65,12 +72,14 @@ struct TransLayout {
 };
 
 struct CbhgWs {
-  int64_t bank, pool, pj1pre, pj1, pj2pre, res, adapt, h[5], th[4], xg, out, ruc;
+  int64_t bank, pool, pj1pre, pj1, pj2pre, res, hx[4], h[5], th[4], xg, out, ruc;
   int64_t s_bank, s_p1, s_p2;  // folded BN scales
+  int64_t sv[4], rowb[4], h0;  // speaker sites: relu(dense(spk)) (B,128), per-sequence adapter bias (B,128), GRU init (B,128)
+  int64_t dh0, dsmall, dsmall2; // backward: (2,B,128), (B,128), (B,128)
 };
 struct WsLayout {
   // forward
-  int64_t emb, p1, p2;
+  int64_t emb, p1, p2, spk_e, dspk_e;
   CbhgWs enc;
   int64_t values, keys;
   int64_t stash, prein, xchg, err;

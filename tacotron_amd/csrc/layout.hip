@@ -22,6 +22,7 @@ int validate_shape(const TacoShape* s) {
   TACO_REQUIRE(s->Td >= 1 && s->Td <= 8192, "Td=%d out of range", s->Td);
   TACO_REQUIRE(s->r >= 1 && s->r <= 5, "r=%d out of range (1..5)", s->r);
   TACO_REQUIRE(s->V >= 1, "V=%d out of range", s->V);
+  TACO_REQUIRE(s->S >= 0 && s->S <= 100000, "S=%d out of range", s->S);
   return TACO_OK;
 }
 
@@ -64,7 +65,8 @@ void add_gru(Adder& a, const std::string& n, int cin, int h, GruP& g) {
   g.wc = a.add(n + "/candidate/kernel", {cin + h, h});
   g.bc = a.add(n + "/candidate/bias", {h});
 }
-void add_cbhg(Adder& a, const std::string& p, int K, int cin, int c1, int c2, CbhgP& c) {
+void add_cbhg(Adder& a, const std::string& p, int K, int cin, int c1, int c2, bool spk, CbhgP& c) {
+  c.spk = spk;
   c.K = K;
   c.cin = cin;
   c.c1 = c1;
@@ -83,13 +85,19 @@ void add_cbhg(Adder& a, const std::string& p, int K, int cin, int c1, int c2, Cb
   c.p2_b = a.add(p + "proj2/bias", {c2});
   c.p2_g = a.add(p + "proj2_bn/gamma", {c2});
   c.p2_be = a.add(p + "proj2_bn/beta", {c2});
-  c.has_adapt = (c2 != kCb);
   for (int l = 0; l < 4; ++l) {
     const std::string hp = p + "highway_" + std::to_string(l) + "/";
-    if (l == 0 && c.has_adapt) add_dense(a, hp + "adapt", c2, kCb, true, c.adapt);
+    c.has_adapt[l] = spk || (l == 0 && c2 != kCb);
+    if (spk) {
+      add_dense(a, hp + "spk", 16, kCb, true, c.spkd[l]);
+      add_dense(a, hp + "adapt", 2 * kCb, kCb, true, c.adapt[l]);
+    } else if (c.has_adapt[l]) {
+      add_dense(a, hp + "adapt", c2, kCb, true, c.adapt[l]);
+    }
     add_dense(a, hp + "T", kCb, kCb, true, c.hwT[l]);
     add_dense(a, hp + "H", kCb, kCb, true, c.hwH[l]);
   }
+  if (spk) add_dense(a, p + "gru_init", 16, kCb, true, c.gru_init);
   add_gru(a, p + "bigru/fw", kCb, kCb, c.fw);
   add_gru(a, p + "bigru/bw", kCb, kCb, c.bw);
 }
@@ -99,10 +107,12 @@ void build_param_layout(const TacoShape& s, ParamLayout& L) {
   L.rows.clear();
   Adder a{&L.rows};
   const int R80 = kMel * s.r;
+  const bool multi = s.S > 1;
   L.emb = a.add("embedding", {s.V, kEmbed});
+  L.spk_embed = multi ? a.add("speaker_embed", {s.S, 16}) : -1;
   add_dense(a, "encoder/pre_net/dense", kEmbed, kPre1, true, L.enc_pre1);
   add_dense(a, "encoder/pre_net/dense_1", kPre1, kPre2, true, L.enc_pre2);
-  add_cbhg(a, "encoder/cbhg/", 16, kPre2, kCb, kCb, L.enc);
+  add_cbhg(a, "encoder/cbhg/", 16, kPre2, kCb, kCb, multi, L.enc);
   L.mem_w = a.add("decoder/memory_layer/kernel", {2 * kCb, kAtt});
   add_dense(a, "decoder/pre_net/dense", kMel, kPre1, true, L.dec_pre1);
   add_dense(a, "decoder/pre_net/dense_1", kPre1, kPre2, true, L.dec_pre2);
@@ -112,7 +122,7 @@ void build_param_layout(const TacoShape& s, ParamLayout& L) {
   L.q_w = a.add("decoder/query_layer/kernel", {R80, kAtt});
   L.att_v = a.add("decoder/attention_v", {kAtt});
   L.att_w = a.add("decoder/attention_layer/kernel", {R80 + kAtt, kAtt});
-  add_cbhg(a, "post/cbhg/", 8, kMel, 256, kMel, L.post);
+  add_cbhg(a, "post/cbhg/", 8, kMel, 256, kMel, false, L.post);
   add_dense(a, "post/dense", 2 * kCb, kFft, true, L.post_dense);
   L.total = a.off;
 }
@@ -121,7 +131,12 @@ static void trans_cbhg(Adder& a, const CbhgP& c, CbhgT& t) {
   for (int k = 1; k <= c.K; ++k) t.bank[k - 1] = a.add("", {k, kCb, c.cin});
   t.p1 = a.add("", {3, c.c1, c.K * kCb});
   t.p2 = a.add("", {3, c.c2, c.c1});
-  t.adapt = c.has_adapt ? a.add("", {kCb, c.c2}) : -1;
+  for (int l = 0; l < 4; ++l) {
+    t.adapt[l] = c.has_adapt[l] ? a.add("", {kCb, c.spk ? kCb : c.c2}) : -1;
+    t.adapt_s[l] = c.spk ? a.add("", {kCb, kCb}) : -1;
+    t.spkd[l] = c.spk ? a.add("", {kCb, 16}) : -1;
+  }
+  t.gru_init = c.spk ? a.add("", {kCb, 16}) : -1;
   for (int l = 0; l < 4; ++l) t.hw[l] = a.add("", {2 * kCb, kCb});
   t.gru_x = a.add("", {6 * kCb, kCb});
   for (int d = 0; d < 2; ++d) {
@@ -153,7 +168,7 @@ void build_trans_layout(const TacoShape& s, const ParamLayout& P, TransLayout& T
   T.total = a.off;
 }
 
-static void ws_cbhg(Adder& a, const std::string& p, const CbhgP& c, int64_t M, bool train, CbhgWs& w) {
+static void ws_cbhg(Adder& a, const std::string& p, const CbhgP& c, int64_t M, int64_t B, bool train, CbhgWs& w) {
   (void)train;
   w.bank = a.add(p + "bank", {M, c.K * kCb});
   w.pool = a.add(p + "pool", {M, c.K * kCb});
@@ -161,9 +176,9 @@ static void ws_cbhg(Adder& a, const std::string& p, const CbhgP& c, int64_t M, b
   w.pj1 = a.add(p + "pj1", {M, c.c1});
   w.pj2pre = a.add(p + "pj2pre", {M, c.c2});
   w.res = a.add(p + "res", {M, c.c2});
-  w.adapt = c.has_adapt ? a.add(p + "adapt", {M, kCb}) : -1;
-  w.h[0] = c.has_adapt ? w.adapt : w.res;
+  w.h[0] = w.res;   // h[l] = input of highway layer l (before the optional adapter); hx[l] = after it
   for (int l = 1; l <= 4; ++l) w.h[l] = a.add(p + "h" + std::to_string(l), {M, kCb});
+  for (int l = 0; l < 4; ++l) w.hx[l] = c.has_adapt[l] ? a.add(p + "hx" + std::to_string(l), {M, kCb}) : w.h[l];
   for (int l = 0; l < 4; ++l) w.th[l] = a.add(p + "th" + std::to_string(l), {M, 2 * kCb});
   w.xg = a.add(p + "xg", {M, 6 * kCb});
   w.out = a.add(p + "out", {M, 2 * kCb});
@@ -171,6 +186,14 @@ static void ws_cbhg(Adder& a, const std::string& p, const CbhgP& c, int64_t M, b
   w.s_bank = a.add(p + "s_bank", {c.K * kCb});
   w.s_p1 = a.add(p + "s_p1", {c.c1});
   w.s_p2 = a.add(p + "s_p2", {c.c2});
+  for (int l = 0; l < 4; ++l) {
+    w.sv[l] = c.spk ? a.add(p + "sv" + std::to_string(l), {B, kCb}) : -1;
+    w.rowb[l] = c.spk ? a.add(p + "rowb" + std::to_string(l), {B, kCb}) : -1;
+  }
+  w.h0 = c.spk ? a.add(p + "h0", {B, kCb}) : -1;
+  w.dh0 = c.spk ? a.add(p + "dh0", {2, B, kCb}) : -1;
+  w.dsmall = c.spk ? a.add(p + "dsmall", {B, kCb}) : -1;
+  w.dsmall2 = c.spk ? a.add(p + "dsmall2", {B, kCb}) : -1;
 }
 
 void build_ws_layout(const TacoShape& s, bool train, const TransLayout& T, WsLayout& W) {
@@ -184,14 +207,16 @@ void build_ws_layout(const TacoShape& s, bool train, const TransLayout& T, WsLay
   W.emb = a.add("enc.emb", {M1, kEmbed});
   W.p1 = a.add("enc.p1", {M1, kPre1});
   W.p2 = a.add("enc.p2", {M1, kPre2});
-  ws_cbhg(a, "enc.", P.enc, M1, train, W.enc);
+  W.spk_e = s.S > 1 ? a.add("enc.spk_e", {s.B, 16}) : -1;
+  W.dspk_e = s.S > 1 ? a.add("enc.dspk_e", {s.B, 16}) : -1;
+  ws_cbhg(a, "enc.", P.enc, M1, s.B, train, W.enc);
   W.values = a.add("dec.values", {M1, kAtt});
   W.keys = a.add("dec.keys", {M1, kAtt});
   W.stash = train ? a.add("dec.stash", {MD, kStRec}) : -1;
   W.prein = train ? a.add("dec.prein", {MD, kMel}) : -1;
   W.xchg = a.add("dec.xchg", {decoder_xchg_bytes(s.B, s.Tt) / 4});
   W.err = a.add("dec.err", {512});   // [0],[1] error words; floats 16.. = optional phase trace
-  ws_cbhg(a, "post.", P.post, M2, train, W.post);
+  ws_cbhg(a, "post.", P.post, M2, s.B, train, W.post);
   W.wd_pad = a.add("post.wd_pad", {2 * kCb, 1028});   // post/dense kernel re-pitched to a 16-byte-aligned leading dimension
   W.loss = a.add("loss", {4});
   if (train) {

@@ -22,9 +22,9 @@ struct Layouts {
 
 const Layouts& layouts_for(const TacoShape& s) {
   static std::mutex mu;
-  static std::map<std::tuple<int, int, int, int, int>, Layouts*> cache;
+  static std::map<std::tuple<int, int, int, int, int, int>, Layouts*> cache;
   std::lock_guard<std::mutex> g(mu);
-  auto key = std::make_tuple(s.B, s.Tt, s.Td, s.r, s.V);
+  auto key = std::make_tuple(s.B, s.Tt, s.Td, s.r, s.V, s.S > 1 ? s.S : 1);
   auto it = cache.find(key);
   if (it != cache.end()) return *it->second;
   Layouts* L = new Layouts();
@@ -68,13 +68,27 @@ void prof_end(int which, int slot, hipStream_t s) {
 }
 
 struct CbhgBufs {
-  float *bank, *pool, *pj1pre, *pj1, *pj2pre, *res, *adapt, *h[5], *th[4], *xg, *out, *ruc, *s_bank, *s_p1, *s_p2;
+  float *bank, *pool, *pj1pre, *pj1, *pj2pre, *res, *h[5], *hx[4], *th[4], *xg, *out, *ruc, *s_bank, *s_p1, *s_p2;
+  float *sv[4], *rowb[4], *h0, *dh0, *dsmall, *dsmall2;   // speaker sites (null without speakers)
+  const float* spk_e;   // (B,16) gathered speaker embeddings
+  float* dspk_e;        // (B,16) their gradient (accumulated)
 };
 CbhgBufs cbhg_bufs(float* ws, const CbhgWs& w) {
   CbhgBufs b;
   b.bank = ws + w.bank; b.pool = ws + w.pool; b.pj1pre = ws + w.pj1pre; b.pj1 = ws + w.pj1; b.pj2pre = ws + w.pj2pre;
-  b.res = ws + w.res; b.adapt = w.adapt >= 0 ? ws + w.adapt : nullptr;
+  b.res = ws + w.res;
   for (int l = 0; l < 5; ++l) b.h[l] = ws + w.h[l];
+  for (int l = 0; l < 4; ++l) {
+    b.hx[l] = ws + w.hx[l];
+    b.sv[l] = w.sv[l] >= 0 ? ws + w.sv[l] : nullptr;
+    b.rowb[l] = w.rowb[l] >= 0 ? ws + w.rowb[l] : nullptr;
+  }
+  b.h0 = w.h0 >= 0 ? ws + w.h0 : nullptr;
+  b.dh0 = w.dh0 >= 0 ? ws + w.dh0 : nullptr;
+  b.dsmall = w.dsmall >= 0 ? ws + w.dsmall : nullptr;
+  b.dsmall2 = w.dsmall2 >= 0 ? ws + w.dsmall2 : nullptr;
+  b.spk_e = nullptr;
+  b.dspk_e = nullptr;
   for (int l = 0; l < 4; ++l) b.th[l] = ws + w.th[l];
   b.xg = ws + w.xg; b.out = ws + w.out; b.ruc = ws + w.ruc;
   b.s_bank = ws + w.s_bank; b.s_p1 = ws + w.s_p1; b.s_p2 = ws + w.s_p2;
@@ -132,18 +146,34 @@ int cbhg_fwd(const float* P, const CbhgP& c, const float* x, int B, int T, const
     p.taps = 3; p.T = T; p.pad_l = 1; p.act = TACO_ACT_NONE;
     TACO_TRY(launch_conv_gemm(p, s));
   }
-  // highway x4 (ops.py:27-46, 97-107)
-  if (c.has_adapt)
-    TACO_TRY(launch_conv_gemm(dense_problem(w.res, c.c2, P + c.adapt.w, kCb, P + c.adapt.b, w.adapt, kCb, M, kCb, c.c2,
-                                            TACO_ACT_NONE), s));
+  // highway x4 (ops.py:27-46, 97-107) with the optional input adapter and the per-layer speaker site (ops.py:101-105):
+  // concat([h, tile(s)]) . Wa + ba  ==  h . Wa[:128] + (s . Wa[128:] + ba), i.e. a per-sequence bias -- no (B,T,256) concat.
   for (int l = 0; l < 4; ++l) {
+    if (c.has_adapt[l]) {
+      if (c.spk) {
+        TACO_TRY(launch_conv_gemm(dense_problem(w.spk_e, 16, P + c.spkd[l].w, kCb, P + c.spkd[l].b, w.sv[l], kCb, B, kCb, 16,
+                                                TACO_ACT_RELU), s));
+        TACO_TRY(launch_conv_gemm(dense_problem(w.sv[l], kCb, P + c.adapt[l].w + (int64_t)kCb * kCb, kCb, P + c.adapt[l].b,
+                                                w.rowb[l], kCb, B, kCb, kCb, TACO_ACT_NONE), s));
+        ConvGemmProblem p = dense_problem(w.h[l], kCb, P + c.adapt[l].w, kCb, w.rowb[l], w.hx[l], kCb, M, kCb, kCb, TACO_ACT_NONE);
+        p.T = T;
+        p.bias_stride = kCb;
+        TACO_TRY(launch_conv_gemm(p, s));
+      } else {
+        TACO_TRY(launch_conv_gemm(dense_problem(w.h[l], c.c2, P + c.adapt[l].w, kCb, P + c.adapt[l].b, w.hx[l], kCb, M, kCb,
+                                                c.c2, TACO_ACT_NONE), s));
+      }
+    }
     ConvGemmBatch batch;
     batch.n = 2;
-    batch.p[0] = dense_problem(w.h[l], kCb, P + c.hwT[l].w, kCb, P + c.hwT[l].b, w.th[l], 2 * kCb, M, kCb, kCb, TACO_ACT_SIGMOID);
-    batch.p[1] = dense_problem(w.h[l], kCb, P + c.hwH[l].w, kCb, P + c.hwH[l].b, w.th[l] + kCb, 2 * kCb, M, kCb, kCb, TACO_ACT_RELU);
+    batch.p[0] = dense_problem(w.hx[l], kCb, P + c.hwT[l].w, kCb, P + c.hwT[l].b, w.th[l], 2 * kCb, M, kCb, kCb, TACO_ACT_SIGMOID);
+    batch.p[1] = dense_problem(w.hx[l], kCb, P + c.hwH[l].w, kCb, P + c.hwH[l].b, w.th[l] + kCb, 2 * kCb, M, kCb, kCb, TACO_ACT_RELU);
     TACO_TRY(launch_conv_gemm_batch(batch, s));
-    TACO_TRY(launch_highway_combine(w.th[l], w.h[l], w.h[l + 1], M, s));
+    TACO_TRY(launch_highway_combine(w.th[l], w.hx[l], w.h[l + 1], M, s));
   }
+  if (c.spk)   // bi-GRU initial state of both directions (ops.py:111-124)
+    TACO_TRY(launch_conv_gemm(dense_problem(w.spk_e, 16, P + c.gru_init.w, kCb, P + c.gru_init.b, w.h0, kCb, B, kCb, 16,
+                                            TACO_ACT_RELU), s));
   // bi-GRU: hoisted x-side projections (4 problems) + persistent recurrence (ops.py:117-128)
   {
     ConvGemmBatch batch;
@@ -157,7 +187,7 @@ int cbhg_fwd(const float* P, const CbhgP& c, const float* x, int B, int T, const
     }
     TACO_TRY(launch_conv_gemm_batch(batch, s));
   }
-  TACO_TRY(launch_bigru_fwd(w.xg, bigru_weights(P, c), w.out, keep_ruc ? w.ruc : nullptr, B, T, s));
+  TACO_TRY(launch_bigru_fwd(w.xg, bigru_weights(P, c), c.spk ? w.h0 : nullptr, w.out, keep_ruc ? w.ruc : nullptr, B, T, s));
   return TACO_OK;
 }
 
@@ -175,7 +205,7 @@ DecWeights dec_weights(const float* P, const ParamLayout& L) {
 
 // encoder + attention memory + decoder + post-net; shared by train and inference forward.
 int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const float* P, const int32_t* text,
-                 const int32_t* text_length, const float* mel, const uint8_t* ek1, const uint8_t* ek2, const uint8_t* dk1,
+                 const int32_t* text_length, const int32_t* speaker, const float* mel, const uint8_t* ek1, const uint8_t* ek2, const uint8_t* dk1,
                  const uint8_t* dk2, const uint8_t* sample, float* s2s, float* output, float* align, float* ws, bool train,
                  hipStream_t s) {
   const ParamLayout& PL = L.P;
@@ -194,6 +224,11 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
     TACO_TRY(launch_conv_gemm(q, s));
   }
   CbhgBufs eb = cbhg_bufs(ws, W.enc);
+  if (PL.enc.spk) {   // speaker embedding lookup (tacotron.py:117-124)
+    TACO_REQUIRE(speaker != nullptr, "num_speakers=%d but no speaker ids were given", sh.S);
+    TACO_TRY(launch_embedding(P + PL.spk_embed, speaker, ws + W.spk_e, B, sh.S, s, 16));
+    eb.spk_e = ws + W.spk_e;
+  }
   TACO_TRY(cbhg_fwd(P, PL.enc, ws + W.p2, B, Tt, eb, train, s));
   // attention memory (BahdanauAttention.__init__; tacotron.py:48-52)
   TACO_TRY(launch_mask_rows(eb.out, text_length, ws + W.values, B, Tt, kAtt, s));
@@ -273,7 +308,17 @@ int prepare_transposes(const float* P, const ParamLayout& L, const TransLayout& 
     for (int k = 1; k <= c.K; ++k) TACO_TRY(tr(c.bank_w[k - 1], t.bank[k - 1], k, c.cin, kCb));
     TACO_TRY(tr(c.p1_w, t.p1, 3, c.K * kCb, c.c1));
     TACO_TRY(tr(c.p2_w, t.p2, 3, c.c1, c.c2));
-    if (c.has_adapt) TACO_TRY(tr(c.adapt.w, t.adapt, 1, c.c2, kCb));
+    for (int l = 0; l < 4; ++l) {
+      if (!c.has_adapt[l]) continue;
+      if (c.spk) {
+        TACO_TRY(tr(c.adapt[l].w, t.adapt[l], 1, kCb, kCb));
+        TACO_TRY(tr(c.adapt[l].w + (int64_t)kCb * kCb, t.adapt_s[l], 1, kCb, kCb));
+        TACO_TRY(tr(c.spkd[l].w, t.spkd[l], 1, 16, kCb));
+      } else {
+        TACO_TRY(tr(c.adapt[l].w, t.adapt[l], 1, c.c2, kCb));
+      }
+    }
+    if (c.spk) TACO_TRY(tr(c.gru_init.w, t.gru_init, 1, 16, kCb));
     for (int l = 0; l < 4; ++l) {
       TACO_TRY(tr(c.hwT[l].w, t.hw[l], 1, kCb, kCb));
       TACO_TRY(tr(c.hwH[l].w, t.hw[l] + kCb * kCb, 1, kCb, kCb));
@@ -325,7 +370,7 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
     bw.wghT[d] = PT + t.wghT[d];
     bw.wchT[d] = PT + t.wchT[d];
   }
-  TACO_TRY(launch_bigru_bwd(dOut, w.out, w.ruc, bw, dxg, rh, B, T, s));
+  TACO_TRY(launch_bigru_bwd(dOut, w.out, w.ruc, bw, c.spk ? w.h0 : nullptr, dxg, rh, c.spk ? w.dh0 : nullptr, B, T, s));
   const GruP* g[2] = {&c.fw, &c.bw};
   for (int d = 0; d < 2; ++d) {
     const float* dG = dxg + d * 3 * kCb;
@@ -335,30 +380,64 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
                 d == 0 ? 1 : -1, s));
     TACO_TRY(tn(w.h[4], kCb, kCb, dC, 6 * kCb, kCb, G + g[d]->wc, kCb, M, T, 0, s, 1, G + g[d]->bc));
     TACO_TRY(tn(rh + d * kCb, 2 * kCb, kCb, dC, 6 * kCb, kCb, G + g[d]->wc + (int64_t)kCb * kCb, kCb, M, T, 0, s));
+    if (c.spk) {
+      // non-zero initial state: the first step of each direction sees h_prev = h0 (the shifted-row GEMM above treats it as 0)
+      const float* dG0 = dG + (int64_t)(d == 0 ? 0 : T - 1) * 6 * kCb;   // row t_first of every sequence, stride T*768
+      TACO_TRY(tn(w.h0, kCb, kCb, dG0, T * 6 * kCb, 2 * kCb, G + g[d]->wg + (int64_t)kCb * 2 * kCb, 2 * kCb, B, B, 0, s));
+    }
+  }
+  // small-tensor helper for the speaker sites: dz (B,128) -> dW (16,128), db, dspk_e (B,16) += dz . W^T
+  auto spk_dense_bwd = [&](const float* dz, const DenseP& dp, int64_t wT) -> int {
+    TACO_TRY(tn(w.spk_e, 16, 16, dz, kCb, kCb, G + dp.w, kCb, B, B, 0, s, 1, G + dp.b));
+    ConvGemmProblem p = dense_problem(dz, kCb, PT + wT, 16, nullptr, w.dspk_e, 16, B, 16, kCb, TACO_ACT_NONE);
+    p.residual = w.dspk_e;
+    p.ldr = 16;
+    return launch_conv_gemm(p, s);
+  };
+  if (c.spk) {
+    hipError_t e = hipMemsetAsync(w.dspk_e, 0, (size_t)B * 16 * sizeof(float), s);
+    if (e != hipSuccess) {
+      taco_set_error("cbhg_bwd: memset: %s", hipGetErrorString(e));
+      return TACO_ELAUNCH;
+    }
+    // h0 = relu(dense(spk)) feeds both directions: d h0 = dh0[fw] + dh0[bw]
+    TACO_TRY(launch_add(w.dh0, w.dh0 + (int64_t)B * kCb, w.dsmall, (int64_t)B * kCb, s));
+    TACO_TRY(launch_act_bwd(w.h0, w.dsmall, nullptr, w.dsmall, (int64_t)B * kCb, TACO_ACT_RELU, s));
+    TACO_TRY(spk_dense_bwd(w.dsmall, c.gru_init, t.gru_init));
   }
   float* gh = sc.gE;     // (M,128) gradient wrt current highway output
   float* gh2 = sc.gF;    // ping-pong
   TACO_TRY(launch_conv_gemm(dense_problem(dxg, 6 * kCb, PT + t.gru_x, kCb, nullptr, gh, kCb, M, kCb, 6 * kCb, TACO_ACT_NONE), s));
-  // ---- highway layers 3..0 ----
+  // ---- highway layers 3..0 (with their input adapters / speaker sites) ----
   float* dth = sc.gD;    // (M,256) (rh no longer needed)
   float* dxd = sc.gG;    // (M,128)
   for (int l = 3; l >= 0; --l) {
-    TACO_TRY(launch_highway_combine_bwd(w.th[l], w.h[l], gh, dth, dxd, M, s));
-    TACO_TRY(tn(w.h[l], kCb, kCb, dth, 2 * kCb, kCb, G + c.hwT[l].w, kCb, M, M, 0, s, 1, G + c.hwT[l].b));
-    TACO_TRY(tn(w.h[l], kCb, kCb, dth + kCb, 2 * kCb, kCb, G + c.hwH[l].w, kCb, M, M, 0, s, 1, G + c.hwH[l].b));
+    TACO_TRY(launch_highway_combine_bwd(w.th[l], w.hx[l], gh, dth, dxd, M, s));
+    TACO_TRY(tn(w.hx[l], kCb, kCb, dth, 2 * kCb, kCb, G + c.hwT[l].w, kCb, M, M, 0, s, 1, G + c.hwT[l].b));
+    TACO_TRY(tn(w.hx[l], kCb, kCb, dth + kCb, 2 * kCb, kCb, G + c.hwH[l].w, kCb, M, M, 0, s, 1, G + c.hwH[l].b));
     ConvGemmProblem p = dense_problem(dth, 2 * kCb, PT + t.hw[l], kCb, nullptr, gh2, kCb, M, kCb, 2 * kCb, TACO_ACT_NONE);
     p.residual = dxd;
     p.ldr = kCb;
-    TACO_TRY(launch_conv_gemm(p, s));
-    float* tmp = gh; gh = gh2; gh2 = tmp;
+    TACO_TRY(launch_conv_gemm(p, s));        // gh2 = d hx[l]
+    if (!c.has_adapt[l]) {
+      float* tmp = gh; gh = gh2; gh2 = tmp;  // hx[l] == h[l]
+      continue;
+    }
+    const int cin_h = c.spk ? kCb : c.c2;
+    // adapter weight (rows of h) + bias, and d h[l] = d hx[l] . Wa[:cin_h]^T  -> gh (old gh is dead)
+    TACO_TRY(tn(w.h[l], cin_h, cin_h, gh2, kCb, kCb, G + c.adapt[l].w, kCb, M, M, 0, s, 1, G + c.adapt[l].b));
+    TACO_TRY(launch_conv_gemm(dense_problem(gh2, kCb, PT + t.adapt[l], cin_h, nullptr, gh, cin_h, M, cin_h, kCb, TACO_ACT_NONE), s));
+    if (c.spk) {
+      // per-sequence bias path: d rowb[b] = sum_t d hx[l][b,t]; rowb = sv . Wa[128:] + ba; sv = relu(dense(spk))
+      TACO_TRY(launch_colsum_batched(gh2, kCb, w.dsmall, B, T, kCb, s));
+      TACO_TRY(tn(w.sv[l], kCb, kCb, w.dsmall, kCb, kCb, G + c.adapt[l].w + (int64_t)kCb * kCb, kCb, B, B, 0, s));
+      TACO_TRY(launch_conv_gemm(dense_problem(w.dsmall, kCb, PT + t.adapt_s[l], kCb, nullptr, w.dsmall2, kCb, B, kCb, kCb,
+                                              TACO_ACT_NONE), s));
+      TACO_TRY(launch_act_bwd(w.sv[l], w.dsmall2, nullptr, w.dsmall2, (int64_t)B * kCb, TACO_ACT_RELU, s));
+      TACO_TRY(spk_dense_bwd(w.dsmall2, c.spkd[l], t.spkd[l]));
+    }
   }
-  // ---- adapt dense (post-net only) ----
   float* dres = gh;      // (M, c2) gradient wrt `res`
-  if (c.has_adapt) {
-    TACO_TRY(tn(w.res, c.c2, c.c2, gh, kCb, kCb, G + c.adapt.w, kCb, M, M, 0, s, 1, G + c.adapt.b));
-    TACO_TRY(launch_conv_gemm(dense_problem(gh, kCb, PT + t.adapt, c.c2, nullptr, gh2, c.c2, M, c.c2, kCb, TACO_ACT_NONE), s));
-    dres = gh2;
-  }
   // ---- res = bn(conv(pj1)) + x ----
   float* dz2 = sc.gG;    // (M,c2)
   TACO_TRY(launch_affine_act_bwd(w.pj2pre, P + c.p2_g, dres, dz2, G + c.p2_g, G + c.p2_be, M, c.c2, TACO_ACT_NONE, s));
@@ -445,7 +524,7 @@ extern "C" int taco_workspace_table(const TacoShape* shape, int train, TacoTenso
 }
 
 extern "C" int taco_forward(const TacoShape* shape, const float* params, const int32_t* text, const int32_t* text_length,
-                            const float* mel, const float* stft, const uint8_t* enc_keep1, const uint8_t* enc_keep2,
+                            const int32_t* speaker, const float* mel, const float* stft, const uint8_t* enc_keep1, const uint8_t* enc_keep2,
                             const uint8_t* dec_keep1, const uint8_t* dec_keep2, const uint8_t* sample,
                             float* seq2seq_output, float* output, float* alignments, float* loss, void* workspace,
                             void* stream) {
@@ -456,7 +535,7 @@ extern "C" int taco_forward(const TacoShape* shape, const float* params, const i
   const WsLayout& W = L.Wtrain;
   float* ws = static_cast<float*>(workspace);
   hipStream_t s = as_stream(stream);
-  TACO_TRY(forward_impl(*shape, L, W, params, text, text_length, mel, enc_keep1, enc_keep2, dec_keep1, dec_keep2, sample,
+  TACO_TRY(forward_impl(*shape, L, W, params, text, text_length, speaker, mel, enc_keep1, enc_keep2, dec_keep1, dec_keep2, sample,
                         seq2seq_output, output, alignments, ws, true, s));
   // add_loss_op (tacotron.py:156-165) + sign gradients for the backward pass
   const int R80 = kMel * shape->r;
@@ -478,18 +557,18 @@ extern "C" int taco_forward(const TacoShape* shape, const float* params, const i
 }
 
 extern "C" int taco_infer(const TacoShape* shape, const float* params, const int32_t* text, const int32_t* text_length,
-                          float* seq2seq_output, float* output, float* alignments, void* workspace, void* stream) {
+                          const int32_t* speaker, float* seq2seq_output, float* output, float* alignments, void* workspace, void* stream) {
   TACO_TRY(validate_shape(shape));
   TACO_REQUIRE(params && text && text_length && seq2seq_output && output && alignments && workspace,
                "taco_infer: null pointer argument");
   const Layouts& L = layouts_for(*shape);
-  return forward_impl(*shape, L, L.Winfer, params, text, text_length, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+  return forward_impl(*shape, L, L.Winfer, params, text, text_length, speaker, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                       seq2seq_output, output, alignments, static_cast<float*>(workspace), false, as_stream(stream));
 }
 
 
 extern "C" int taco_backward(const TacoShape* shape, const float* params, const int32_t* text, const int32_t* text_length,
-                             const float* seq2seq_output, const float* alignments, const uint8_t* enc_keep1,
+                             const int32_t* speaker, const float* seq2seq_output, const float* alignments, const uint8_t* enc_keep1,
                              const uint8_t* enc_keep2, const uint8_t* dec_keep1, const uint8_t* dec_keep2,
                              const uint8_t* sample, float* grads, void* workspace, void* stream) {
   TACO_TRY(validate_shape(shape));
@@ -598,7 +677,13 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
   TACO_TRY(launch_mask_rows(dValTot, text_length, dEnc, B, Tt, 2 * kCb, s));
   // ---- encoder CBHG ----
   float* dP2 = sc.gC;       // (M1,128)
+  if (PL.enc.spk) {
+    TACO_REQUIRE(speaker != nullptr, "num_speakers=%d but no speaker ids were given", shape->S);
+    eb.spk_e = ws + W.spk_e;
+    eb.dspk_e = ws + W.dspk_e;
+  }
   TACO_TRY(cbhg_bwd(P, PT, G, PL.enc, TL.enc, ws + W.p2, dEnc, B, Tt, eb, sc, dP2, s));
+  if (PL.enc.spk) TACO_TRY(launch_embedding_bwd(ws + W.dspk_e, speaker, G + PL.spk_embed, B, shape->S, s, 16));
   // ---- encoder pre_net + embedding ----
   float* dz2 = sc.gD;
   TACO_TRY(launch_act_bwd(ws + W.p2, dP2, enc_keep2, dz2, (int64_t)M1 * kPre2, TACO_ACT_RELU, s));
@@ -659,7 +744,7 @@ extern "C" int taco_bigru_fwd(const float* x, const float* wg_fw, const float* b
     batch.p[2 * d + 1] = dense_problem(x, kCb, w.wc[d], kCb, w.bc[d], xg + d * 3 * kCb + 2 * kCb, 6 * kCb, M, kCb, kCb, TACO_ACT_NONE);
   }
   TACO_TRY(launch_conv_gemm_batch(batch, s));
-  return launch_bigru_fwd(xg, w, out, ruc, B, T, s);
+  return launch_bigru_fwd(xg, w, nullptr, out, ruc, B, T, s);
 }
 
 extern "C" int taco_clip_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float cap,

@@ -8,7 +8,7 @@ import torch
 from .config import MAX_TEXT_LEN
 
 
-def synthetic_batch(B=32, Tt=200, Td=180, r=2, V=60, seed=1234, rank=0, min_len=50):
+def synthetic_batch(B=32, Tt=200, Td=180, r=2, V=60, seed=1234, rank=0, min_len=50, num_speakers=1):
     """text_length ~ U{min_len..Tt} with row 0 forced to Tt; ids ~ U{1..V-1} inside the length, 0 (pad)
     outside; mel/stft ~ N(0,1) (the reference standardises per feature, data_input.py:55-65); speech_length = Td."""
     rng = np.random.default_rng(seed + rank)
@@ -19,11 +19,14 @@ def synthetic_batch(B=32, Tt=200, Td=180, r=2, V=60, seed=1234, rank=0, min_len=
     text[np.arange(Tt)[None, :] >= tl[:, None]] = 0
     mel = rng.standard_normal((B, Td, 80 * r), dtype=np.float32)
     stft = rng.standard_normal((B, Td, 1025 * r), dtype=np.float32)
-    return {
+    out = {
         'text': torch.from_numpy(text), 'text_length': torch.from_numpy(tl),
         'mel': torch.from_numpy(mel), 'stft': torch.from_numpy(stft),
         'speech_length': torch.full((B,), Td, dtype=torch.int32),
     }
+    if num_speakers > 1:   # VCTK-shaped: speaker ~ U{0..S-1}
+        out['speaker'] = torch.from_numpy(rng.integers(0, num_speakers, size=B).astype(np.int32))
+    return out
 
 
 def pad(text, max_len, pad_val):

@@ -20,10 +20,11 @@ class TacoError(RuntimeError):
 
 
 class TacoShape(C.Structure):
-    _fields_ = [('B', C.c_int32), ('Tt', C.c_int32), ('Td', C.c_int32), ('r', C.c_int32), ('V', C.c_int32)]
+    _fields_ = [('B', C.c_int32), ('Tt', C.c_int32), ('Td', C.c_int32), ('r', C.c_int32), ('V', C.c_int32),
+                ('S', C.c_int32)]
 
     def __repr__(self):
-        return 'TacoShape(B=%d, Tt=%d, Td=%d, r=%d, V=%d)' % (self.B, self.Tt, self.Td, self.r, self.V)
+        return 'TacoShape(B=%d, Tt=%d, Td=%d, r=%d, V=%d, S=%d)' % (self.B, self.Tt, self.Td, self.r, self.V, self.S)
 
 
 class TacoTensorInfo(C.Structure):
@@ -53,9 +54,9 @@ EXPORTS = {
     'taco_gemm_tn': (C.c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'taco_debug_gemm_naive': (C.c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'taco_bigru_fwd': (C.c_int, [_P] * 12 + [_I, _I, _P]),
-    'taco_forward': (C.c_int, [_SH] + [_P] * 16),
-    'taco_backward': (C.c_int, [_SH] + [_P] * 13),
-    'taco_infer': (C.c_int, [_SH] + [_P] * 8),
+    'taco_forward': (C.c_int, [_SH] + [_P] * 17),
+    'taco_backward': (C.c_int, [_SH] + [_P] * 14),
+    'taco_infer': (C.c_int, [_SH] + [_P] * 9),
     'taco_clip_adam_step': (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_int64, _P, _P, _P]),
     'taco_fill_bernoulli': (C.c_int, [_P, C.c_int64, C.c_float, C.c_uint64, _P]),
     'taco_profile_enable': (C.c_int, [_I]),
@@ -88,8 +89,9 @@ def stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def make_shape(B, Tt, Td, r, V) -> TacoShape:
-    return TacoShape(int(B), int(Tt), int(Td), int(r), int(V))
+def make_shape(B, Tt, Td, r, V, S=1) -> TacoShape:
+    """S = num_speakers (<= 1: single-speaker model, no speaker path)."""
+    return TacoShape(int(B), int(Tt), int(Td), int(r), int(V), int(S))
 
 
 def version() -> int:
@@ -157,24 +159,24 @@ def bigru_fwd(x, w, xg, out, ruc, B, T):
                                ptr(xg), ptr(out), ptr(ruc), B, T, stream_ptr()), 'taco_bigru_fwd')
 
 
-def forward(shape, params, text, text_length, mel, stft, masks, s2s, out, align, loss, workspace):
+def forward(shape, params, text, text_length, mel, stft, masks, s2s, out, align, loss, workspace, speaker=None):
     m = masks or {}
-    _check(_lib.taco_forward(C.byref(shape), ptr(params), ptr(text), ptr(text_length), ptr(mel), ptr(stft),
+    _check(_lib.taco_forward(C.byref(shape), ptr(params), ptr(text), ptr(text_length), ptr(speaker), ptr(mel), ptr(stft),
                              ptr(m.get('enc_keep1')), ptr(m.get('enc_keep2')), ptr(m.get('dec_keep1')),
                              ptr(m.get('dec_keep2')), ptr(m.get('sample')), ptr(s2s), ptr(out), ptr(align), ptr(loss),
                              ptr(workspace), stream_ptr()), 'taco_forward')
 
 
-def backward(shape, params, text, text_length, s2s, align, masks, grads, workspace):
+def backward(shape, params, text, text_length, s2s, align, masks, grads, workspace, speaker=None):
     m = masks or {}
-    _check(_lib.taco_backward(C.byref(shape), ptr(params), ptr(text), ptr(text_length), ptr(s2s), ptr(align),
+    _check(_lib.taco_backward(C.byref(shape), ptr(params), ptr(text), ptr(text_length), ptr(speaker), ptr(s2s), ptr(align),
                               ptr(m.get('enc_keep1')), ptr(m.get('enc_keep2')), ptr(m.get('dec_keep1')),
                               ptr(m.get('dec_keep2')), ptr(m.get('sample')), ptr(grads), ptr(workspace), stream_ptr()),
            'taco_backward')
 
 
-def infer(shape, params, text, text_length, s2s, out, align, workspace):
-    _check(_lib.taco_infer(C.byref(shape), ptr(params), ptr(text), ptr(text_length), ptr(s2s), ptr(out), ptr(align),
+def infer(shape, params, text, text_length, s2s, out, align, workspace, speaker=None):
+    _check(_lib.taco_infer(C.byref(shape), ptr(params), ptr(text), ptr(text_length), ptr(speaker), ptr(s2s), ptr(out), ptr(align),
                            ptr(workspace), stream_ptr()), 'taco_infer')
 
 

@@ -27,7 +27,7 @@ class Tacotron(object):
             Td = inputs['mel'].shape[1]
         else:
             Td = config.max_decode_iter
-        self.shape = lib.make_shape(B, Tt, Td, config.r, config.vocab_size)
+        self.shape = lib.make_shape(B, Tt, Td, config.r, config.vocab_size, config.num_speakers)
         if params is None:
             params = ParamBuffer(self.shape, self.device).init_(seed)
         self.params = params
@@ -63,6 +63,9 @@ class Tacotron(object):
             'text': inputs['text'].to(dev, torch.int32).contiguous(),
             'text_length': inputs['text_length'].to(dev, torch.int32).contiguous(),
         }
+        self.speaker = None
+        if self.config.num_speakers > 1:   # tacotron.py:117-124
+            self.speaker = inputs['speaker'].to(dev, torch.int32).contiguous()
         if self.train:
             self.inputs['mel'] = inputs['mel'].to(dev, torch.float32).contiguous()
             self.inputs['stft'] = inputs['stft'].to(dev, torch.float32).contiguous()
@@ -87,12 +90,12 @@ class Tacotron(object):
         i = self.inputs
         self.masks = masks
         lib.forward(self.shape, self.params.flat, i['text'], i['text_length'], i['mel'], i['stft'], masks,
-                    self.seq2seq_output, self.output, self.alignments, self._loss, self.workspace)
+                    self.seq2seq_output, self.output, self.alignments, self._loss, self.workspace, self.speaker)
 
     def backward(self):
         i = self.inputs
         lib.backward(self.shape, self.params.flat, i['text'], i['text_length'], self.seq2seq_output, self.alignments,
-                     self.masks, self.grads, self.workspace)
+                     self.masks, self.grads, self.workspace, self.speaker)
 
     def apply_gradients(self, lr):
         self.global_step += 1
@@ -123,7 +126,7 @@ class Tacotron(object):
         """`sess.run([model.output, model.alignments])` for train=False (test.py:52-56)."""
         i = self.inputs
         lib.infer(self.shape, self.params.flat, i['text'], i['text_length'], self.seq2seq_output, self.output,
-                  self.alignments, self.workspace)
+                  self.alignments, self.workspace, self.speaker)
         return self.output, self.alignments
 
     # -- checkpoint (train.py:47,85-90: weights + Adam slots + global_step) --------------------------------

@@ -22,10 +22,11 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 class Runner:
     """Thin harness over the C ABI (no tacotron_amd.model involved, so op/host bugs separate cleanly)."""
 
-    def __init__(self, lib, B, Tt, Td, r, V, train=True):
+    def __init__(self, lib, B, Tt, Td, r, V, train=True, S=1):
         from tacotron_amd.params import ParamBuffer
         self.lib, self.train = lib, train
-        self.shape = lib.make_shape(B, Tt, Td, r, V)
+        self.speaker = None
+        self.shape = lib.make_shape(B, Tt, Td, r, V, S)
         self.pb = ParamBuffer(self.shape, 'cuda')
         self.ws = torch.zeros(lib.workspace_bytes(self.shape, train) // 4, device='cuda')
         self.s2s = torch.zeros(B, Td, 80 * r, device='cuda')
@@ -39,6 +40,8 @@ class Runner:
         self.pb.load_dict_(p)
         self.text = torch.as_tensor(inp['text']).to('cuda', torch.int32).contiguous()
         self.tl = torch.as_tensor(inp['text_length']).to('cuda', torch.int32).contiguous()
+        if 'speaker' in inp:
+            self.speaker = torch.as_tensor(inp['speaker']).to('cuda', torch.int32).contiguous()
         if 'mel' in inp:
             self.mel = torch.as_tensor(inp['mel']).to('cuda', torch.float32).contiguous()
             self.stft = torch.as_tensor(inp['stft']).to('cuda', torch.float32).contiguous()
@@ -46,17 +49,18 @@ class Runner:
 
     def forward(self):
         self.lib.forward(self.shape, self.pb.flat, self.text, self.tl, self.mel, self.stft, self.masks, self.s2s, self.out,
-                         self.al, self.loss, self.ws)
+                         self.al, self.loss, self.ws, self.speaker)
         torch.cuda.synchronize()
         self.check_err()
 
     def backward(self):
-        self.lib.backward(self.shape, self.pb.flat, self.text, self.tl, self.s2s, self.al, self.masks, self.grads, self.ws)
+        self.lib.backward(self.shape, self.pb.flat, self.text, self.tl, self.s2s, self.al, self.masks, self.grads, self.ws,
+                          self.speaker)
         torch.cuda.synchronize()
         self.check_err()
 
     def infer(self):
-        self.lib.infer(self.shape, self.pb.flat, self.text, self.tl, self.s2s, self.out, self.al, self.ws)
+        self.lib.infer(self.shape, self.pb.flat, self.text, self.tl, self.s2s, self.out, self.al, self.ws, self.speaker)
         torch.cuda.synchronize()
         self.check_err()
 
@@ -75,11 +79,13 @@ def f64(d):
             for k, v in d.items()}
 
 
-def golden(r):
-    g = np.load(os.path.join(GOLD, 'model_r%d.npz' % r))
-    V = int(g['V'])
-    p = on.init_params(V, r, seed=int(g['seed']), perturb=float(g['perturb']))
+def golden(r, spk=False):
+    g = np.load(os.path.join(GOLD, 'model_r%d%s.npz' % (r, '_spk' if spk else '')))
+    V, S = int(g['V']), int(g['num_speakers'])
+    p = on.init_params(V, r, seed=int(g['seed']), perturb=float(g['perturb']), num_speakers=S)
     inp = {'text': g['text'], 'text_length': g['text_length'], 'mel': g['mel'], 'stft': g['stft']}
+    if S > 1:
+        inp['speaker'] = g['speaker']
     masks = {k[5:]: g[k] for k in g.files if k.startswith('mask_')}
     return g, p, inp, masks
 
@@ -187,6 +193,34 @@ def test_backward_matches_autograd_golden(built_lib, r):
         assert abs(np.linalg.norm(ref[n]) - gn) <= 1e-9 * max(1.0, gn)
     bad = check_grads(R, ref)
     assert not bad, bad
+
+
+def test_multi_speaker_forward_backward_infer(built_lib):
+    """SURVEY §8 a4/a9 / BASELINE config 5: speaker table + encoder CBHG speaker sites, against the committed fixture
+    and torch autograd."""
+    g, p, inp, masks = golden(2, spk=True)
+    B, Tt, Td, V, S = int(g['B']), int(g['Tt']), int(g['Td']), int(g['V']), int(g['num_speakers'])
+    R = Runner(built_lib, B, Tt, Td, 2, V, S=S)
+    R.set(p, inp, masks)
+    R.forward()
+    r1, m1 = report('spk seq2seq_output', R.s2s.cpu().numpy(), g['seq2seq_output'])
+    r2, m2 = report('spk output', R.out.cpu().numpy(), g['output'])
+    r3, m3 = report('spk alignments', R.al.cpu().numpy(), g['alignments'])
+    assert report('spk enc.out', R.wsget('enc.out'), g['encoded'].reshape(B * Tt, -1))[0] < 3e-5
+    assert r1 < 1e-5 and m1 < 5e-5 and r2 < 1e-5 and m2 < 5e-5 and m3 < 1e-6
+    assert abs(R.loss[0].item() - float(g['loss'])) <= 1e-5 * float(g['loss'])
+    R.backward()
+    _, _, _, _, ref = ot.loss_and_grads(p, f64(inp), 2, Td, f64(masks))
+    bad = check_grads(R, ref)
+    assert not bad, bad
+    Ri = Runner(built_lib, B, Tt, Td, 2, V, train=False, S=S)
+    Ri.set(p, {'text': inp['text'], 'text_length': inp['text_length'], 'speaker': inp['speaker']})
+    Ri.infer()
+    assert report('spk infer output', Ri.out.cpu().numpy(), g['infer_output'])[0] < 1e-5
+    # a model built for speakers refuses to run without ids (loud failure, not a silent single-speaker fallback)
+    Ri.speaker = None
+    with pytest.raises(built_lib.TacoError):
+        Ri.infer()
 
 
 def test_backward_without_masks_and_ragged_lengths(built_lib):

@@ -23,11 +23,11 @@ def test_exports_match_header(built_lib):
     assert built_lib.version() == 100
 
 
-@pytest.mark.parametrize('V,r', [(60, 2), (20, 5), (33, 3)])
-def test_param_table_matches_oracle_spec(built_lib, V, r):
-    shape = built_lib.make_shape(4, 10, 6, r, V)
+@pytest.mark.parametrize('V,r,S', [(60, 2, 1), (20, 5, 1), (33, 3, 1), (60, 2, 109), (20, 2, 7)])
+def test_param_table_matches_oracle_spec(built_lib, V, r, S):
+    shape = built_lib.make_shape(4, 10, 6, r, V, S)
     table = built_lib.param_table(shape)
-    spec = on.param_spec(V, r)
+    spec = on.param_spec(V, r, S)
     assert len(table) == len(spec)
     off = 0
     for (name, o, size, dims), (n2, shp, _) in zip(table, spec):
@@ -39,6 +39,8 @@ def test_param_table_matches_oracle_spec(built_lib, V, r):
 
 def test_nancy_param_count(built_lib):
     assert built_lib.param_count(built_lib.make_shape(32, 200, 180, 2, 60)) == 6926609
+    # VCTK config 5: 109 speakers (speaker table + 4 x (spk dense + 256->128 adapter) + GRU-init dense)
+    assert built_lib.param_count(built_lib.make_shape(32, 200, 180, 2, 60, 109)) == 7070817
 
 
 def test_workspace_table(built_lib):

@@ -42,6 +42,21 @@ def test_numpy_and_torch_restatements_agree(r):
     assert np.abs(s2s - t[0].numpy()).max() < 1e-11 and np.abs(out - t[1].numpy()).max() < 1e-11
 
 
+def test_multi_speaker_restatements_agree():
+    """speaker table + encoder-CBHG speaker sites (ops.py:101-127)."""
+    V, r, S = 20, 2, 5
+    p = on.init_params(V, r, seed=1, perturb=0.3, num_speakers=S)
+    inp, masks = small_case(r=r, V=V, Td=4)
+    inp = {k: (v.astype(np.float64) if v.dtype == np.float32 else v) for k, v in inp.items()}
+    inp['speaker'] = np.array([4, 1])
+    s2s, out, al, _ = on.forward(p, inp, r, 4, True, _f64(masks))
+    lt, s2, o2, a2, grads = ot.loss_and_grads(p, inp, r, 4, _f64(masks))
+    assert np.abs(s2s - s2).max() < 1e-11 and np.abs(out - o2).max() < 1e-11 and np.abs(al - a2).max() < 1e-12
+    assert np.linalg.norm(grads['speaker_embed']) > 0 and np.linalg.norm(grads['speaker_embed'][0]) == 0   # only used rows
+    inp2 = dict(inp, speaker=np.array([2, 1]))
+    assert np.abs(on.forward(p, inp2, r, 4, True, _f64(masks))[0] - s2s).max() > 1e-6   # the speaker id matters
+
+
 def test_alignments_are_masked_distributions():
     p = on.init_params(20, 2, seed=2)
     inp, masks = small_case()
@@ -82,14 +97,16 @@ def test_autograd_matches_finite_differences():
         assert abs(fd - an) <= 2e-4 * max(1.0, abs(an)), (name, fd, an)
 
 
-@pytest.mark.parametrize('r', [2, 5])
-def test_golden_fixture_reproduced(r):
-    g = np.load(os.path.join(GOLD, 'model_r%d.npz' % r))
-    V, Td = int(g['V']), int(g['Td'])
-    p = on.init_params(V, r, seed=int(g['seed']), perturb=float(g['perturb']))
-    assert abs(np.abs(on.flatten_params(p, V, r, np.float64)).sum() - float(g['param_checksum'])) < 1e-9
+@pytest.mark.parametrize('name', ['model_r2', 'model_r5', 'model_r2_spk'])
+def test_golden_fixture_reproduced(name):
+    g = np.load(os.path.join(GOLD, name + '.npz'))
+    V, Td, r, S = int(g['V']), int(g['Td']), int(g['r']), int(g['num_speakers'])
+    p = on.init_params(V, r, seed=int(g['seed']), perturb=float(g['perturb']), num_speakers=S)
+    assert abs(np.abs(on.flatten_params(p, V, r, np.float64, S)).sum() - float(g['param_checksum'])) < 1e-9
     inp = {'text': g['text'], 'text_length': g['text_length'], 'mel': g['mel'].astype(np.float64),
            'stft': g['stft'].astype(np.float64)}
+    if S > 1:
+        inp['speaker'] = g['speaker']
     masks = {k[5:]: g[k].astype(np.float64) for k in g.files if k.startswith('mask_')}
     s2s, out, al, enc = on.forward(p, inp, r, Td, True, masks)
     assert np.abs(s2s - g['seq2seq_output']).max() < 1e-12
