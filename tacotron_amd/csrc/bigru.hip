@@ -2,10 +2,12 @@
 // tf.nn.bidirectional_dynamic_rnn(GRUCell(128), GRUCell(128), h) with no sequence_length).
 //
 // The x-side projections of all T steps are hoisted into one MFMA GEMM (gemm.hip); only the h-side recurrence
-// runs here.  One workgroup (256 threads = 4 waves, one per SIMD) owns ONE (direction, batch row) for the whole
+// runs here.  One workgroup (512 threads = 8 waves, two per SIMD) owns ONE (direction, batch row) for the whole
 // sequence: the h-side weights Wg[128:,:] (128x256) and Wc[128:,:] (128x128) -- 48K floats -- live in that
-// workgroup's VGPRs (192 per lane) for all T steps, the 128-float hidden state lives in LDS, and nothing but the
-// per-step x-projection (1.5 KB) and the outputs touch HBM inside the loop.  No inter-workgroup communication.
+// workgroup's VGPRs (96 per lane) for all T steps, the 128-float hidden state lives in LDS, the per-step inputs arrive
+// by direct global->LDS DMA in 8-step chunks, and only the outputs leave the CU inside the loop.  Every reduction is
+// split over the four lanes of a quad and combined with DPP quad_perm swaps (no LDS partials, 2 barriers per step).
+// No inter-workgroup communication.
 //
 // GRUCell r1.2: [r,u] = sigmoid([x,h].Wg + bg); c = tanh([x, r*h].Wc + bc); h' = u*h + (1-u)*c.
 #include "common.h"
@@ -15,182 +17,239 @@ namespace {
 
 constexpr int H = kCb;  // 128
 
-// grid = (B, 2 directions); block = 256
-__global__ __launch_bounds__(256, 1) void bigru_fwd_kernel(const float* __restrict__ xg, BiGruWeights w,
+// Direct global->LDS DMA of 64 consecutive floats (one dword per lane): LDS destination = wave-uniform base + lane*4.
+// No VGPR destination, so nothing for the compiler to wait on; the issuing wave waits with an explicit s_waitcnt vmcnt.
+__device__ __forceinline__ void dma64(const float* gsrc_lane, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// sum over the 4 lanes of a quad (every lane gets the total): two DPP quad_perm swaps, no LDS
+__device__ __forceinline__ float quad_sum(float v) {
+  v += dpp_move<0xb1>(0.f, v);   // quad_perm [1,0,3,2]
+  v += dpp_move<0x4e>(0.f, v);   // quad_perm [2,3,0,1]
+  return v;
+}
+
+constexpr int NTG = 512;      // 8 waves = 2 per SIMD: a lone wave per SIMD only issues ~1 instruction per 4 cycles
+constexpr int CH = 8;         // time steps per DMA chunk
+
+// Forward.  grid = (B, 2 directions); block = 512.
+//  gates    : thread (cp = t>>2, kq = t&3) owns gate columns {cp, cp+128} (= r_cp and u_cp) over k in [32kq, 32kq+32):
+//             64 weights in VGPRs, 8 broadcast ds_read_b128 of h, quad_sum combines the four k-quarters in-register.
+//  candidate: thread (cc = t>>2, kq) owns candidate column cc over the same k-quarter (32 weights); lane kq==0 of each
+//             quad finishes c, h' and issues the stores.  Two workgroup barriers per step.
+//  inputs   : the hoisted x-projections arrive by LDS-DMA in chunks of CH steps, issued by wave 7 one chunk ahead.
+__global__ __launch_bounds__(NTG, 2) void bigru_fwd_kernel(const float* __restrict__ xg, BiGruWeights w,
                                                            const float* __restrict__ h0, float* __restrict__ out,
-                                                           float* __restrict__ ruc, int B, int T) {
-  const int b = blockIdx.x, d = blockIdx.y, j = threadIdx.x;
-  const int col = j & (H - 1), half = j >> 7;
+                                                           float* __restrict__ ruc, int B, int T, long long* trace) {
+  (void)trace;
+  const int b = blockIdx.x, d = blockIdx.y, t_ = threadIdx.x;
+  const int cp = t_ >> 2, kq = t_ & 3, lane = t_ & 63, wv = t_ >> 6;
   __shared__ __attribute__((aligned(16))) float hs[H];
   __shared__ __attribute__((aligned(16))) float rhs[H];
   __shared__ float us[H];
-  __shared__ float cpart[H];
+  __shared__ __attribute__((aligned(16))) float xgs[2][CH][3 * H];
 
-  // h-side weights -> registers
-  float wgh[H];
-  float wch[H / 2];
+  float wr[H / 4], wu[H / 4], wcand[H / 4];   // Wg_h[32kq + k][cp], Wg_h[..][128 + cp], Wc_h[32kq + k][cp]
   {
-    const float* wg = w.wg[d] + (int64_t)H * (2 * H) + j;  // rows 128.., column j
+    const float* wg = w.wg[d] + (int64_t)(H + kq * (H / 4)) * (2 * H) + cp;
+    const float* wc = w.wc[d] + (int64_t)(H + kq * (H / 4)) * H + cp;
 #pragma unroll
-    for (int k = 0; k < H; ++k) wgh[k] = wg[(int64_t)k * (2 * H)];
-    const float* wc = w.wc[d] + (int64_t)(H + half * (H / 2)) * H + col;
-#pragma unroll
-    for (int k = 0; k < H / 2; ++k) wch[k] = wc[(int64_t)k * H];
+    for (int k = 0; k < H / 4; ++k) {
+      wr[k] = wg[(int64_t)k * (2 * H)];
+      wu[k] = wg[(int64_t)k * (2 * H) + H];
+      wcand[k] = wc[(int64_t)k * H];
+    }
   }
-  if (j < H) hs[j] = h0 ? h0[(int64_t)b * H + j] : 0.f;   // initial_state_fw = initial_state_bw = s (ops.py:123-124)
-  lds_barrier();
+  if (t_ < H) hs[t_] = h0 ? h0[(int64_t)b * H + t_] : 0.f;   // initial_state_fw = initial_state_bw = s (ops.py:123-124)
 
   const int64_t row0 = (int64_t)b * T;
   const int tstart = d == 0 ? 0 : T - 1, tstep = d == 0 ? 1 : -1;
-  float xg_g = xg[(row0 + tstart) * (6 * H) + d * 3 * H + j];
-  float xg_c = half == 0 ? xg[(row0 + tstart) * (6 * H) + d * 3 * H + 2 * H + col] : 0.f;
+  // wave 7 DMAs chunk c (steps [c*CH, c*CH+CH) in recurrence order) into xgs[c & 1]
+  auto dma_chunk = [&](int c) {
+    for (int i = 0; i < CH; ++i) {
+      const int s = c * CH + i;
+      if (s >= T) break;
+      const float* src = xg + (row0 + tstart + s * tstep) * (6 * H) + d * 3 * H + lane;
+      float* dst = &xgs[c & 1][i][0];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) dma64(src + 64 * q, dst + 64 * q);
+    }
+  };
+  if (wv == 7) {
+    dma_chunk(0);
+    wait_vm0();
+  }
+  lds_barrier();
 
   for (int s = 0, t = tstart; s < T; ++s, t += tstep) {
-    // prefetch next step's x-projection (independent of the recurrence)
-    float nxg_g = 0.f, nxg_c = 0.f;
-    if (s + 1 < T) {
-      const int64_t nr = (row0 + t + tstep) * (6 * H) + d * 3 * H;
-      nxg_g = xg[nr + j];
-      if (half == 0) nxg_c = xg[nr + 2 * H + col];
-    }
-    // ---- gates: thread j owns gate column j ----
-    float acc0 = xg_g, acc1 = 0.f;
+    const int c = s / CH, i = s - c * CH;
+    if (wv == 7 && i == 0 && (c + 1) * CH < T) dma_chunk(c + 1);
+    const float* xrow = &xgs[c & 1][i][0];
+    // ---- gates ----
+    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
 #pragma unroll
-    for (int k4 = 0; k4 < H / 4; ++k4) {
-      const float4 hv = reinterpret_cast<const float4*>(hs)[k4];
-      acc0 = fmaf(hv.x, wgh[4 * k4 + 0], acc0);
-      acc1 = fmaf(hv.y, wgh[4 * k4 + 1], acc1);
-      acc0 = fmaf(hv.z, wgh[4 * k4 + 2], acc0);
-      acc1 = fmaf(hv.w, wgh[4 * k4 + 3], acc1);
+    for (int k4 = 0; k4 < H / 16; ++k4) {
+      const float4 hv = reinterpret_cast<const float4*>(hs)[kq * (H / 16) + k4];
+      a0 = fmaf(hv.x, wr[4 * k4 + 0], a0); b0 = fmaf(hv.x, wu[4 * k4 + 0], b0);
+      a1 = fmaf(hv.y, wr[4 * k4 + 1], a1); b1 = fmaf(hv.y, wu[4 * k4 + 1], b1);
+      a0 = fmaf(hv.z, wr[4 * k4 + 2], a0); b0 = fmaf(hv.z, wu[4 * k4 + 2], b0);
+      a1 = fmaf(hv.w, wr[4 * k4 + 3], a1); b1 = fmaf(hv.w, wu[4 * k4 + 3], b1);
     }
-    const float g = sigmoid_f(acc0 + acc1);
-    const float hprev = hs[col];
-    if (half == 0) rhs[col] = g * hprev;   // r * h
-    else us[col] = g;                      // u
+    const float rg = sigmoid_fast(quad_sum(a0 + a1) + xrow[cp]);
+    const float ug = sigmoid_fast(quad_sum(b0 + b1) + xrow[H + cp]);
+    const float hprev = hs[cp];
+    if (kq == 0) {
+      rhs[cp] = rg * hprev;
+      us[cp] = ug;
+    }
     lds_barrier();
-    // ---- candidate: thread (col, half) reduces its half of r*h ----
+    // ---- candidate ----
     float p0 = 0.f, p1 = 0.f;
 #pragma unroll
-    for (int k4 = 0; k4 < H / 8; ++k4) {
-      const float4 rv = reinterpret_cast<const float4*>(rhs)[half * (H / 8) + k4];
-      p0 = fmaf(rv.x, wch[4 * k4 + 0], p0);
-      p1 = fmaf(rv.y, wch[4 * k4 + 1], p1);
-      p0 = fmaf(rv.z, wch[4 * k4 + 2], p0);
-      p1 = fmaf(rv.w, wch[4 * k4 + 3], p1);
+    for (int k4 = 0; k4 < H / 16; ++k4) {
+      const float4 rv = reinterpret_cast<const float4*>(rhs)[kq * (H / 16) + k4];
+      p0 = fmaf(rv.x, wcand[4 * k4 + 0], p0);
+      p1 = fmaf(rv.y, wcand[4 * k4 + 1], p1);
+      p0 = fmaf(rv.z, wcand[4 * k4 + 2], p0);
+      p1 = fmaf(rv.w, wcand[4 * k4 + 3], p1);
     }
-    if (half == 1) cpart[col] = p0 + p1;
-    lds_barrier();
-    if (half == 0) {
-      const float c = tanh_f(xg_c + p0 + p1 + cpart[col]);
-      const float u = us[col];
-      const float hn = u * hprev + (1.f - u) * c;
-      hs[col] = hn;
-      out[(row0 + t) * (2 * H) + d * H + col] = hn;
+    const float cpre = quad_sum(p0 + p1) + xrow[2 * H + cp];
+    // wave 7 must see its next-chunk DMA landed before the chunk is read; its own (younger) stores below are issued after
+    if (wv == 7 && i == CH - 1) wait_vm0();
+    if (kq == 0) {
+      const float cc = tanh_fast(cpre);
+      const float hn = ug * hprev + (1.f - ug) * cc;
+      hs[cp] = hn;
+      out[(row0 + t) * (2 * H) + d * H + cp] = hn;
       if (ruc) {
         float* rp = ruc + (row0 + t) * (6 * H) + d * 3 * H;
-        rp[col] = g;          // r (this thread's gate column is r_col)
-        rp[H + col] = u;
-        rp[2 * H + col] = c;
+        rp[cp] = rg;
+        rp[H + cp] = ug;
+        rp[2 * H + cp] = cc;
       }
     }
-    xg_g = nxg_g;
-    xg_c = nxg_c;
     lds_barrier();
   }
 }
 
-// Backward recurrence.  grid = (B, 2); block = 256.
+// Backward recurrence.  grid = (B, 2); block = 512.
 // Per step (reverse of the forward order), with h_prev = previous forward state, dh = carried gradient:
 //   dht = dh + dout; du = dht*(h_prev - c); dc = dht*(1-u); dcp = dc*(1-c^2); d(rh) = dcp . Wc_h^T
 //   dr = d(rh)*h_prev; dgp = [dr*r(1-r), du*u(1-u)]; dh = dht*u + d(rh)*r + dgp . Wg_h^T
-__global__ __launch_bounds__(256, 1) void bigru_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+// Thread (cp = t>>2, kq = t&3) owns hidden unit cp; every reduction is split over the quad's four lanes (k-quarters) and
+// combined with quad_sum.  Inputs {r,u,c,dout,h_prev} arrive by LDS-DMA in chunks of CH steps (wave 7).
+__global__ __launch_bounds__(NTG, 2) void bigru_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                            const float* __restrict__ ruc, BiGruBwdWeights w,
                                                            const float* __restrict__ h0, float* __restrict__ dxg,
                                                            float* __restrict__ rh_out, float* __restrict__ dh0, int B,
                                                            int T) {
-  const int b = blockIdx.x, d = blockIdx.y, j = threadIdx.x;
-  const int col = j & (H - 1), half = j >> 7;
-  __shared__ __attribute__((aligned(16))) float dcp_s[2][H];
-  __shared__ __attribute__((aligned(16))) float dgp_s[2][2 * H];
-  __shared__ float part_s[2][H];
+  const int b = blockIdx.x, d = blockIdx.y, t_ = threadIdx.x;
+  const int cp = t_ >> 2, kq = t_ & 3, lane = t_ & 63, wv = t_ >> 6;
+  __shared__ __attribute__((aligned(16))) float dcp_s[H];
+  __shared__ __attribute__((aligned(16))) float dgp_s[2 * H];
+  __shared__ __attribute__((aligned(16))) float in_s[2][CH][5 * H];   // [r | u | c | dout | h_prev]
 
-  // transposed h-side weights -> registers.  wchT (128 [col], 128 [k]); wghT (256 [j], 128 [k]).
-  float wc_r[H / 2];   // d(rh)[k=col] partial over cols in [half*64, half*64+64)
-  float wg_r[H];       // dh[k=col] partial over gate columns in [half*128, half*128+128)
+  // wchT (128 [c], 128 [k]): d(rh)[cp] = sum_c dcp[c] * wchT[c][cp]      -> this lane: c in [32kq, 32kq+32)
+  // wghT (256 [j], 128 [k]): dh[cp]   += sum_j dgp[j] * wghT[j][cp]      -> this lane: j in [64kq, 64kq+64)
+  float wc_r[H / 4], wg_r[H / 2];
   {
-    const float* p = w.wchT[d] + (int64_t)(half * (H / 2)) * H + col;
+    const float* p = w.wchT[d] + (int64_t)(kq * (H / 4)) * H + cp;
 #pragma unroll
-    for (int i = 0; i < H / 2; ++i) wc_r[i] = p[(int64_t)i * H];
-    const float* q = w.wghT[d] + (int64_t)(half * H) * H + col;
+    for (int i = 0; i < H / 4; ++i) wc_r[i] = p[(int64_t)i * H];
+    const float* q = w.wghT[d] + (int64_t)(kq * (H / 2)) * H + cp;
 #pragma unroll
-    for (int i = 0; i < H; ++i) wg_r[i] = q[(int64_t)i * H];
+    for (int i = 0; i < H / 2; ++i) wg_r[i] = q[(int64_t)i * H];
   }
 
   const int64_t row0 = (int64_t)b * T;
   // forward order for d=0 is t = 0..T-1, so backward visits T-1..0; for d=1 forward is T-1..0, backward 0..T-1.
   const int tstart = d == 0 ? T - 1 : 0, tstep = d == 0 ? -1 : 1;
-  float dh = 0.f;  // carried gradient for k = col (held by half 0)
+  float dh = 0.f;  // carried gradient of unit cp (kept by every lane of the quad)
+
+  auto dma_chunk = [&](int c) {
+    for (int i = 0; i < CH; ++i) {
+      const int s = c * CH + i;
+      if (s >= T) break;
+      const int t = tstart + s * tstep;
+      float* dst = &in_s[c & 1][i][0];
+      const float* rp = ruc + (row0 + t) * (6 * H) + d * 3 * H + lane;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) dma64(rp + 64 * q, dst + 64 * q);                    // r | u | c
+      const float* dp = dout + (row0 + t) * (2 * H) + d * H + lane;
+      dma64(dp, dst + 3 * H);
+      dma64(dp + 64, dst + 3 * H + 64);
+      if (s + 1 < T) {
+        const float* hp = out + (row0 + t + tstep) * (2 * H) + d * H + lane;
+        dma64(hp, dst + 4 * H);
+        dma64(hp + 64, dst + 4 * H + 64);
+      } else if (h0) {
+        dma64(h0 + (int64_t)b * H + lane, dst + 4 * H);
+        dma64(h0 + (int64_t)b * H + 64 + lane, dst + 4 * H + 64);
+      } else {
+        dst[4 * H + lane] = 0.f;
+        dst[4 * H + 64 + lane] = 0.f;
+      }
+    }
+  };
+  if (wv == 7) {
+    dma_chunk(0);
+    wait_vm0();
+  }
+  lds_barrier();
 
   for (int s = 0, t = tstart; s < T; ++s, t += tstep) {
-    const int buf = s & 1;
-    const int tp = t + tstep;  // time index of the previous forward step (h_prev lives there)
-    const bool has_prev = (s + 1 < T);
-    float r = 0.f, u = 0.f, c = 0.f, hp = 0.f, dht = 0.f;
-    if (half == 0) {
-      const float* rp = ruc + (row0 + t) * (6 * H) + d * 3 * H;
-      r = rp[col];
-      u = rp[H + col];
-      c = rp[2 * H + col];
-      hp = has_prev ? out[(row0 + tp) * (2 * H) + d * H + col] : (h0 ? h0[(int64_t)b * H + col] : 0.f);
-      dht = dh + dout[(row0 + t) * (2 * H) + d * H + col];
-      const float du = dht * (hp - c);
-      const float dc = dht * (1.f - u);
-      const float dcp = dc * (1.f - c * c);
-      const float dup = du * u * (1.f - u);
-      dcp_s[buf][col] = dcp;
-      dgp_s[buf][H + col] = dup;
+    const int c = s / CH, i = s - c * CH;
+    if (wv == 7 && i == 0 && (c + 1) * CH < T) dma_chunk(c + 1);
+    const float* in = &in_s[c & 1][i][0];
+    const float r = in[cp], u = in[H + cp], cc = in[2 * H + cp], hp = in[4 * H + cp];
+    const float dht = dh + in[3 * H + cp];
+    const float du = dht * (hp - cc);
+    const float dc = dht * (1.f - u);
+    const float dcp = dc * (1.f - cc * cc);
+    const float dup = du * u * (1.f - u);
+    if (kq == 0) {
+      dcp_s[cp] = dcp;
+      dgp_s[H + cp] = dup;
       float* xo = dxg + (row0 + t) * (6 * H) + d * 3 * H;
-      xo[2 * H + col] = dcp;
-      xo[H + col] = dup;
-      rh_out[(row0 + t) * (2 * H) + d * H + col] = r * hp;
+      xo[2 * H + cp] = dcp;
+      xo[H + cp] = dup;
+      rh_out[(row0 + t) * (2 * H) + d * H + cp] = r * hp;
     }
     lds_barrier();
-    // d(rh)[col] partial
+    // d(rh)[cp]
     float p0 = 0.f, p1 = 0.f;
 #pragma unroll
-    for (int i4 = 0; i4 < H / 8; ++i4) {
-      const float4 v = reinterpret_cast<const float4*>(dcp_s[buf])[half * (H / 8) + i4];
+    for (int i4 = 0; i4 < H / 16; ++i4) {
+      const float4 v = reinterpret_cast<const float4*>(dcp_s)[kq * (H / 16) + i4];
       p0 = fmaf(v.x, wc_r[4 * i4 + 0], p0);
       p1 = fmaf(v.y, wc_r[4 * i4 + 1], p1);
       p0 = fmaf(v.z, wc_r[4 * i4 + 2], p0);
       p1 = fmaf(v.w, wc_r[4 * i4 + 3], p1);
     }
-    if (half == 1) part_s[0][col] = p0 + p1;
-    lds_barrier();
-    float dh_acc = 0.f;
-    if (half == 0) {
-      const float drh = p0 + p1 + part_s[0][col];
-      const float dr = drh * hp;
-      const float drp = dr * r * (1.f - r);
-      dgp_s[buf][col] = drp;
-      dxg[(row0 + t) * (6 * H) + d * 3 * H + col] = drp;
-      dh_acc = dht * u + drh * r;
+    const float drh = quad_sum(p0 + p1);
+    const float drp = drh * hp * r * (1.f - r);
+    if (kq == 0) {
+      dgp_s[cp] = drp;
+      dxg[(row0 + t) * (6 * H) + d * 3 * H + cp] = drp;
     }
     lds_barrier();
     float q0 = 0.f, q1 = 0.f;
 #pragma unroll
-    for (int i4 = 0; i4 < H / 4; ++i4) {
-      const float4 v = reinterpret_cast<const float4*>(dgp_s[buf])[half * (H / 4) + i4];
+    for (int i4 = 0; i4 < H / 8; ++i4) {
+      const float4 v = reinterpret_cast<const float4*>(dgp_s)[kq * (H / 8) + i4];
       q0 = fmaf(v.x, wg_r[4 * i4 + 0], q0);
       q1 = fmaf(v.y, wg_r[4 * i4 + 1], q1);
       q0 = fmaf(v.z, wg_r[4 * i4 + 2], q0);
       q1 = fmaf(v.w, wg_r[4 * i4 + 3], q1);
     }
-    if (half == 1) part_s[1][col] = q0 + q1;
-    lds_barrier();
-    if (half == 0) dh = dh_acc + q0 + q1 + part_s[1][col];
+    dh = dht * u + drh * r + quad_sum(q0 + q1);
+    if (wv == 7 && i == CH - 1) wait_vm0();   // next chunk landed (one store-latency wait per CH steps)
+    lds_barrier();                             // dcp_s / dgp_s are rewritten by the next step
   }
-  if (dh0 && half == 0) dh0[((int64_t)d * B + b) * H + col] = dh;   // gradient w.r.t. the initial state
+  if (dh0 && kq == 0) dh0[((int64_t)d * B + b) * H + cp] = dh;   // gradient w.r.t. the initial state
 }
 
 }  // namespace
@@ -198,7 +257,8 @@ __global__ __launch_bounds__(256, 1) void bigru_bwd_kernel(const float* __restri
 int launch_bigru_fwd(const float* xg, const BiGruWeights& w, const float* h0, float* out, float* ruc, int B, int T,
                      hipStream_t s) {
   TACO_REQUIRE(B > 0 && T > 0, "bigru_fwd: bad dims");
-  hipLaunchKernelGGL(bigru_fwd_kernel, dim3(B, 2), dim3(256), 0, s, xg, w, h0, out, ruc, B, T);
+  long long* trace = nullptr;
+  hipLaunchKernelGGL(bigru_fwd_kernel, dim3(B, 2), dim3(NTG), 0, s, xg, w, h0, out, ruc, B, T, trace);
   TACO_LAUNCH_CHECK("bigru_fwd");
   return TACO_OK;
 }
@@ -206,7 +266,7 @@ int launch_bigru_fwd(const float* xg, const BiGruWeights& w, const float* h0, fl
 int launch_bigru_bwd(const float* dout, const float* out, const float* ruc, const BiGruBwdWeights& w, const float* h0,
                      float* dxg, float* rh, float* dh0, int B, int T, hipStream_t s) {
   TACO_REQUIRE(B > 0 && T > 0, "bigru_bwd: bad dims");
-  hipLaunchKernelGGL(bigru_bwd_kernel, dim3(B, 2), dim3(256), 0, s, dout, out, ruc, w, h0, dxg, rh, dh0, B, T);
+  hipLaunchKernelGGL(bigru_bwd_kernel, dim3(B, 2), dim3(NTG), 0, s, dout, out, ruc, w, h0, dxg, rh, dh0, B, T);
   TACO_LAUNCH_CHECK("bigru_bwd");
   return TACO_OK;
 }

@@ -53,15 +53,37 @@ __device__ __forceinline__ float tanh_f(float x) {
   return 2.0f / (1.0f + expf(-2.0f * x)) - 1.0f;
 }
 
+// Attention inner loops only: tanh on the hardware exp / rcp units (v_exp_f32, v_rcp_f32; ~1 ulp each), absolute error
+// ~2e-7 -- 51 K tanh per row-step make the IEEE-division version the largest VALU cost of the attention phases.
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) {
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x));
+}
+
+// Wave64 reductions on the DPP path (gfx9 row_ror / row_bcast: plain VALU moves, no LDS-crossbar ds_bpermute as __shfl_xor
+// uses): quad_perm swaps + row_ror 4/8 leave every lane of a 16-lane row with the row total; row_bcast:15 / :31 then fold the
+// four rows so lanes 48..63 hold the wave total, which v_readlane broadcasts.  ~6 VALU ops instead of 6 dependent shuffles.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_move(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_move<0xb1>(0.f, v);          // quad_perm [1,0,3,2]
+  v += dpp_move<0x4e>(0.f, v);          // quad_perm [2,3,0,1]
+  v += dpp_move<0x124>(0.f, v);         // row_ror:4
+  v += dpp_move<0x128>(0.f, v);         // row_ror:8
+  v += dpp_move<0x142, 0xa>(0.f, v);    // row_bcast:15 -> rows 1,3
+  v += dpp_move<0x143, 0xc>(0.f, v);    // row_bcast:31 -> rows 2,3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_move<0xb1>(v, v));
+  v = fmaxf(v, dpp_move<0x4e>(v, v));
+  v = fmaxf(v, dpp_move<0x124>(v, v));
+  v = fmaxf(v, dpp_move<0x128>(v, v));
+  v = fmaxf(v, dpp_move<0x142, 0xa>(v, v));
+  v = fmaxf(v, dpp_move<0x143, 0xc>(v, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // Workgroup barrier for LDS-only communication: waits for this wave's LDS traffic (lgkmcnt) but NOT for its outstanding

@@ -65,6 +65,57 @@ __device__ __forceinline__ float xget(const Xchg& X, int idx) {
   }
 }
 
+// free-form trace mark (slot 40+id) for sections that are not phase() calls
+__device__ __forceinline__ void tmark(const Xchg& X, int id) {
+  if (X.trace && threadIdx.x == 0) {
+    X.trace[160 + id] = wall_clock64();
+    if (id == 0 || id == 5) X.trace[190 + (id != 0)] = clock64();   // shader-cycle counter: effective clock = dcycles / dwall
+  }
+}
+
+// Sum of the P peers' partial values for element `idx` (own partial `own` already published at reg + peer*stride + idx).
+// All remote granules are polled concurrently; the sum runs in peer order so every peer gets the bit-identical result.
+__device__ __forceinline__ float xsum_partials(const Xchg& X, int reg, int stride, int idx, float own) {
+  constexpr int MAXP = 8;
+  float v[MAXP];
+  bool ok[MAXP];
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) {
+    ok[p] = (p >= X.P) || (p == X.peer);
+    v[p] = (p == X.peer) ? own : 0.f;
+  }
+  if (!*X.dead) {
+    for (unsigned spin = 0;; ++spin) {
+      bool all = true;
+#pragma unroll
+      for (int p = 0; p < MAXP; ++p) {
+        if (!ok[p]) {
+          const u64 x = __hip_atomic_load((gu64*)(X.base + reg + p * stride + idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((unsigned)(x >> 32) == X.epoch) {
+            v[p] = __uint_as_float((unsigned)x);
+            ok[p] = true;
+          } else {
+            all = false;
+          }
+        }
+      }
+      if (all) break;
+      if ((spin & 1023u) == 1023u) {
+        if (spin > (1u << 23) || __hip_atomic_load((gi32*)X.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+          __hip_atomic_store((gi32*)X.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          *X.dead = 1;
+          break;
+        }
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) s += v[p];
+  return s;
+}
+
 // One mat-vec phase of the cluster:  y[n] = sum_k x[k] * W[k*ldw + n]  for this peer's column slice, then
 //   v = epi(n, y) (owner only: activation, stash writes), put(n, v) on EVERY peer (LDS state update) after the all-gather.
 // x lives in LDS and must be readable up to K rounded up to 4.  N % 4 == 0 and N/4 >= P.  Contains ONE lds_barrier();
@@ -372,10 +423,11 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
     // ---- energies e[s] = sum_u v_u tanh(keys[s,u] + q_u): one wave per memory row, rows dealt round-robin to peers ----
     {
       tstamp(X, 0);
+      tmark(X, 0);
       const float4 q4 = reinterpret_cast<const float4*>(S.qs)[lane];
       auto score = [&](int s, float4 k4) {
-        float e = v4.x * tanh_f(k4.x + q4.x) + v4.y * tanh_f(k4.y + q4.y) + v4.z * tanh_f(k4.z + q4.z) +
-                  v4.w * tanh_f(k4.w + q4.w);
+        float e = v4.x * tanh_fast(k4.x + q4.x) + v4.y * tanh_fast(k4.y + q4.y) + v4.z * tanh_fast(k4.z + q4.z) +
+                  v4.w * tanh_fast(k4.w + q4.w);
         e = wave_sum(e);
         if (lane == 0) {
           S.es[s] = e;
@@ -390,14 +442,17 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
       for (int s = s_first + kAR * s_stride; s < len; s += s_stride)
         score(s, reinterpret_cast<const float4*>(keys + (int64_t)s * kAtt)[lane]);
       tstamp(X, 2);
+      tmark(X, 1);
       if (P > 1) {
         for (int s = tid; s < len; s += NT)
           if (s % P != X.peer) S.es[s] = xget(X, XF_E + s);
       }
       tstamp(X, 3);
+      tmark(X, 2);
       X.tslot++;
     }
     lds_barrier();
+    tmark(X, 3);
     // ---- masked softmax over s < len (score_mask_value = -inf => alignment 0 past text_length) ----
     {
       float m = -INFINITY;
@@ -413,7 +468,9 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
         if (lead) a.align[bt * Tt + s] = al;
       }
     }
+    tmark(X, 4);
     lds_barrier();
+    tmark(X, 5);
     // ---- context = alignments . values ----
     tstamp(X, 1);   // (slot of the ctx phase, stamp 1 is overwritten; the softmax end shows as stamp 0 of ctx)
     phase(values, kAtt, len, kAtt, S.als, S.part, X, XF_CTX,
@@ -569,6 +626,8 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
 
   for (int t = Td - 1; t >= 0; --t) {
     X.epoch = (unsigned)(Td - t);
+    X.trace = (a.trace && blockIdx.x == 0 && t == Td / 2) ? a.trace : nullptr;
+    X.tslot = 0;
     const int64_t bt = (int64_t)b * Td + t;
     float* gs = a.gstash + bt * kGsRec;
     const bool next_from_out = (t + 1 < Td) && a.sample && a.sample[(int64_t)t * B + b];
@@ -606,6 +665,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
     lds_barrier();
     // 3a. d alignments[s] = values[s] . dctx   (memory rows dealt round-robin to peers)
     {
+      tmark(X, 10);
       const float4 c4 = reinterpret_cast<const float4*>(S.dov + R80)[lane];
       auto dal = [&](int s, float4 x4) {
         float d = x4.x * c4.x + x4.y * c4.y + x4.z * c4.z + x4.w * c4.w;
@@ -622,12 +682,15 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
       }
       for (int s = s_first + kAR * s_stride; s < len; s += s_stride)
         dal(s, reinterpret_cast<const float4*>(values + (int64_t)s * kAtt)[lane]);
+      tmark(X, 11);
       if (P > 1) {
         for (int s = tid; s < len; s += NT)
           if (s % P != X.peer) S.des[s] = xget(X, XB_DAL + s);
       }
+      tmark(X, 12);
     }
     lds_barrier();
+    tmark(X, 13);
     // 3b. softmax backward: de = al * (dal - sum al*dal)   (every wave computes the dot redundantly)
     {
       float dot = 0.f;
@@ -637,13 +700,14 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
       for (int s = tid; s < len; s += NT) S.des[s] = S.als[s] * (S.des[s] - dot);
     }
     lds_barrier();
+    tmark(X, 14);
     // 3c. energy backward on this peer's rows: th = tanh(keys+q); dpre = de*v*(1-th^2); dq += dpre; dkeys += dpre; dv += de*th
     {
       const float4 q4 = reinterpret_cast<const float4*>(S.rec + RL_Q)[lane];
       float4 dq4 = make_float4(0.f, 0.f, 0.f, 0.f);
       auto ebwd = [&](int s, float4 k4, float4 dk) {
         const float de = S.des[s];
-        const float t0 = tanh_f(k4.x + q4.x), t1 = tanh_f(k4.y + q4.y), t2 = tanh_f(k4.z + q4.z), t3 = tanh_f(k4.w + q4.w);
+        const float t0 = tanh_fast(k4.x + q4.x), t1 = tanh_fast(k4.y + q4.y), t2 = tanh_fast(k4.z + q4.z), t3 = tanh_fast(k4.w + q4.w);
         const float p0 = de * v4.x * (1.f - t0 * t0), p1 = de * v4.y * (1.f - t1 * t1);
         const float p2 = de * v4.z * (1.f - t2 * t2), p3 = de * v4.w * (1.f - t3 * t3);
         dq4.x += p0; dq4.y += p1; dq4.z += p2; dq4.w += p3;
@@ -662,21 +726,24 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
         reinterpret_cast<float4*>(dkeys + (int64_t)s * kAtt)[lane] = dk;
       }
       reinterpret_cast<float4*>(S.red + wave * 256)[lane] = dq4;
+      tmark(X, 15);
     }
     lds_barrier();
+    tmark(X, 16);
     if (tid < kAtt) {
       float d = 0.f;
 #pragma unroll
       for (int i = 0; i < NT / 64; ++i) d += S.red[i * 256 + tid];
       if (P > 1) {
         xput(X, XB_DQP + X.peer * 256 + tid, d);
-        for (int p = 0; p < P; ++p)
-          if (p != X.peer) d += xget(X, XB_DQP + p * 256 + tid);
+        d = xsum_partials(X, XB_DQP, 256, tid, d);
       }
       S.dq[tid] = d;
       if (lead) gs[kGsQ + tid] = d;
     }
+    tmark(X, 17);
     lds_barrier();
+    tmark(X, 18);
     // 4. query layer: do += dq . Wq^T   (wT.q_w is (256, 80r))
     phase(w.q_w, R80, kAtt, R80, S.dq, S.part, X, XB_Q,
           [&](int n, float y) {

@@ -190,6 +190,7 @@ struct DecBwdArgs {
   float* datt_v;         // (256) accumulated (atomics)
   void* xchg;
   int* err;
+  long long* trace;      // optional per-phase stamps (see DecFwdArgs)
   int B, Tt, Td, r;
   int P;
 };

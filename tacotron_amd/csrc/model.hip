@@ -628,6 +628,7 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     a.dout = dS2S; a.out = seq2seq_output; a.align = alignments; a.stash = st; a.gstash = gs;
     a.dkeys = ws + W.dkeys; a.datt_v = G + PL.att_v;
     a.xchg = ws + W.xchg; a.err = reinterpret_cast<int*>(ws + W.err) + 1;
+    a.trace = getenv("TACO_DEC_TRACE") ? reinterpret_cast<long long*>(ws + W.err + 16) + 128 : nullptr;
     a.B = B; a.Tt = Tt; a.Td = Td; a.r = r; a.P = 1;
     const int slot = prof_begin(1, s);
     TACO_TRY(launch_decoder_bwd(a, s));

@@ -25,3 +25,24 @@ for i, n in enumerate(names):
     nxt = (tr[i + 1, 0] - t0) / 100.0 if i + 1 < len(names) else float('nan')
     print('%-5s %9.2f %8.2f %12.2f %10.2f %8.2f' % (n, a, b - a, c_ - b, d - c_, nxt - a))
 print('step total us: %.2f' % ((tr[len(names) - 1, 3] - t0) / 100.0))
+mk = m.workspace[o + 16 + 320:o + 16 + 320 + 2 * 32].view(torch.int64).cpu().numpy()
+print('fwd attention marks (us since e-phase start):', ['%.2f' % ((mk[i] - mk[0]) / 100.0) for i in range(6)],
+      ' [0 start,1 energies done,2 gathered,3 barrier,4 softmax done,5 barrier]')
+ck = m.workspace[o + 16 + 380:o + 16 + 380 + 4].view(torch.int64).cpu().numpy()
+print('shader clock during the decoder kernel: %.0f MHz' % ((ck[1] - ck[0]) / ((mk[5] - mk[0]) / 100.0)))
+# ---- backward ----
+m.backward()
+torch.cuda.synchronize()
+tb = m.workspace[o + 16 + 256:o + 16 + 256 + 4 * 2 * 20].view(torch.int64).cpu().numpy().reshape(-1, 4)
+bn = ['attT', 'qT', 'outT', 'c2T', 'g2T', 'c1T', 'g1T', 'c0T', 'g0T', 'inT', 'p2T', 'p1T']
+t0 = tb[0, 0]
+print('BACKWARD phase start_us matvec finalize gather total')
+for i, n in enumerate(bn):
+    if tb[i, 0] == 0: break
+    a, b, c_, d = [(x - t0) / 100.0 for x in tb[i]]
+    nxt = (tb[i + 1, 0] - t0) / 100.0 if (i + 1 < len(bn) and tb[i + 1, 0] != 0) else float('nan')
+    print('%-5s %9.2f %8.2f %12.2f %10.2f %8.2f' % (n, a, b - a, c_ - b, d - c_, nxt - a))
+
+mk = m.workspace[o + 16 + 256 + 320:o + 16 + 256 + 320 + 2 * 32].view(torch.int64).cpu().numpy()
+print('bwd attention marks (us since 3a start):', ['%.2f' % ((mk[i] - mk[10]) / 100.0) for i in range(10, 19)],
+      ' [10 start,11 dal done,12 gathered,13 barrier,14 softmax-bwd done,15 energy-bwd done,16 barrier,17 dq exchanged,18 barrier]')
