@@ -67,26 +67,23 @@ __global__ __launch_bounds__(NTG, 2) void bigru_fwd_kernel(const float* __restri
 
   const int64_t row0 = (int64_t)b * T;
   const int tstart = d == 0 ? 0 : T - 1, tstep = d == 0 ? 1 : -1;
-  // wave 7 DMAs chunk c (steps [c*CH, c*CH+CH) in recurrence order) into xgs[c & 1]
+  // wave i DMAs step i of chunk c (recurrence steps [c*CH, c*CH+CH)) into xgs[c & 1][i]   (CH == number of waves)
   auto dma_chunk = [&](int c) {
-    for (int i = 0; i < CH; ++i) {
-      const int s = c * CH + i;
-      if (s >= T) break;
+    const int s = c * CH + wv;
+    if (s < T) {
       const float* src = xg + (row0 + tstart + s * tstep) * (6 * H) + d * 3 * H + lane;
-      float* dst = &xgs[c & 1][i][0];
+      float* dst = &xgs[c & 1][wv][0];
 #pragma unroll
       for (int q = 0; q < 6; ++q) dma64(src + 64 * q, dst + 64 * q);
     }
   };
-  if (wv == 7) {
-    dma_chunk(0);
-    wait_vm0();
-  }
+  dma_chunk(0);
+  wait_vm0();
   lds_barrier();
 
   for (int s = 0, t = tstart; s < T; ++s, t += tstep) {
     const int c = s / CH, i = s - c * CH;
-    if (wv == 7 && i == 0 && (c + 1) * CH < T) dma_chunk(c + 1);
+    if (i == 0 && (c + 1) * CH < T) dma_chunk(c + 1);
     const float* xrow = &xgs[c & 1][i][0];
     // ---- gates ----
     float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
@@ -117,8 +114,8 @@ __global__ __launch_bounds__(NTG, 2) void bigru_fwd_kernel(const float* __restri
       p1 = fmaf(rv.w, wcand[4 * k4 + 3], p1);
     }
     const float cpre = quad_sum(p0 + p1) + xrow[2 * H + cp];
-    // wave 7 must see its next-chunk DMA landed before the chunk is read; its own (younger) stores below are issued after
-    if (wv == 7 && i == CH - 1) wait_vm0();
+    // every wave's share of the next chunk has had CH-1 steps to land; wait before this step's (younger) stores are issued
+    if (i == CH - 1) wait_vm0();
     if (kq == 0) {
       const float cc = tanh_fast(cpre);
       const float hn = ug * hprev + (1.f - ug) * cc;
@@ -169,12 +166,11 @@ __global__ __launch_bounds__(NTG, 2) void bigru_bwd_kernel(const float* __restri
   const int tstart = d == 0 ? T - 1 : 0, tstep = d == 0 ? -1 : 1;
   float dh = 0.f;  // carried gradient of unit cp (kept by every lane of the quad)
 
-  auto dma_chunk = [&](int c) {
-    for (int i = 0; i < CH; ++i) {
-      const int s = c * CH + i;
-      if (s >= T) break;
+  auto dma_chunk = [&](int c) {   // wave i stages step i of chunk c
+    const int s = c * CH + wv;
+    if (s < T) {
       const int t = tstart + s * tstep;
-      float* dst = &in_s[c & 1][i][0];
+      float* dst = &in_s[c & 1][wv][0];
       const float* rp = ruc + (row0 + t) * (6 * H) + d * 3 * H + lane;
 #pragma unroll
       for (int q = 0; q < 6; ++q) dma64(rp + 64 * q, dst + 64 * q);                    // r | u | c
@@ -194,15 +190,13 @@ __global__ __launch_bounds__(NTG, 2) void bigru_bwd_kernel(const float* __restri
       }
     }
   };
-  if (wv == 7) {
-    dma_chunk(0);
-    wait_vm0();
-  }
+  dma_chunk(0);
+  wait_vm0();
   lds_barrier();
 
   for (int s = 0, t = tstart; s < T; ++s, t += tstep) {
     const int c = s / CH, i = s - c * CH;
-    if (wv == 7 && i == 0 && (c + 1) * CH < T) dma_chunk(c + 1);
+    if (i == 0 && (c + 1) * CH < T) dma_chunk(c + 1);
     const float* in = &in_s[c & 1][i][0];
     const float r = in[cp], u = in[H + cp], cc = in[2 * H + cp], hp = in[4 * H + cp];
     const float dht = dh + in[3 * H + cp];
@@ -246,7 +240,7 @@ __global__ __launch_bounds__(NTG, 2) void bigru_bwd_kernel(const float* __restri
       q1 = fmaf(v.w, wg_r[4 * i4 + 3], q1);
     }
     dh = dht * u + drh * r + quad_sum(q0 + q1);
-    if (wv == 7 && i == CH - 1) wait_vm0();   // next chunk landed (one store-latency wait per CH steps)
+    if (i == CH - 1) wait_vm0();   // next chunk landed (one store-latency wait per CH steps)
     lds_barrier();                             // dcp_s / dgp_s are rewritten by the next step
   }
   if (dh0 && kq == 0) dh0[((int64_t)d * B + b) * H + cp] = dh;   // gradient w.r.t. the initial state

@@ -199,12 +199,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmBatch batch) {
 
 // dW[z][tap][k][n] += sum_m A[z][row(m,tap)][k] * dY[z][m][n]; reduction over m split across blockIdx.z slices.
 template <int WM, int WN, bool VA, bool VB>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs P) {
+__device__ __forceinline__ void gemm_tn_body(const GemmTnArgs& P, const int bx, const int by, const int bz_) {
   constexpr int BM = 64 * WM, BN = 64 * WN;   // BM tiles the k (output row) dimension
   constexpr int LDS_A = BM + 4, LDS_B = BN + 4;
   constexpr int A_PER = BM / 64, B_PER = BN / 64;
-  const int k0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  int z = blockIdx.z;
+  const int k0 = bx * BM, n0 = by * BN;
+  int z = bz_;
   const int split = z % P.splits;
   z /= P.splits;
   const int tap = z % P.taps;
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs P) {
 
   float4 ra[A_PER], rb[B_PER];
   bool oka[A_PER], okb[B_PER];
-  const bool do_bias = P.dbias != nullptr && blockIdx.x == 0 && tap == 0;
+  const bool do_bias = P.dbias != nullptr && bx == 0 && tap == 0;
   float4 bsum[B_PER];
 #pragma unroll
   for (int i = 0; i < B_PER; ++i) bsum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -371,6 +371,26 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs P) {
   }
 }
 
+template <int WM, int WN, bool VA, bool VB>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs P) {
+  gemm_tn_body<WM, WN, VA, VB>(P, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Grouped launch: independent weight-gradient GEMMs (all 64x64 tiles, vector contract) share ONE grid; block -> problem
+// by a prefix table of block counts, so ~20 launch-latency-sized GEMMs run concurrently instead of back to back.
+__global__ __launch_bounds__(256) void gemm_tn_batch_kernel(GemmTnBatch B) {
+  int pi = 0;
+  for (int i = 1; i < B.n; ++i)
+    if ((int)blockIdx.x >= B.first[i]) pi = i;
+  const GemmTnArgs& P = B.p[pi];
+  int rel = blockIdx.x - B.first[pi];
+  const int gx = B.gx[pi], gy = B.gy[pi];
+  const int bz = rel / (gx * gy);
+  rel -= bz * gx * gy;
+  const int by = rel / gx, bx = rel - by * gx;
+  gemm_tn_body<1, 1, true, true>(P, bx, by, bz);
+}
+
 __global__ void gemm_naive_kernel(ConvGemmProblem P) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)P.M * P.N) return;
@@ -453,25 +473,13 @@ static void dispatch_tn(int flags, dim3 grid, hipStream_t s, const GemmTnArgs& a
   }
 }
 
-int launch_gemm_tn(GemmTnArgs a, bool zero_first, hipStream_t stream) {
-  TACO_REQUIRE(a.A && a.Y && a.W, "gemm_tn: null operand");
-  TACO_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.taps > 0 && a.T > 0 && a.batch > 0, "gemm_tn: bad dims");
-  TACO_REQUIRE(a.M % a.T == 0, "gemm_tn: M (%d) must be a multiple of T (%d)", a.M, a.T);
+// Validates one problem, derives its vector flags and split plan.  Returns the tile size used (64 or 128).
+static int plan_gemm_tn(GemmTnArgs& a, bool force_small, dim3& grid) {
   a.flags = 0;
   if (a.Nld <= 0) a.Nld = (a.N % 4 == 0) ? a.N : 0;
   if (a.lda % 4 == 0 && aligned16(a.A) && a.strideA % 4 == 0 && a.K % 4 == 0) a.flags |= 1;
   if (a.ldy % 4 == 0 && aligned16(a.Y) && a.strideY % 4 == 0 && a.Nld > 0 && a.Nld % 4 == 0 && a.Nld <= a.ldy) a.flags |= 2;
-  if (zero_first) {
-    for (int b = 0; b < a.batch; ++b) {
-      hipError_t e = hipMemset2DAsync(a.W + (int64_t)b * a.strideW, (size_t)a.ldw * 4, 0, (size_t)a.N * 4,
-                                      (size_t)a.taps * a.K, stream);
-      if (e != hipSuccess) {
-        taco_set_error("gemm_tn memset: %s", hipGetErrorString(e));
-        return TACO_ELAUNCH;
-      }
-    }
-  }
-  const bool big = (int64_t)cdiv(a.K, 128) * cdiv(a.N, 128) * a.taps * a.batch >= 128 && a.K >= 128 && a.N >= 128;
+  const bool big = !force_small && (int64_t)cdiv(a.K, 128) * cdiv(a.N, 128) * a.taps * a.batch >= 128 && a.K >= 128 && a.N >= 128;
   const int bm = big ? 128 : 64;
   const int64_t tiles = (int64_t)cdiv(a.K, bm) * cdiv(a.N, bm) * a.taps * a.batch;
   int splits = (int)((768 + tiles - 1) / tiles);
@@ -483,12 +491,63 @@ int launch_gemm_tn(GemmTnArgs a, bool zero_first, hipStream_t stream) {
   splits = cdiv(a.M, chunk);
   a.splits = splits;
   a.chunk = chunk;
-  dim3 grid(cdiv(a.K, bm), cdiv(a.N, bm), a.batch * a.taps * splits);
-  if (big)
+  grid = dim3(cdiv(a.K, bm), cdiv(a.N, bm), a.batch * a.taps * splits);
+  return bm;
+}
+
+int launch_gemm_tn(GemmTnArgs a, bool zero_first, hipStream_t stream) {
+  TACO_REQUIRE(a.A && a.Y && a.W, "gemm_tn: null operand");
+  TACO_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.taps > 0 && a.T > 0 && a.batch > 0, "gemm_tn: bad dims");
+  TACO_REQUIRE(a.M % a.T == 0, "gemm_tn: M (%d) must be a multiple of T (%d)", a.M, a.T);
+  if (zero_first) {
+    for (int b = 0; b < a.batch; ++b) {
+      hipError_t e = hipMemset2DAsync(a.W + (int64_t)b * a.strideW, (size_t)a.ldw * 4, 0, (size_t)a.N * 4,
+                                      (size_t)a.taps * a.K, stream);
+      if (e != hipSuccess) {
+        taco_set_error("gemm_tn memset: %s", hipGetErrorString(e));
+        return TACO_ELAUNCH;
+      }
+    }
+  }
+  dim3 grid;
+  const int bm = plan_gemm_tn(a, false, grid);
+  if (bm == 128)
     dispatch_tn<2, 2>(a.flags, grid, stream, a);
   else
     dispatch_tn<1, 1>(a.flags, grid, stream, a);
   TACO_LAUNCH_CHECK("gemm_tn");
+  return TACO_OK;
+}
+
+// Accumulating (never zeroing) grouped launch.  Problems that do not meet the vector contract, or that are large enough
+// for the 128x128 tile, are launched on their own.
+int launch_gemm_tn_batch(GemmTnBatch& b, hipStream_t stream) {
+  TACO_REQUIRE(b.n >= 0 && b.n <= kMaxTnBatch, "gemm_tn_batch: %d problems out of range", b.n);
+  GemmTnBatch grouped;
+  int blocks = 0;
+  for (int i = 0; i < b.n; ++i) {
+    GemmTnArgs a = b.p[i];
+    TACO_REQUIRE(a.A && a.Y && a.W, "gemm_tn_batch: null operand");
+    TACO_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.taps > 0 && a.T > 0 && a.batch > 0 && a.M % a.T == 0, "gemm_tn_batch: bad dims");
+    dim3 grid;
+    GemmTnArgs probe = a;
+    const int bm = plan_gemm_tn(probe, false, grid);
+    if (bm == 128 || probe.flags != 3) {
+      TACO_TRY(launch_gemm_tn(a, false, stream));
+      continue;
+    }
+    const int j = grouped.n++;
+    grouped.p[j] = probe;
+    grouped.first[j] = blocks;
+    grouped.gx[j] = (int)grid.x;
+    grouped.gy[j] = (int)grid.y;
+    blocks += (int)(grid.x * grid.y * grid.z);
+  }
+  if (grouped.n > 0) {
+    hipLaunchKernelGGL(gemm_tn_batch_kernel, dim3(blocks), dim3(256), 0, stream, grouped);
+    TACO_LAUNCH_CHECK("gemm_tn_batch");
+  }
+  b.n = 0;
   return TACO_OK;
 }
 

@@ -41,6 +41,15 @@ struct GemmTnArgs {
 int launch_conv_gemm_batch(ConvGemmBatch& batch, hipStream_t stream);
 int launch_conv_gemm(const ConvGemmProblem& p, hipStream_t stream);
 int launch_gemm_tn(GemmTnArgs a, bool zero_first, hipStream_t stream);
+constexpr int kMaxTnBatch = 26;
+struct GemmTnBatch {
+  GemmTnArgs p[kMaxTnBatch];
+  int first[kMaxTnBatch];   // first linear block of each problem (filled by the launcher)
+  int gx[kMaxTnBatch], gy[kMaxTnBatch];
+  int n = 0;
+};
+// Launches every queued problem (accumulating into W) in as few grids as possible and empties the batch.
+int launch_gemm_tn_batch(GemmTnBatch& b, hipStream_t stream);
 int launch_gemm_naive(const ConvGemmProblem& p, hipStream_t stream);
 
 // ---------------------------------------------------------------- elementwise.hip

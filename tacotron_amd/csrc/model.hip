@@ -278,6 +278,17 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
   return TACO_OK;
 }
 
+// Weight-gradient GEMM.  Inside a TnGroup scope the call is queued and launched with its independent siblings in ONE grid
+// (launch_gemm_tn_batch); otherwise it is launched immediately.
+thread_local GemmTnBatch* g_tnq = nullptr;
+struct TnGroup {
+  GemmTnBatch batch;
+  hipStream_t s;
+  explicit TnGroup(hipStream_t stream) : s(stream) { g_tnq = &batch; }
+  int flush() { return batch.n ? launch_gemm_tn_batch(batch, s) : TACO_OK; }
+  ~TnGroup() { g_tnq = nullptr; }
+};
+
 int tn(const float* A, int lda, int K, const float* Y, int ldy, int N, float* W, int ldw, int M, int T, int pad_l,
        hipStream_t s, int taps = 1, float* dbias = nullptr, int Nld = 0) {
   GemmTnArgs a;
@@ -285,6 +296,11 @@ int tn(const float* A, int lda, int K, const float* Y, int ldy, int N, float* W,
   a.Nld = Nld;
   a.A = A; a.lda = lda; a.Y = Y; a.ldy = ldy; a.W = W; a.ldw = ldw; a.M = M; a.N = N; a.K = K; a.taps = taps; a.T = T;
   a.pad_l = pad_l;
+  if (g_tnq) {
+    if (g_tnq->n == kMaxTnBatch) TACO_TRY(launch_gemm_tn_batch(*g_tnq, s));
+    g_tnq->p[g_tnq->n++] = a;
+    return TACO_OK;
+  }
   return launch_gemm_tn(a, false, s);
 }
 
@@ -372,6 +388,7 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
   }
   TACO_TRY(launch_bigru_bwd(dOut, w.out, w.ruc, bw, c.spk ? w.h0 : nullptr, dxg, rh, c.spk ? w.dh0 : nullptr, B, T, s));
   const GruP* g[2] = {&c.fw, &c.bw};
+  TnGroup gru_group(s);   // the 8 (10 with speakers) bi-GRU weight gradients are independent: one grid
   for (int d = 0; d < 2; ++d) {
     const float* dG = dxg + d * 3 * kCb;
     const float* dC = dG + 2 * kCb;
@@ -386,6 +403,8 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
       TACO_TRY(tn(w.h0, kCb, kCb, dG0, T * 6 * kCb, 2 * kCb, G + g[d]->wg + (int64_t)kCb * 2 * kCb, 2 * kCb, B, B, 0, s));
     }
   }
+  TACO_TRY(gru_group.flush());
+  g_tnq = nullptr;
   // small-tensor helper for the speaker sites: dz (B,128) -> dW (16,128), db, dspk_e (B,16) += dz . W^T
   auto spk_dense_bwd = [&](const float* dz, const DenseP& dp, int64_t wT) -> int {
     TACO_TRY(tn(w.spk_e, 16, 16, dz, kCb, kCb, G + dp.w, kCb, B, B, 0, s, 1, G + dp.b));
@@ -412,6 +431,7 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
   float* dth = sc.gD;    // (M,256) (rh no longer needed)
   float* dxd = sc.gG;    // (M,128)
   for (int l = 3; l >= 0; --l) {
+    TnGroup hw_group(s);   // this layer's weight gradients (T, H, adapter) share one grid, flushed before buffers are reused
     TACO_TRY(launch_highway_combine_bwd(w.th[l], w.hx[l], gh, dth, dxd, M, s));
     TACO_TRY(tn(w.hx[l], kCb, kCb, dth, 2 * kCb, kCb, G + c.hwT[l].w, kCb, M, M, 0, s, 1, G + c.hwT[l].b));
     TACO_TRY(tn(w.hx[l], kCb, kCb, dth + kCb, 2 * kCb, kCb, G + c.hwH[l].w, kCb, M, M, 0, s, 1, G + c.hwH[l].b));
@@ -420,6 +440,7 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
     p.ldr = kCb;
     TACO_TRY(launch_conv_gemm(p, s));        // gh2 = d hx[l]
     if (!c.has_adapt[l]) {
+      TACO_TRY(hw_group.flush());
       float* tmp = gh; gh = gh2; gh2 = tmp;  // hx[l] == h[l]
       continue;
     }
@@ -436,6 +457,7 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
       TACO_TRY(launch_act_bwd(w.sv[l], w.dsmall2, nullptr, w.dsmall2, (int64_t)B * kCb, TACO_ACT_RELU, s));
       TACO_TRY(spk_dense_bwd(w.dsmall2, c.spkd[l], t.spkd[l]));
     }
+    TACO_TRY(hw_group.flush());
   }
   float* dres = gh;      // (M, c2) gradient wrt `res`
   // ---- res = bn(conv(pj1)) + x ----
@@ -472,6 +494,7 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
     }
     ConvGemmBatch batch;
     batch.n = c.K;
+    TnGroup bank_group(s);   // K independent conv-bank weight gradients: one grid
     for (int k = 1; k <= c.K; ++k) {
       const float* dzk = dbank + (k - 1) * kCb;
       TACO_TRY(tn(x, c.cin, c.cin, dzk, KC, kCb, G + c.bank_w[k - 1], kCb, M, T, (k - 1) / 2, s, k, G + c.bank_b[k - 1]));
@@ -484,6 +507,7 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
         p.ldr = c.c2;
       }
     }
+    TACO_TRY(bank_group.flush());
     TACO_TRY(launch_conv_gemm_batch(batch, s));
   }
   return TACO_OK;
@@ -634,8 +658,9 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     TACO_TRY(launch_decoder_bwd(a, s));
     prof_end(1, slot, s);
   }
-  // ---- decoder weight gradients: dense GEMMs over the B*Td stashed rows ----
+  // ---- decoder weight gradients: dense GEMMs over the B*Td stashed rows, all independent -> one grouped launch ----
   {
+    TnGroup dec_group(s);
     const float* prein = ws + W.prein;
     TACO_TRY(tn(prein, kMel, kMel, gs + kGsP1, kGsRec, kPre1, G + PL.dec_pre1.w, kPre1, MD, Td, 0, s, 1, G + PL.dec_pre1.b));
     TACO_TRY(tn(st + kStP1, kStRec, kPre1, gs + kGsP2, kGsRec, kPre2, G + PL.dec_pre2.w, kPre2, MD, Td, 0, s, 1, G + PL.dec_pre2.b));
@@ -656,6 +681,7 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     TACO_TRY(tn(seq2seq_output, R80, R80, gs + kGsQ, kGsRec, kAtt, G + PL.q_w, kAtt, MD, Td, 0, s));
     TACO_TRY(tn(seq2seq_output, R80, R80, gs + kGsAtt, kGsRec, kAtt, G + PL.att_w, kAtt, MD, Td, 0, s));
     TACO_TRY(tn(st + kStCtx, kStRec, kAtt, gs + kGsAtt, kGsRec, kAtt, G + PL.att_w + (int64_t)R80 * kAtt, kAtt, MD, Td, 0, s));
+    TACO_TRY(dec_group.flush());
   }
   // ---- attention memory: dvalues[b] = alignments[b]^T . dctx[b] ; keys = values . Wm ----
   {
