@@ -42,6 +42,9 @@ def cpu_baseline(B, Tt, Td, r, V, steps=2):
     reported baseline only."""
     import numpy as np
 
+    # many tiny GEMMs inside 180-step Python loops: torch-CPU is fastest with a moderate thread count (8 threads here:
+    # 6 s/step; 128 threads on the GPU box: 21 s/step), so cap it and report the count actually used
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
     from oracle import taco_numpy as on
     from oracle import taco_torch as ot
     from tacotron_amd.data import synthetic_batch
