@@ -21,7 +21,8 @@
 namespace {
 
 constexpr int NT = 512;
-constexpr int kPartFloats = NT * 4;
+constexpr int kPartFloats = NT * 8;   // two partial-sum regions of NT*4 floats (merged rounds run two mat-vecs per barrier)
+constexpr int kPartRegion = NT * 4;
 constexpr int kMaxKG = 64;
 constexpr int kAR = 4;   // attention memory rows kept register-resident per wave
 
@@ -120,27 +121,44 @@ __device__ __forceinline__ float xsum_partials(const Xchg& X, int reg, int strid
 //   v = epi(n, y) (owner only: activation, stash writes), put(n, v) on EVERY peer (LDS state update) after the all-gather.
 // x lives in LDS and must be readable up to K rounded up to 4.  N % 4 == 0 and N/4 >= P.  Contains ONE lds_barrier();
 // the caller must __syncthreads() afterwards before `part`/x/the put() targets are reused.
-template <class Epi, class Put>
-__device__ __forceinline__ void phase(const float* __restrict__ W, int ldw, int K, int N, const float* x, float* part,
-                                      Xchg& X, int reg, Epi epi, Put put) {
-  const int tid = threadIdx.x;
-  tstamp(X, 0);
+// ---- one mat-vec phase of the cluster, in three parts so that independent mat-vecs can share an exchange round ----
+//   y[n] = sum_k x[k] * W[k*ldw + n]  for this peer's column slice;  v = epi(n, y) on the owner (activation, stash writes);
+//   put(n, v) on EVERY peer (LDS state update) once the value is known locally or gathered.
+// x lives in LDS and must be readable up to K rounded up to 4.  N % 4 == 0 and N/4 >= P.
+struct Slice {
+  int g0, n4, nloc, nbeg, rows;
+  bool shfl;
+};
+__device__ __forceinline__ Slice slice_of(const Xchg& X, int N) {
+  Slice s;
   const int N4 = N >> 2;
-  const int g0 = (X.peer * N4) / X.P, g1 = ((X.peer + 1) * N4) / X.P;
-  const int n4 = g1 - g0;
-  const int nloc = n4 * 4;
+  s.g0 = (X.peer * N4) / X.P;
+  s.n4 = ((X.peer + 1) * N4) / X.P - s.g0;
+  s.nloc = s.n4 * 4;
+  s.nbeg = s.g0 * 4;
   // k-groups: threads with equal c4 split K.  When n4 divides 64 the lanes of a wave that share c4 are reduced with
   // __shfl_xor and only 8 per-wave partials reach LDS; otherwise up to kMaxKG partial rows go through LDS.
-  const bool shfl = (64 % n4) == 0;
-  int KG = NT / n4;
-  if (!shfl && KG > kMaxKG) KG = kMaxKG;
+  s.shfl = (64 % s.n4) == 0;
+  int KG = NT / s.n4;
+  if (!s.shfl && KG > kMaxKG) KG = kMaxKG;
+  s.rows = s.shfl ? NT / 64 : KG;
+  return s;
+}
+
+// part: a kPartRegion-float LDS region private to this mat-vec until its phase_fin has run
+__device__ __forceinline__ void phase_mv(const float* __restrict__ W, int ldw, int K, int N, const float* x, float* part,
+                                         const Xchg& X) {
+  const int tid = threadIdx.x;
+  const Slice S = slice_of(X, N);
+  const int n4 = S.n4, nloc = S.nloc;
+  const int KG = S.shfl ? NT / n4 : S.rows;
   const int kg = tid / n4, c4 = tid - kg * n4;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (kg < KG) {
     const int Kc = (((K + KG - 1) / KG) + 3) & ~3;
     const int k0 = kg * Kc;
     const int k1 = min(K, k0 + Kc);
-    const float* wp = W + (int64_t)k0 * ldw + (g0 + c4) * 4;
+    const float* wp = W + (int64_t)k0 * ldw + (S.g0 + c4) * 4;
     int k = k0;
 #pragma unroll 2
     for (; k + 3 < k1; k += 4) {
@@ -162,8 +180,7 @@ __device__ __forceinline__ void phase(const float* __restrict__ W, int ldw, int 
       acc.x = fmaf(xs, w0.x, acc.x); acc.y = fmaf(xs, w0.y, acc.y); acc.z = fmaf(xs, w0.z, acc.z); acc.w = fmaf(xs, w0.w, acc.w);
     }
   }
-  int rows;  // partial rows in LDS
-  if (shfl) {
+  if (S.shfl) {
     for (int off = n4; off < 64; off <<= 1) {
       acc.x += __shfl_xor(acc.x, off, 64);
       acc.y += __shfl_xor(acc.y, off, 64);
@@ -171,37 +188,57 @@ __device__ __forceinline__ void phase(const float* __restrict__ W, int ldw, int 
       acc.w += __shfl_xor(acc.w, off, 64);
     }
     if ((tid & 63) < n4) *reinterpret_cast<float4*>(part + (tid >> 6) * nloc + c4 * 4) = acc;
-    rows = NT / 64;
   } else {
     if (kg < KG) *reinterpret_cast<float4*>(part + kg * nloc + c4 * 4) = acc;
-    rows = KG;
   }
-  tstamp(X, 1);
-  lds_barrier();
-  const int nbeg = g0 * 4;
-  for (int i = tid; i < nloc; i += NT) {
+}
+
+// after a workgroup barrier: reduce the partial rows, run the owner epilogue, update local state, publish the slice
+template <class Epi, class Put>
+__device__ __forceinline__ void phase_fin(int N, const float* part, const Xchg& X, int reg, Epi epi, Put put) {
+  const Slice S = slice_of(X, N);
+  for (int i = threadIdx.x; i < S.nloc; i += NT) {
     float y0 = 0.f, y1 = 0.f, y2 = 0.f, y3 = 0.f;
     int g = 0;
 #pragma unroll 2
-    for (; g + 3 < rows; g += 4) {
-      y0 += part[g * nloc + i];
-      y1 += part[(g + 1) * nloc + i];
-      y2 += part[(g + 2) * nloc + i];
-      y3 += part[(g + 3) * nloc + i];
+    for (; g + 3 < S.rows; g += 4) {
+      y0 += part[g * S.nloc + i];
+      y1 += part[(g + 1) * S.nloc + i];
+      y2 += part[(g + 2) * S.nloc + i];
+      y3 += part[(g + 3) * S.nloc + i];
     }
-    for (; g < rows; ++g) y0 += part[g * nloc + i];
-    const int n = nbeg + i;
+    for (; g < S.rows; ++g) y0 += part[g * S.nloc + i];
+    const int n = S.nbeg + i;
     const float v = epi(n, (y0 + y1) + (y2 + y3));
     put(n, v);
     if (X.P > 1) xput(X, reg + n, v);
   }
-  tstamp(X, 2);
+}
+
+// all-gather of the other peers' slices
+template <class Put>
+__device__ __forceinline__ void phase_gather(int N, const Xchg& X, int reg, Put put) {
   if (X.P > 1) {
-    for (int n = tid; n < N; n += NT) {
-      if (n >= nbeg && n < nbeg + nloc) continue;
+    const Slice S = slice_of(X, N);
+    for (int n = threadIdx.x; n < N; n += NT) {
+      if (n >= S.nbeg && n < S.nbeg + S.nloc) continue;
       put(n, xget(X, reg + n));
     }
   }
+}
+
+// A single mat-vec as its own exchange round.  Contains ONE workgroup barrier; the caller must barrier afterwards before
+// `part`/x/the put() targets are reused.
+template <class Epi, class Put>
+__device__ __forceinline__ void phase(const float* __restrict__ W, int ldw, int K, int N, const float* x, float* part,
+                                      Xchg& X, int reg, Epi epi, Put put) {
+  tstamp(X, 0);
+  phase_mv(W, ldw, K, N, x, part, X);
+  tstamp(X, 1);
+  lds_barrier();
+  phase_fin(N, part, X, reg, epi, put);
+  tstamp(X, 2);
+  phase_gather(N, X, reg, put);
   tstamp(X, 3);
   X.tslot++;
 }
@@ -317,37 +354,63 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
   }
   lds_barrier();
 
+  // pre_net (tacotron.py:38-44, 64-71) of step tt from the frame in S.fr: two layers, each an exchange round.  Step 0 runs
+  // them standalone here; step t+1's layers ride along with step t's query / energy rounds (they only need cell_output[t]
+  // or mel[t+1]), which removes two dependent rounds from every step.
+  auto p1_epi = [&](int64_t btt) {
+    return [&, btt](int n, float y) {
+      y = fmaxf(y + S.bias[BO_P1 + n], 0.f) * S.km1[n];
+      if (a.stash) a.stash[btt * kStRec + kStP1 + n] = y;
+      return y;
+    };
+  };
+  auto p2_epi = [&](int64_t btt) {
+    return [&, btt](int n, float y) {
+      y = fmaxf(y + S.bias[BO_P2 + n], 0.f) * S.km2[n];
+      if (a.stash) a.stash[btt * kStRec + kStP2 + n] = y;
+      return y;
+    };
+  };
+  auto p1_put = [&](int n, float v) { S.p1[n] = v; };
+  auto p2_put = [&](int n, float v) { S.xin[n] = v; };
+  {
+    const int64_t bt0 = (int64_t)b * Td;
+    X.epoch = 0x7fffffffu;   // prologue tag, distinct from every step tag
+    if (a.prein && lead && tid < kMel) a.prein[bt0 * kMel + tid] = S.fr[tid];
+    phase(w.pre_w1, kPre1, kMel, kPre1, S.fr, S.part, X, XF_P1, p1_epi(bt0), p1_put);
+    lds_barrier();
+    phase(w.pre_w2, kPre2, kPre1, kPre2, S.p1, S.part, X, XF_P2, p2_epi(bt0), p2_put);
+    lds_barrier();
+  }
+  // parked one step ahead in registers: dropout multipliers and the teacher frame of step t+1
+  float km1n = 1.f, km2n = 1.f, frn = 0.f;
+  auto park_next = [&](int tn) {   // tn = step whose pre-net inputs are fetched
+    km1n = km2n = 1.f;
+    frn = 0.f;
+    if (tn < Td) {
+      if (a.keep1 && tid < kPre1) km1n = a.keep1[((int64_t)b * Td + tn) * kPre1 + tid] ? 2.f : 0.f;
+      if (a.keep2 && tid < kPre2) km2n = a.keep2[((int64_t)b * Td + tn) * kPre2 + tid] ? 2.f : 0.f;
+      if (a.mel && tid < kMel) frn = a.mel[((int64_t)b * Td + tn) * R80 + kMel * (r - 1) + tid];
+    }
+  };
+  park_next(1);
+
   for (int t = 0; t < Td; ++t) {
     X.epoch = (unsigned)(t + 1);
-    // dropout multipliers of the NEXT step: issued now, parked in a register, written to LDS at the end of this step
-    float km1n = 1.f, km2n = 1.f;
-    if (t + 1 < Td) {
-      if (a.keep1 && tid < kPre1) km1n = a.keep1[((int64_t)b * Td + t + 1) * kPre1 + tid] ? 2.f : 0.f;
-      if (a.keep2 && tid < kPre2) km2n = a.keep2[((int64_t)b * Td + t + 1) * kPre2 + tid] ? 2.f : 0.f;
-    }
     X.trace = (a.trace && blockIdx.x == 0 && t == Td / 2) ? a.trace : nullptr;
     X.tslot = 0;
     const int64_t bt = (int64_t)b * Td + t;
     float* st = a.stash ? a.stash + bt * kStRec : nullptr;
-    if (a.prein && lead && tid < kMel) a.prein[bt * kMel + tid] = S.fr[tid];
+    const bool has_next = t + 1 < Td;
+    // helper.next_inputs (TrainingHelper / ScheduledOutputTrainingHelper / InferenceHelper): step t+1 is fed cell_output[t]
+    // at inference or when sampled, else mel[t+1]
+    const bool from_out = (a.mel == nullptr) || (a.sample && a.sample[(int64_t)t * B + b]);
+    // land the parked step-(t+1) values (step t's copies were consumed during step t-1), fetch those of step t+2
+    if (tid < kPre1) S.km1[tid] = km1n;
+    if (tid < kPre2) S.km2[tid] = km2n;
+    if (tid < kMel) S.fr[tid] = frn;
+    park_next(t + 2);
 
-    // ---- pre_net (tacotron.py:38-44, 64-71) ----
-    phase(w.pre_w1, kPre1, kMel, kPre1, S.fr, S.part, X, XF_P1,
-          [&](int n, float y) {
-            y = fmaxf(y + S.bias[BO_P1 + n], 0.f) * S.km1[n];
-            if (st) st[kStP1 + n] = y;
-            return y;
-          },
-          [&](int n, float v) { S.p1[n] = v; });
-    lds_barrier();
-    phase(w.pre_w2, kPre2, kPre1, kPre2, S.p1, S.part, X, XF_P2,
-          [&](int n, float y) {
-            y = fmaxf(y + S.bias[BO_P2 + n], 0.f) * S.km2[n];
-            if (st) st[kStP2 + n] = y;
-            return y;
-          },
-          [&](int n, float v) { S.xin[n] = v; });
-    lds_barrier();
     // ---- InputProjectionWrapper: x = [pre_net ; attention] Wi + bi (tacotron.py:56-59) ----
     phase(w.in_w, kDec, kPre2 + kAtt, kDec, S.xin, S.part, X, XF_X,
           [&](int n, float y) {
@@ -366,7 +429,7 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
       float* cl = S.cat + l * 512;
       phase(w.gw[l], 2 * kDec, 2 * kDec, 2 * kDec, cl, S.part, X, XF_G + l * 768,
             [&](int n, float y) {
-              const float g = sigmoid_f(y + S.bias[BO_G + l * 768 + n]);
+              const float g = sigmoid_fast(y + S.bias[BO_G + l * 768 + n]);
               if (n < kDec) {
                 const float rh = g * cl[kDec + n];
                 if (st) { st[kStR + l * kDec + n] = g; st[kStRH + l * kDec + n] = rh; }
@@ -382,7 +445,7 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
       lds_barrier();
       phase(w.cw[l], kDec, 2 * kDec, kDec, S.catc, S.part, X, XF_C + l * 768,
             [&](int n, float y) {
-              const float c = tanh_f(y + S.bias[BO_C + l * 768 + n]);
+              const float c = tanh_fast(y + S.bias[BO_C + l * 768 + n]);
               const float u = S.us[n];
               const float hn = u * cl[kDec + n] + (1.f - u) * c;
               if (st) {
@@ -410,15 +473,32 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
             a.out[bt * R80 + n] = y;
             return y;
           },
-          [&](int n, float v) { S.octx[n] = v; });
+          [&](int n, float v) {
+            S.octx[n] = v;
+            if (from_out && n >= kMel * (r - 1)) S.fr[n - kMel * (r - 1)] = v;   // next pre-net input = last frame of the group
+          });
     lds_barrier();
-    // ---- BahdanauAttention: query layer (no bias) ----
-    phase(w.q_w, kAtt, R80, kAtt, S.octx, S.part, X, XF_Q,
-          [&](int n, float y) {
-            if (st) st[kStQ + n] = y;
-            return y;
-          },
-          [&](int n, float v) { S.qs[n] = v; });
+    if (a.prein && lead && has_next && tid < kMel) a.prein[(bt + 1) * kMel + tid] = S.fr[tid];
+    // ---- round: BahdanauAttention query layer (no bias)  +  pre_net layer 1 of step t+1 ----
+    {
+      auto q_epi = [&](int n, float y) {
+        if (st) st[kStQ + n] = y;
+        return y;
+      };
+      auto q_put = [&](int n, float v) { S.qs[n] = v; };
+      tstamp(X, 0);
+      phase_mv(w.q_w, kAtt, R80, kAtt, S.octx, S.part, X);
+      if (has_next) phase_mv(w.pre_w1, kPre1, kMel, kPre1, S.fr, S.part + kPartRegion, X);
+      tstamp(X, 1);
+      lds_barrier();
+      phase_fin(kAtt, S.part, X, XF_Q, q_epi, q_put);
+      if (has_next) phase_fin(kPre1, S.part + kPartRegion, X, XF_P1, p1_epi(bt + 1), p1_put);
+      tstamp(X, 2);
+      phase_gather(kAtt, X, XF_Q, q_put);
+      if (has_next) phase_gather(kPre1, X, XF_P1, p1_put);
+      tstamp(X, 3);
+      X.tslot++;
+    }
     lds_barrier();
     // ---- energies e[s] = sum_u v_u tanh(keys[s,u] + q_u): one wave per memory row, rows dealt round-robin to peers ----
     {
@@ -441,12 +521,19 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
       }
       for (int s = s_first + kAR * s_stride; s < len; s += s_stride)
         score(s, reinterpret_cast<const float4*>(keys + (int64_t)s * kAtt)[lane]);
+      // same round: pre_net layer 2 of step t+1 (reads the p1 gathered in the previous round)
+      if (has_next) {
+        phase_mv(w.pre_w2, kPre2, kPre1, kPre2, S.p1, S.part, X);
+        lds_barrier();
+        phase_fin(kPre2, S.part, X, XF_P2, p2_epi(bt + 1), p2_put);
+      }
       tstamp(X, 2);
       tmark(X, 1);
       if (P > 1) {
         for (int s = tid; s < len; s += NT)
           if (s % P != X.peer) S.es[s] = xget(X, XF_E + s);
       }
+      if (has_next) phase_gather(kPre2, X, XF_P2, p2_put);
       tstamp(X, 3);
       tmark(X, 2);
       X.tslot++;
@@ -487,16 +574,6 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
             return y;
           },
           [&](int n, float v) { S.xin[kPre2 + n] = v; });
-    // ---- helper.next_inputs: TrainingHelper / ScheduledOutputTrainingHelper / InferenceHelper ----
-    if (tid < kMel && t + 1 < Td) {
-      float nf;
-      const bool from_out = (a.mel == nullptr) || (a.sample && a.sample[(int64_t)t * B + b]);
-      if (from_out) nf = S.octx[kMel * (r - 1) + tid];
-      else nf = a.mel[(bt + 1) * R80 + kMel * (r - 1) + tid];
-      S.fr[tid] = nf;
-    }
-    if (tid < kPre1) S.km1[tid] = km1n;
-    if (tid < kPre2) S.km2[tid] = km2n;
     lds_barrier();
   }
 }
