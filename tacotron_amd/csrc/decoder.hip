@@ -25,6 +25,7 @@ constexpr int kPartFloats = NT * 8;   // two partial-sum regions of NT*4 floats 
 constexpr int kPartRegion = NT * 4;
 constexpr int kMaxKG = 64;
 constexpr int kAR = 4;   // attention memory rows kept register-resident per wave
+constexpr int kKR = 13;  // rows per thread kept resident by the unit-split energy backward (NSG = 16: Tt <= 208)
 
 typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) u64 gu64;
@@ -598,6 +599,7 @@ struct DecBwdSmem {
   float* dp1;     // 256
   float* red;     // 8*256 cross-wave dq reduction
   float* rec;     // kRecFloats: this step's forward stash pieces (prefetched one step ahead)
+  float* p1prev;  // 256: pre-net layer-1 activations of the step processed before (its layer-2 backward runs one step late)
   float* als;     // TtP
   float* des;     // TtP
   int* dead;
@@ -606,7 +608,7 @@ struct DecBwdSmem {
 constexpr int RL_P1 = 0, RL_P2 = 256, RL_R = 384, RL_U = 1152, RL_C = 1920, RL_Q = 2688, RL_HP = 2944, kRecFloats = 3712;
 constexpr int kRecRegs = (kRecFloats + NT - 1) / NT;   // 8 registers per thread hold the next record in flight
 constexpr int kBwdSmemFixed = kPartFloats + 768 + 256 + 80 + 656 + 256 + 256 + 256 + 256 + 512 + 256 + 256 + 128 + 256 +
-                              8 * 256 + kRecFloats + 4;
+                              8 * 256 + kRecFloats + 256 + 4;
 
 __device__ __forceinline__ DecBwdSmem carve_bwd(float* base, int TtP) {
   DecBwdSmem s;
@@ -627,6 +629,7 @@ __device__ __forceinline__ DecBwdSmem carve_bwd(float* base, int TtP) {
   s.dp1 = p; p += 256;
   s.red = p; p += 8 * 256;
   s.rec = p; p += kRecFloats;
+  s.p1prev = p; p += 256;
   s.als = p; p += TtP;
   s.des = p; p += TtP;
   s.dead = reinterpret_cast<int*>(p); p += 4;
@@ -675,19 +678,31 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
   if (tid < 80) S.dfr[tid] = 0.f;
   for (int i = tid; i < TtP; i += NT) { S.als[i] = 0.f; S.des[i] = 0.f; }
   if (tid == 0) *S.dead = 0;
-  const float4 v4 = reinterpret_cast<const float4*>(a.att_v)[lane];
-  float4 dv4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  // Register-resident memory rows of this wave (see the forward kernel): keys, values and the dkeys accumulators.
+  // Register-resident attention memory.  d alignments (3a) is split by memory ROW: this wave's rows of `values` (as in the
+  // forward kernel).  The energy backward (3c) is split by attention UNIT: this peer owns units [ub, ub+un) of all rows, so
+  // dq needs no cross-peer partial sums; thread (ul = tid % un, sg = tid / un) walks rows s = sg, sg+NSG, ... and keeps
+  // keys[s][u] and the dkeys[s][u] accumulators of its first kKR rows in registers for the whole launch.
   const int s_first = X.peer + P * wave, s_stride = P * (NT / 64);
-  float4 kres[kAR], vres[kAR], dkacc[kAR];
+  float4 vres[kAR];
 #pragma unroll
   for (int i = 0; i < kAR; ++i) {
     const int s = s_first + i * s_stride;
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    kres[i] = s < len ? reinterpret_cast<const float4*>(keys + (int64_t)s * kAtt)[lane] : z;
-    vres[i] = s < len ? reinterpret_cast<const float4*>(values + (int64_t)s * kAtt)[lane] : z;
-    dkacc[i] = z;
+    vres[i] = s < len ? reinterpret_cast<const float4*>(values + (int64_t)s * kAtt)[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  const Slice US = slice_of(X, kAtt);
+  const int ub = US.nbeg, un = US.nloc;
+  const int NSG = NT / un;                       // row groups
+  const int ul = tid % un, sg = tid / un;        // sg >= NSG: idle thread (un does not divide NT)
+  const bool uact = sg < NSG;
+  const float vu = a.att_v[ub + ul];
+  float kr[kKR], dkr[kKR];
+#pragma unroll
+  for (int i = 0; i < kKR; ++i) {
+    const int s = sg + i * NSG;
+    kr[i] = (uact && s < len) ? keys[(int64_t)s * kAtt + ub + ul] : 0.f;
+    dkr[i] = 0.f;
+  }
+  float dvu = 0.f;                               // d attention_v[ub + ul] partial of this thread
   // Prefetch registers: the record / output gradient / alignment row of the step about to be processed.
   float pre[kRecRegs];
   float pre_dout = 0.f, pre_al = 0.f;
@@ -700,6 +715,20 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
     if (tid < Tt) pre_al = a.align[bt * Tt + tid];
   }
   lds_barrier();
+
+  // The pre-net backward of a step (p2T, p1T) is off the critical path: it runs one step late, inside the attT / d-alignment
+  // exchange rounds of the next processed step.  `pend` = such a deferred pair exists (from step t+1).
+  bool pend = false;
+  float* gs_pend = nullptr;
+  const float km1c = a.keep1 ? 2.f : 1.f;
+  auto p2T_epi = [&](int n, float y) {
+    const float g = S.p1prev[n] > 0.f ? km1c * y : 0.f;
+    gs_pend[kGsP1 + n] = g;
+    return g;
+  };
+  auto p2T_put = [&](int n, float v) { S.dp1[n] = v; };
+  auto p1T_epi = [&](int n, float y) { return y; };
+  auto p1T_put = [&](int n, float v) { S.dfr[n] = v; };
 
   for (int t = Td - 1; t >= 0; --t) {
     X.epoch = (unsigned)(Td - t);
@@ -716,11 +745,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
     for (int i = 0; i < kRecRegs; ++i)
       if (tid + i * NT < kRecFloats) S.rec[tid + i * NT] = pre[i];
     // 1. d cell_output: direct (loss + post-net) + sampled next-input path (replicated on every peer)
-    if (tid < R80) {
-      float g = pre_dout;
-      if (next_from_out && tid >= kMel * (r - 1)) g += S.dfr[tid - kMel * (r - 1)];
-      S.dov[tid] = g;
-    }
+    if (tid < R80) S.dov[tid] = pre_dout;   // the sampled next-input path (dfr of step t+1) is added after round 2
     if (tid < Tt) S.als[tid] = pre_al;
     for (int s = tid + NT; s < Tt; s += NT) S.als[s] = a.align[bt * Tt + s];
     if (lead && tid < kAtt) gs[kGsAtt + tid] = S.datt[tid];
@@ -731,14 +756,28 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
       if (tid < Tt) pre_al = a.align[(bt - 1) * Tt + tid];
     }
     lds_barrier();
-    // 2. attention layer: d[o ; ctx] += datt . Wa^T      (wT.att_w is (256, 80r+256))
-    phase(w.att_w, R80 + kAtt, kAtt, R80 + kAtt, S.datt, S.part, X, XB_ATT,
-          [&](int n, float y) {
-            if (n < R80) return S.dov[n] + y;
-            gs[kGsCtx + n - R80] = y;
-            return y;
-          },
-          [&](int n, float v) { S.dov[n] = v; });
+    // 2. round: attention layer d[o ; ctx] += datt . Wa^T (wT.att_w is (256, 80r+256))  +  deferred pre-net layer 2 of
+    //    step t+1: dp1 = dp2pre . W2^T (wT.pre_w2 is (128, 256))
+    {
+      auto att_epi = [&](int n, float y) {
+        if (n < R80) return S.dov[n] + y;
+        gs[kGsCtx + n - R80] = y;
+        return y;
+      };
+      auto att_put = [&](int n, float v) { S.dov[n] = v; };
+      tstamp(X, 0);
+      phase_mv(w.att_w, R80 + kAtt, kAtt, R80 + kAtt, S.datt, S.part, X);
+      if (pend) phase_mv(w.pre_w2, kPre1, kPre2, kPre1, S.dp2, S.part + kPartRegion, X);
+      tstamp(X, 1);
+      lds_barrier();
+      phase_fin(R80 + kAtt, S.part, X, XB_ATT, att_epi, att_put);
+      if (pend) phase_fin(kPre1, S.part + kPartRegion, X, XB_P2, p2T_epi, p2T_put);
+      tstamp(X, 2);
+      phase_gather(R80 + kAtt, X, XB_ATT, att_put);
+      if (pend) phase_gather(kPre1, X, XB_P2, p2T_put);
+      tstamp(X, 3);
+      X.tslot++;
+    }
     lds_barrier();
     // 3a. d alignments[s] = values[s] . dctx   (memory rows dealt round-robin to peers)
     {
@@ -759,15 +798,25 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
       }
       for (int s = s_first + kAR * s_stride; s < len; s += s_stride)
         dal(s, reinterpret_cast<const float4*>(values + (int64_t)s * kAtt)[lane]);
+      // same round: deferred pre-net layer 1 input gradient of step t+1 (only when step t+1 was fed cell_output[t])
+      const bool do_p1T = pend && next_from_out;
+      if (do_p1T) {
+        phase_mv(w.pre_w1, kMel, kPre1, kMel, S.dp1, S.part, X);
+        lds_barrier();
+        phase_fin(kMel, S.part, X, XB_P1, p1T_epi, p1T_put);
+      }
       tmark(X, 11);
       if (P > 1) {
         for (int s = tid; s < len; s += NT)
           if (s % P != X.peer) S.des[s] = xget(X, XB_DAL + s);
       }
+      if (do_p1T) phase_gather(kMel, X, XB_P1, p1T_put);
       tmark(X, 12);
     }
     lds_barrier();
     tmark(X, 13);
+    // d cell_output[t] += d(pre-net input of step t+1) on the last frame of the group (sampled rows only)
+    if (pend && next_from_out && tid < kMel) S.dov[kMel * (r - 1) + tid] += S.dfr[tid];
     // 3b. softmax backward: de = al * (dal - sum al*dal)   (every wave computes the dot redundantly)
     {
       float dot = 0.f;
@@ -778,45 +827,49 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
     }
     lds_barrier();
     tmark(X, 14);
-    // 3c. energy backward on this peer's rows: th = tanh(keys+q); dpre = de*v*(1-th^2); dq += dpre; dkeys += dpre; dv += de*th
+    // 3c. energy backward on this peer's UNITS over all rows: th = tanh(keys+q); dpre = de*v*(1-th^2);
+    //     dq[u] = sum_s dpre; dkeys[s,u] += dpre; dv[u] += de*th
     {
-      const float4 q4 = reinterpret_cast<const float4*>(S.rec + RL_Q)[lane];
-      float4 dq4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      auto ebwd = [&](int s, float4 k4, float4 dk) {
-        const float de = S.des[s];
-        const float t0 = tanh_fast(k4.x + q4.x), t1 = tanh_fast(k4.y + q4.y), t2 = tanh_fast(k4.z + q4.z), t3 = tanh_fast(k4.w + q4.w);
-        const float p0 = de * v4.x * (1.f - t0 * t0), p1 = de * v4.y * (1.f - t1 * t1);
-        const float p2 = de * v4.z * (1.f - t2 * t2), p3 = de * v4.w * (1.f - t3 * t3);
-        dq4.x += p0; dq4.y += p1; dq4.z += p2; dq4.w += p3;
-        dk.x += p0; dk.y += p1; dk.z += p2; dk.w += p3;
-        dv4.x += de * t0; dv4.y += de * t1; dv4.z += de * t2; dv4.w += de * t3;
-        return dk;
-      };
+      float dqa = 0.f;
+      if (uact) {
+        const float qu = S.rec[RL_Q + ub + ul];
 #pragma unroll
-      for (int i = 0; i < kAR; ++i) {
-        const int s = s_first + i * s_stride;
-        if (s < len) dkacc[i] = ebwd(s, kres[i], dkacc[i]);
+        for (int i = 0; i < kKR; ++i) {
+          const int s = sg + i * NSG;
+          if (s < len) {
+            const float de = S.des[s];
+            const float th = tanh_fast(kr[i] + qu);
+            const float pre = de * vu * (1.f - th * th);
+            dqa += pre;
+            dkr[i] += pre;
+            dvu += de * th;
+          }
+        }
+        for (int s = sg + kKR * NSG; s < len; s += NSG) {   // rows beyond the resident set: read-modify-write in memory
+          const float de = S.des[s];
+          const float th = tanh_fast(keys[(int64_t)s * kAtt + ub + ul] + qu);
+          const float pre = de * vu * (1.f - th * th);
+          dqa += pre;
+          dkeys[(int64_t)s * kAtt + ub + ul] += pre;
+          dvu += de * th;
+        }
+        S.red[sg * un + ul] = dqa;
       }
-      for (int s = s_first + kAR * s_stride; s < len; s += s_stride) {   // rows beyond the resident set: RMW in memory
-        float4 dk = reinterpret_cast<float4*>(dkeys + (int64_t)s * kAtt)[lane];
-        dk = ebwd(s, reinterpret_cast<const float4*>(keys + (int64_t)s * kAtt)[lane], dk);
-        reinterpret_cast<float4*>(dkeys + (int64_t)s * kAtt)[lane] = dk;
-      }
-      reinterpret_cast<float4*>(S.red + wave * 256)[lane] = dq4;
       tmark(X, 15);
     }
     lds_barrier();
     tmark(X, 16);
-    if (tid < kAtt) {
-      float d = 0.f;
-#pragma unroll
-      for (int i = 0; i < NT / 64; ++i) d += S.red[i * 256 + tid];
-      if (P > 1) {
-        xput(X, XB_DQP + X.peer * 256 + tid, d);
-        d = xsum_partials(X, XB_DQP, 256, tid, d);
+    {
+      auto dq_put = [&](int n, float v) { S.dq[n] = v; };
+      if (tid < un) {
+        float dsum = 0.f;
+        for (int g = 0; g < NSG; ++g) dsum += S.red[g * un + tid];
+        const int n = ub + tid;
+        S.dq[n] = dsum;
+        gs[kGsQ + n] = dsum;
+        if (P > 1) xput(X, XB_DQP + n, dsum);
       }
-      S.dq[tid] = d;
-      if (lead) gs[kGsQ + tid] = d;
+      phase_gather(kAtt, X, XB_DQP, dq_put);
     }
     tmark(X, 17);
     lds_barrier();
@@ -909,36 +962,33 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
             else S.datt[n - kPre2] = v;
           });
     lds_barrier();
-    // 8. pre-net layer 2: dp1 = dp2pre . W2^T   (wT.pre_w2 is (128, 256))
-    phase(w.pre_w2, kPre1, kPre2, kPre1, S.dp2, S.part, X, XB_P2,
-          [&](int n, float y) {
-            const float g = S.rec[RL_P1 + n] > 0.f ? km1 * y : 0.f;
-            gs[kGsP1 + n] = g;
-            return g;
-          },
-          [&](int n, float v) { S.dp1[n] = v; });
+    // 8./9. pre-net layers 2 and 1 backward of THIS step are deferred into the next processed step's rounds 2 and 3a
+    if (tid < kPre1) S.p1prev[tid] = S.rec[RL_P1 + tid];
+    pend = true;
+    gs_pend = gs;
     lds_barrier();
-    // 9. pre-net layer 1 input gradient, only when this step's input was the previous cell_output
-    if (this_from_out) {
-      phase(w.pre_w1, kMel, kPre1, kMel, S.dp1, S.part, X, XB_P1, [&](int n, float y) { return y; },
-            [&](int n, float v) { S.dfr[n] = v; });
-      lds_barrier();
+  }
+  // deferred pre-net layer 2 of step 0 (its layer-1 input gradient is not needed: nothing precedes step 0)
+  if (pend) {
+    X.epoch = (unsigned)(Td + 1);
+    phase(w.pre_w2, kPre1, kPre2, kPre1, S.dp2, S.part, X, XB_P2, p2T_epi, p2T_put);
+    lds_barrier();
+  }
+  // resident dkeys accumulators -> memory (each (row, unit) is owned by exactly one thread of one peer)
+  if (uact) {
+#pragma unroll
+    for (int i = 0; i < kKR; ++i) {
+      const int s = sg + i * NSG;
+      if (s < len) dkeys[(int64_t)s * kAtt + ub + ul] = dkr[i];
     }
+    S.red[sg * un + ul] = dvu;
   }
-  // resident dkeys accumulators -> memory (each row is owned by exactly one wave of one peer)
-#pragma unroll
-  for (int i = 0; i < kAR; ++i) {
-    const int s = s_first + i * s_stride;
-    if (s < len) reinterpret_cast<float4*>(dkeys + (int64_t)s * kAtt)[lane] = dkacc[i];
-  }
-  // attention_v gradient: reduce per-lane partials across waves, then one atomic per element
-  reinterpret_cast<float4*>(S.red + wave * 256)[lane] = dv4;
+  // attention_v gradient: reduce the row groups, one atomic per owned unit
   lds_barrier();
-  if (tid < kAtt) {
-    float d = 0.f;
-#pragma unroll
-    for (int i = 0; i < NT / 64; ++i) d += S.red[i * 256 + tid];
-    atomicAdd(&a.datt_v[tid], d);
+  if (tid < un) {
+    float dsum = 0.f;
+    for (int g = 0; g < NSG; ++g) dsum += S.red[g * un + tid];
+    atomicAdd(&a.datt_v[ub + tid], dsum);
   }
 }
 
