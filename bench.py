@@ -135,6 +135,29 @@ def main():
     bwd_ms = lib.profile_read(1)
     loss = float(model.loss)
 
+    # ---- inference (BASELINE configs[3]: prompt -> mel -> linear, Tt=140 as data_input.MAX_TEXT_LEN, always Td steps) ----
+    infer = None
+    if rank == 0 and world == 1:
+        ci = Config()
+        ci.r, ci.vocab_size, ci.num_speakers = 2, 60, args.speakers
+        ci.max_decode_iter = Td
+        infer = {}
+        for Bi in (1, 32):
+            bi = synthetic_batch(Bi, 140, Td, ci.r, ci.vocab_size, seed=77, min_len=40, num_speakers=args.speakers)
+            mi = Tacotron(ci, bi, train=False, params=None, seed=0)
+            for _ in range(2):
+                mi.run()
+            torch.cuda.synchronize()
+            ti = time.perf_counter()
+            n_it = 5
+            for _ in range(n_it):
+                mi.run()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - ti) / n_it * 1e3
+            infer['B%d' % Bi] = {'ms_per_batch': ms, 'mel_frames_per_s': Bi * Td * ci.r / (ms * 1e-3)}
+            del mi
+        infer['shape'] = 'Tt=140, Td=%d steps (r=2 -> %d frames/utt), full forward incl. post-net + linear' % (Td, Td * 2)
+
     if rank == 0:
         frames = world * B * Td * c.r
         fa = sum(fwd_ms) / max(1, len(fwd_ms))
@@ -168,6 +191,8 @@ def main():
                            'us_per_decoder_step_fwd': fa * 1e3 / Td, 'us_per_decoder_step_bwd': ba * 1e3 / Td},
             'final_loss': loss,
         }
+        if infer:
+            res['inference'] = infer
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(B, Tt, Td, c.r, c.vocab_size)
         print(json.dumps(res), flush=True)
