@@ -244,6 +244,37 @@ def test_backward_without_masks_and_ragged_lengths(built_lib):
     assert not bad, bad
 
 
+@pytest.mark.parametrize('cluster', ['8', '4', '2', '1'])
+def test_long_text_and_cluster_widths(built_lib, cluster, monkeypatch):
+    """Tt = 300 (> 256) leaves the register-resident attention rows and exercises the streamed fall-back paths of both
+    decoder kernels; TACO_DEC_CLUSTER forces the narrower cluster widths used when B * 8 workgroups are not co-resident;
+    B = 1 is the single-prompt inference shape."""
+    monkeypatch.setenv('TACO_DEC_CLUSTER', cluster)
+    r, V, B, Tt, Td = 2, 25, 2, 300, 4
+    p = on.init_params(V, r, seed=6, perturb=0.2)
+    inp, masks = small_case(r=r, V=V, B=B, Tt=Tt, Td=Td, seed=12)
+    inp['text_length'][:] = [300, 211]
+    inp['text'][1, 211:] = 0
+    R = Runner(built_lib, B, Tt, Td, r, V)
+    R.set(p, inp, masks)
+    R.forward()
+    R.backward()
+    lt, s2, o2, a2, ref = ot.loss_and_grads(p, f64(inp), r, Td, f64(masks))
+    assert report('s2s (Tt=300, P=%s)' % cluster, R.s2s.cpu().numpy(), s2)[0] < 1e-5
+    assert report('out', R.out.cpu().numpy(), o2)[0] < 1e-5
+    assert report('align', R.al.cpu().numpy(), a2)[1] < 1e-6
+    bad = check_grads(R, ref)
+    assert not bad, bad
+    # single-row inference
+    R1 = Runner(built_lib, 1, Tt, Td, r, V, train=False)
+    R1.set(p, {'text': inp['text'][:1], 'text_length': inp['text_length'][:1]})
+    R1.infer()
+    s1, o1, a1, _ = on.forward({k: v for k, v in p.items()}, {'text': inp['text'][:1], 'text_length': inp['text_length'][:1]},
+                               r, Td, False)
+    assert report('B=1 infer out', R1.out.cpu().numpy(), o1)[0] < 1e-5
+    assert report('B=1 infer align', R1.al.cpu().numpy(), a1)[1] < 1e-6
+
+
 def test_medium_shape_forward_backward(built_lib):
     """B=4, Tt=37, Td=12: multi-tile GEMMs, several attention rows per wave, sampling + dropout masks."""
     r, V, B, Tt, Td = 2, 40, 4, 37, 12
