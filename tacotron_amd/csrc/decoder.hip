@@ -126,6 +126,13 @@ __device__ __forceinline__ float xsum_partials(const Xchg& X, int reg, int strid
 //   y[n] = sum_k x[k] * W[k*ldw + n]  for this peer's column slice;  v = epi(n, y) on the owner (activation, stash writes);
 //   put(n, v) on EVERY peer (LDS state update) once the value is known locally or gathered.
 // x lives in LDS and must be readable up to K rounded up to 4.  N % 4 == 0 and N/4 >= P.
+// threadIdx.x behind an opaque move: everything a phase derives from it (slice coordinates, weight pointers) is then
+// recomputed per phase instead of being hoisted out of the step loop into ~100 long-lived registers
+__device__ __forceinline__ int opaque_tid() {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
 struct Slice {
   int g0, n4, nloc, nbeg, rows;
   bool shfl;
@@ -146,10 +153,38 @@ __device__ __forceinline__ Slice slice_of(const Xchg& X, int N) {
   return s;
 }
 
+// Cross-round weight prefetch: the first kPF rows (float4 each) of this thread's k-chunk of the NEXT mat-vec, fetched
+// into registers right after the current round's slice has been published, i.e. while the all-gather is in flight.  The
+// weights are data independent, so the next mat-vec then starts as pure FMAs instead of an exposed L2 round trip.
+constexpr int kPF = 8;
+struct Pref {
+  float4 w[kPF];
+  const float* W = nullptr;   // which matrix the registers hold (tag checked by phase_mv)
+};
+__device__ __forceinline__ void prefetch_w(Pref& pf, const float* __restrict__ W, int ldw, int K, int N, const Xchg& X) {
+  const int tid = opaque_tid();
+  const Slice S = slice_of(X, N);
+  const int KG = S.shfl ? NT / S.n4 : S.rows;
+  const int kg = tid / S.n4, c4 = tid - kg * S.n4;
+  pf.W = W;
+  if (kg < KG) {
+    const int Kc = (((K + KG - 1) / KG) + 3) & ~3;
+    const int k0 = kg * Kc;
+    const int k1 = min(K, k0 + Kc);
+    const float* wp = W + (S.g0 + c4) * 4;
+#pragma unroll
+    for (int i = 0; i < kPF; ++i) {
+      const bool ok = k0 + i < k1;
+      pf.w[i] = *reinterpret_cast<const float4*>(wp + (int64_t)(ok ? k0 + i : 0) * ldw);   // clamped address, value unused if !ok
+    }
+  }
+}
+
 // part: a kPartRegion-float LDS region private to this mat-vec until its phase_fin has run
-__device__ __forceinline__ void phase_mv(const float* __restrict__ W, int ldw, int K, int N, const float* x, float* part,
-                                         const Xchg& X) {
-  const int tid = threadIdx.x;
+template <bool PF>
+__device__ __forceinline__ void phase_mv_impl(const float* __restrict__ W, int ldw, int K, int N, const float* x,
+                                              float* part, const Xchg& X, const Pref& pf) {
+  const int tid = opaque_tid();
   const Slice S = slice_of(X, N);
   const int n4 = S.n4, nloc = S.nloc;
   const int KG = S.shfl ? NT / n4 : S.rows;
@@ -161,6 +196,21 @@ __device__ __forceinline__ void phase_mv(const float* __restrict__ W, int ldw, i
     const int k1 = min(K, k0 + Kc);
     const float* wp = W + (int64_t)k0 * ldw + (S.g0 + c4) * 4;
     int k = k0;
+    if (PF && pf.W == W) {   // rows k0 .. k0+kPF-1 are already in registers (as far as whole groups of 4 exist)
+#pragma unroll
+      for (int g = 0; g < kPF / 4; ++g) {
+        if (k + 3 < k1) {
+          const float4 xv = *reinterpret_cast<const float4*>(x + k);
+          const float4 w0 = pf.w[4 * g + 0], w1 = pf.w[4 * g + 1], w2 = pf.w[4 * g + 2], w3 = pf.w[4 * g + 3];
+          acc.x = fmaf(xv.x, w0.x, acc.x); acc.y = fmaf(xv.x, w0.y, acc.y); acc.z = fmaf(xv.x, w0.z, acc.z); acc.w = fmaf(xv.x, w0.w, acc.w);
+          acc.x = fmaf(xv.y, w1.x, acc.x); acc.y = fmaf(xv.y, w1.y, acc.y); acc.z = fmaf(xv.y, w1.z, acc.z); acc.w = fmaf(xv.y, w1.w, acc.w);
+          acc.x = fmaf(xv.z, w2.x, acc.x); acc.y = fmaf(xv.z, w2.y, acc.y); acc.z = fmaf(xv.z, w2.z, acc.z); acc.w = fmaf(xv.z, w2.w, acc.w);
+          acc.x = fmaf(xv.w, w3.x, acc.x); acc.y = fmaf(xv.w, w3.y, acc.y); acc.z = fmaf(xv.w, w3.z, acc.z); acc.w = fmaf(xv.w, w3.w, acc.w);
+          k += 4;
+          wp += 4 * (int64_t)ldw;
+        }
+      }
+    }
 #pragma unroll 2
     for (; k + 3 < k1; k += 4) {
       const float4 xv = *reinterpret_cast<const float4*>(x + k);
@@ -195,6 +245,16 @@ __device__ __forceinline__ void phase_mv(const float* __restrict__ W, int ldw, i
 }
 
 // after a workgroup barrier: reduce the partial rows, run the owner epilogue, update local state, publish the slice
+__device__ __forceinline__ void phase_mv(const float* __restrict__ W, int ldw, int K, int N, const float* x, float* part,
+                                         const Xchg& X) {
+  Pref none;
+  phase_mv_impl<false>(W, ldw, K, N, x, part, X, none);
+}
+__device__ __forceinline__ void phase_mv(const float* __restrict__ W, int ldw, int K, int N, const float* x, float* part,
+                                         const Xchg& X, const Pref& pf) {
+  phase_mv_impl<true>(W, ldw, K, N, x, part, X, pf);
+}
+
 template <class Epi, class Put>
 __device__ __forceinline__ void phase_fin(int N, const float* part, const Xchg& X, int reg, Epi epi, Put put) {
   const Slice S = slice_of(X, N);
@@ -230,6 +290,26 @@ __device__ __forceinline__ void phase_gather(int N, const Xchg& X, int reg, Put 
 
 // A single mat-vec as its own exchange round.  Contains ONE workgroup barrier; the caller must barrier afterwards before
 // `part`/x/the put() targets are reused.
+// next mat-vec to prefetch (weights only), or W == nullptr
+struct NextMv {
+  const float* W = nullptr;
+  int ldw = 0, K = 0, N = 0;
+};
+template <class Epi, class Put>
+__device__ __forceinline__ void phase(const float* __restrict__ W, int ldw, int K, int N, const float* x, float* part,
+                                      Xchg& X, int reg, Epi epi, Put put, Pref& pf, NextMv nx) {
+  tstamp(X, 0);
+  phase_mv(W, ldw, K, N, x, part, X, pf);
+  tstamp(X, 1);
+  lds_barrier();
+  phase_fin(N, part, X, reg, epi, put);
+  tstamp(X, 2);
+  if (nx.W) prefetch_w(pf, nx.W, nx.ldw, nx.K, nx.N, X);
+  phase_gather(N, X, reg, put);
+  tstamp(X, 3);
+  X.tslot++;
+}
+
 template <class Epi, class Put>
 __device__ __forceinline__ void phase(const float* __restrict__ W, int ldw, int K, int N, const float* x, float* part,
                                       Xchg& X, int reg, Epi epi, Put put) {
@@ -374,13 +454,16 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
   };
   auto p1_put = [&](int n, float v) { S.p1[n] = v; };
   auto p2_put = [&](int n, float v) { S.xin[n] = v; };
+  Pref pf;   // next round's first weight rows, fetched during the current round's all-gather
+  const NextMv nx_in{w.in_w, kDec, kPre2 + kAtt, kDec}, nx_out{w.out_w, R80, kDec, R80}, nx_q{w.q_w, kAtt, R80, kAtt},
+      nx_att{w.att_w, kAtt, R80 + kAtt, kAtt};
   {
     const int64_t bt0 = (int64_t)b * Td;
     X.epoch = 0x7fffffffu;   // prologue tag, distinct from every step tag
     if (a.prein && lead && tid < kMel) a.prein[bt0 * kMel + tid] = S.fr[tid];
     phase(w.pre_w1, kPre1, kMel, kPre1, S.fr, S.part, X, XF_P1, p1_epi(bt0), p1_put);
     lds_barrier();
-    phase(w.pre_w2, kPre2, kPre1, kPre2, S.p1, S.part, X, XF_P2, p2_epi(bt0), p2_put);
+    phase(w.pre_w2, kPre2, kPre1, kPre2, S.p1, S.part, X, XF_P2, p2_epi(bt0), p2_put, pf, nx_in);
     lds_barrier();
   }
   // parked one step ahead in registers: dropout multipliers and the teacher frame of step t+1
@@ -423,7 +506,8 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
             S.xs[n] = v;
             S.cat[n] = v;
             S.catc[n] = v;
-          });
+          },
+          pf, NextMv{w.gw[0], 2 * kDec, 2 * kDec, 2 * kDec});
     lds_barrier();
     // ---- MultiRNNCell[GRUCell(256) x3] inside ONE ResidualWrapper (tacotron.py:54-58) ----
     for (int l = 0; l < 3; ++l) {
@@ -442,7 +526,8 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
             [&](int n, float v) {
               if (n < kDec) S.catc[kDec + n] = v;   // r * h
               else S.us[n - kDec] = v;              // u
-            });
+            },
+            pf, NextMv{w.cw[l], kDec, 2 * kDec, kDec});
       lds_barrier();
       phase(w.cw[l], kDec, 2 * kDec, kDec, S.catc, S.part, X, XF_C + l * 768,
             [&](int n, float y) {
@@ -464,7 +549,8 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
               } else {
                 S.ys[n] = S.xs[n] + hn;
               }
-            });
+            },
+            pf, l < 2 ? NextMv{w.gw[l + 1], 2 * kDec, 2 * kDec, 2 * kDec} : nx_out);
       lds_barrier();
     }
     // ---- OutputProjectionWrapper: cell_output = (x + h3) Wo + bo (tacotron.py:54-60) ----
@@ -477,7 +563,8 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
           [&](int n, float v) {
             S.octx[n] = v;
             if (from_out && n >= kMel * (r - 1)) S.fr[n - kMel * (r - 1)] = v;   // next pre-net input = last frame of the group
-          });
+          },
+          pf, nx_q);
     lds_barrier();
     if (a.prein && lead && has_next && tid < kMel) a.prein[(bt + 1) * kMel + tid] = S.fr[tid];
     // ---- round: BahdanauAttention query layer (no bias)  +  pre_net layer 1 of step t+1 ----
@@ -488,13 +575,15 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
       };
       auto q_put = [&](int n, float v) { S.qs[n] = v; };
       tstamp(X, 0);
-      phase_mv(w.q_w, kAtt, R80, kAtt, S.octx, S.part, X);
+      phase_mv(w.q_w, kAtt, R80, kAtt, S.octx, S.part, X, pf);
       if (has_next) phase_mv(w.pre_w1, kPre1, kMel, kPre1, S.fr, S.part + kPartRegion, X);
       tstamp(X, 1);
       lds_barrier();
       phase_fin(kAtt, S.part, X, XF_Q, q_epi, q_put);
       if (has_next) phase_fin(kPre1, S.part + kPartRegion, X, XF_P1, p1_epi(bt + 1), p1_put);
       tstamp(X, 2);
+      if (has_next) prefetch_w(pf, w.pre_w2, kPre2, kPre1, kPre2, X);
+      else prefetch_w(pf, values, kAtt, len, kAtt, X);
       phase_gather(kAtt, X, XF_Q, q_put);
       if (has_next) phase_gather(kPre1, X, XF_P1, p1_put);
       tstamp(X, 3);
@@ -524,9 +613,10 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
         score(s, reinterpret_cast<const float4*>(keys + (int64_t)s * kAtt)[lane]);
       // same round: pre_net layer 2 of step t+1 (reads the p1 gathered in the previous round)
       if (has_next) {
-        phase_mv(w.pre_w2, kPre2, kPre1, kPre2, S.p1, S.part, X);
+        phase_mv(w.pre_w2, kPre2, kPre1, kPre2, S.p1, S.part, X, pf);
         lds_barrier();
         phase_fin(kPre2, S.part, X, XF_P2, p2_epi(bt + 1), p2_put);
+        prefetch_w(pf, values, kAtt, len, kAtt, X);
       }
       tstamp(X, 2);
       tmark(X, 1);
@@ -566,7 +656,7 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
             if (st) st[kStCtx + n] = y;
             return y;
           },
-          [&](int n, float v) { S.octx[R80 + n] = v; });
+          [&](int n, float v) { S.octx[R80 + n] = v; }, pf, nx_att);
     lds_barrier();
     // ---- attention = [cell_output ; context] Wa (attention_layer_size=256, no bias; tacotron.py:76) ----
     phase(w.att_w, kAtt, R80 + kAtt, kAtt, S.octx, S.part, X, XF_ATT,
@@ -574,7 +664,7 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
             if (st) st[kStAtt + n] = y;
             return y;
           },
-          [&](int n, float v) { S.xin[kPre2 + n] = v; });
+          [&](int n, float v) { S.xin[kPre2 + n] = v; }, pf, has_next ? nx_in : NextMv());
     lds_barrier();
   }
 }
