@@ -819,6 +819,10 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
   auto p2T_put = [&](int n, float v) { S.dp1[n] = v; };
   auto p1T_epi = [&](int n, float y) { return y; };
   auto p1T_put = [&](int n, float v) { S.dfr[n] = v; };
+  Pref pf;   // next round's first weight rows, fetched during the current round's all-gather
+  const NextMv nx_att{w.att_w, R80 + kAtt, kAtt, R80 + kAtt}, nx_out{w.out_w, kDec, R80, kDec},
+      nx_in{w.in_w, kPre2 + kAtt, kDec, kPre2 + kAtt};
+  prefetch_w(pf, nx_att.W, nx_att.ldw, nx_att.K, nx_att.N, X);
 
   for (int t = Td - 1; t >= 0; --t) {
     X.epoch = (unsigned)(Td - t);
@@ -856,7 +860,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
       };
       auto att_put = [&](int n, float v) { S.dov[n] = v; };
       tstamp(X, 0);
-      phase_mv(w.att_w, R80 + kAtt, kAtt, R80 + kAtt, S.datt, S.part, X);
+      phase_mv(w.att_w, R80 + kAtt, kAtt, R80 + kAtt, S.datt, S.part, X, pf);
       if (pend) phase_mv(w.pre_w2, kPre1, kPre2, kPre1, S.dp2, S.part + kPartRegion, X);
       tstamp(X, 1);
       lds_barrier();
@@ -959,6 +963,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
         gs[kGsQ + n] = dsum;
         if (P > 1) xput(X, XB_DQP + n, dsum);
       }
+      prefetch_w(pf, w.q_w, R80, kAtt, R80, X);
       phase_gather(kAtt, X, XB_DQP, dq_put);
     }
     tmark(X, 17);
@@ -971,14 +976,15 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
             gs[kGsO + n] = g;
             return g;
           },
-          [&](int n, float v) { S.dov[n] = v; });
+          [&](int n, float v) { S.dov[n] = v; }, pf, nx_out);
     lds_barrier();
     // 5. output projection: dy = do . Wo^T   (wT.out_w is (80r, 256))
     phase(w.out_w, kDec, R80, kDec, S.dov, S.part, X, XB_OUT, [&](int n, float y) { return y; },
           [&](int n, float v) {
             S.dy[n] = v;
             S.dht[n] = S.dh[2 * kDec + n] + v;   // dL/dh3' = carried + residual path
-          });
+          },
+          pf, NextMv{w.cw[2], 2 * kDec, kDec, 2 * kDec});
     lds_barrier();
     // 6. GRU layers, top down
     for (int l = 2; l >= 0; --l) {
@@ -1021,7 +1027,8 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
                 S.dgp[i] = y * HPl[i] * rr * (1.f - rr);
                 S.dh[l * kDec + i] = S.dht[i] * Ul[i] + y * rr;   // partial new carry: dht*u + d(rh)*r
               }
-            });
+            },
+            pf, NextMv{w.gw[l], 2 * kDec, 2 * kDec, 2 * kDec});
       lds_barrier();
       // [d inp ; d h] += dgp . Wg^T       (wT.gw[l] is (512, 512))
       phase(w.gw[l], 2 * kDec, 2 * kDec, 2 * kDec, S.dgp, S.part, X, XB_G + l * 1024, [&](int n, float y) { return y; },
@@ -1033,7 +1040,8 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
               } else {
                 S.dh[l * kDec + n - kDec] += y;
               }
-            });
+            },
+            pf, l > 0 ? NextMv{w.cw[l - 1], 2 * kDec, kDec, 2 * kDec} : nx_in);
       lds_barrier();
     }
     if (lead && tid < kDec) gs[kGsX + tid] = S.dx[tid];
@@ -1050,7 +1058,8 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
           [&](int n, float v) {
             if (n < kPre2) S.dp2[n] = v;
             else S.datt[n - kPre2] = v;
-          });
+          },
+          pf, t > 0 ? nx_att : NextMv());
     lds_barrier();
     // 8./9. pre-net layers 2 and 1 backward of THIS step are deferred into the next processed step's rounds 2 and 3a
     if (tid < kPre1) S.p1prev[tid] = S.rec[RL_P1 + tid];
