@@ -325,24 +325,31 @@ __device__ __forceinline__ void phase(const float* __restrict__ W, int ldw, int 
 }
 
 // ---- forward exchange regions (granule indices within a row's area) ----
-constexpr int XF_P1 = 0, XF_P2 = 256, XF_X = 384, XF_G = 640 /* +l*768 */, XF_C = 1152 /* +l*768 */, XF_O = 2944,
-              XF_Q = 3344, XF_CTX = 3600, XF_ATT = 3856, XF_E = 4112;
+constexpr int XF_P1 = 0, XF_P2 = 256, XF_X = 384, XF_G = 640 /* +l*768 */, XF_C = 1152 /* +l*768 */, XF_O = 2944 /* NO <= 1024 */,
+              XF_CTX = 3968, XF_E = 4224;
 // ---- backward exchange regions ----
 constexpr int XB_ATT = 0, XB_DQP = 656, XB_Q = 2704, XB_OUT = 3104, XB_C = 3360 /* +l*1024 */, XB_G = 3872 /* +l*1024 */,
               XB_IN = 6432, XB_P2 = 6816, XB_P1 = 7072, XB_DAL = 7200;
 constexpr int kXchgFixed = 7200;
 
+// Forward step, 9 exchange rounds (DecComposite folds the purely linear links of the reference's cell, tacotron.py:54-60,73-76):
+//   G0   x = [p2 ; out' ; ctx'] Wx + bi   and   gates_1 = sigmoid([p2 ; out' ; ctx' ; h1] Wg0' + bg0')     (' = previous step)
+//   C0   candidate_1 / h1            G1 C1 G2 C2  likewise for GRU 2, 3 (plain weights)
+//   OUT  [q | cell_output] = (x + h3) [Wo Wq | Wo] + ...    and   pre_net layer 1 of step t+1
+//   E    energies (all-gather) + softmax   and   pre_net layer 2 of step t+1
+//   CTX  context = alignments . values
+// The AttentionWrapper's attention vector [cell_output ; context] Wa is never formed: it only feeds the next step's input
+// projection, and Wa Wi_a is part of Wx.
 struct DecSmem {
   float* part;   // kPartFloats
   float* fr;     // 80   pre-net input frame
   float* p1;     // 256
-  float* xin;    // 384  [p2 ; attention]
+  float* u0;     // 128+80r+256+256  [p2 ; cell_output ; context ; h1]: input of round G0
   float* xs;     // 256  in-proj output (residual)
-  float* cat;    // 3*512 [layer input ; h_l]
+  float* cat;    // 3*512 [layer input ; h_l] (l = 1, 2; slot 0 unused)
   float* catc;   // 512  [layer input ; r*h_l]
   float* us;     // 256
   float* ys;     // 256
-  float* octx;   // 656  [cell_output (80r) ; context (256)]
   float* qs;     // 256
   float* es;     // TtP energies
   float* als;    // TtP alignments
@@ -352,8 +359,9 @@ struct DecSmem {
   int* dead;
 };
 // bias staging offsets
-constexpr int BO_P1 = 0, BO_P2 = 256, BO_IN = 384, BO_G = 640 /* +l*768 */, BO_C = 1152 /* +l*768 */, BO_O = 2944;
-constexpr int kBiasFloats = 3344;
+constexpr int BO_P1 = 0, BO_P2 = 256, BO_IN = 384, BO_G = 640 /* +l*768 */, BO_C = 1152 /* +l*768 */, BO_P1O = 2944, BO_O = 3200;
+constexpr int kBiasFloats = 3200 + 1024;
+constexpr int kU0Max = kPre2 + kMel * 5 + kAtt + kDec;
 
 __device__ __forceinline__ DecSmem carve(float* base, int TtP) {
   DecSmem s;
@@ -361,13 +369,12 @@ __device__ __forceinline__ DecSmem carve(float* base, int TtP) {
   s.part = p; p += kPartFloats;
   s.fr = p; p += 80;
   s.p1 = p; p += 256;
-  s.xin = p; p += 384;
+  s.u0 = p; p += kU0Max;
   s.xs = p; p += 256;
   s.cat = p; p += 3 * 512;
   s.catc = p; p += 512;
   s.us = p; p += 256;
   s.ys = p; p += 256;
-  s.octx = p; p += 656;
   s.qs = p; p += 256;
   s.es = p; p += TtP;
   s.als = p; p += TtP;
@@ -378,7 +385,7 @@ __device__ __forceinline__ DecSmem carve(float* base, int TtP) {
   return s;
 }
 constexpr int kFwdSmemFixed =
-    kPartFloats + 80 + 256 + 384 + 256 + 3 * 512 + 512 + 256 + 256 + 656 + 256 + kBiasFloats + 256 + 128 + 4;
+    kPartFloats + 80 + 256 + kU0Max + 256 + 3 * 512 + 512 + 256 + 256 + 256 + kBiasFloats + 256 + 128 + 4;
 
 __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -387,9 +394,12 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
   const int b = blockIdx.x / P;
   const int B = a.B, Tt = a.Tt, Td = a.Td, r = a.r;
   const int R80 = kMel * r;
+  const int KX = kPre2 + R80 + kAtt;   // rows of Wx;  u0 = [p2 (0) ; out (128) ; ctx (128+R80) ; h1 (KX)]
+  const int NO = a.c.NO;
   const int TtP = (Tt + 3) & ~3;
   DecSmem S = carve(smem, TtP);
   const DecWeights& w = a.w;
+  const DecComposite& cw = a.c;
   Xchg X;
   X.P = P;
   X.peer = blockIdx.x - b * P;
@@ -405,22 +415,25 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
   len = len < 1 ? 1 : (len > Tt ? Tt : len);
   const float* keys = a.keys + (int64_t)b * Tt * kAtt;
   const float* values = a.values + (int64_t)b * Tt * kAtt;
+  float* const u_out = S.u0 + kPre2;
+  float* const u_ctx = S.u0 + kPre2 + R80;
+  float* const h1 = S.u0 + KX;
 
-  // zero state (AttentionWrapper.zero_state, tacotron.py:94)
+  // zero state (AttentionWrapper.zero_state, tacotron.py:94): h = 0, attention = 0 (<=> previous output and context 0)
   for (int i = tid; i < 3 * 512; i += NT) S.cat[i] = 0.f;
-  for (int i = tid; i < 384; i += NT) S.xin[i] = 0.f;
+  for (int i = tid; i < KX + kDec; i += NT) S.u0[i] = 0.f;
   for (int i = tid; i < TtP; i += NT) { S.als[i] = 0.f; S.es[i] = 0.f; }
-  for (int i = tid; i < 656; i += NT) S.octx[i] = 0.f;
   if (tid < kMel) S.fr[tid] = a.mel ? a.mel[((int64_t)b * Td) * R80 + kMel * (r - 1) + tid] : 0.f;
   if (tid == 0) *S.dead = 0;
   for (int i = tid; i < kPre1; i += NT) S.bias[BO_P1 + i] = w.pre_b1[i];
+  for (int i = tid; i < kPre1; i += NT) S.bias[BO_P1O + i] = cw.bp1o[i];
   for (int i = tid; i < kPre2; i += NT) S.bias[BO_P2 + i] = w.pre_b2[i];
   for (int i = tid; i < kDec; i += NT) S.bias[BO_IN + i] = w.in_b[i];
   for (int l = 0; l < 3; ++l) {
-    for (int i = tid; i < 2 * kDec; i += NT) S.bias[BO_G + l * 768 + i] = w.gb[l][i];
+    for (int i = tid; i < 2 * kDec; i += NT) S.bias[BO_G + l * 768 + i] = l == 0 ? cw.bg0[i] : w.gb[l][i];
     for (int i = tid; i < kDec; i += NT) S.bias[BO_C + l * 768 + i] = w.cb[l][i];
   }
-  for (int i = tid; i < R80; i += NT) S.bias[BO_O + i] = w.out_b[i];
+  for (int i = tid; i < NO; i += NT) S.bias[BO_O + i] = cw.bo[i];
   if (tid < kPre1) S.km1[tid] = a.keep1 ? (a.keep1[((int64_t)b * Td) * kPre1 + tid] ? 2.f : 0.f) : 1.f;
   if (tid < kPre2) S.km2[tid] = a.keep2 ? (a.keep2[((int64_t)b * Td) * kPre2 + tid] ? 2.f : 0.f) : 1.f;
   const float4 v4 = reinterpret_cast<const float4*>(w.att_v)[lane];
@@ -435,12 +448,12 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
   }
   lds_barrier();
 
-  // pre_net (tacotron.py:38-44, 64-71) of step tt from the frame in S.fr: two layers, each an exchange round.  Step 0 runs
-  // them standalone here; step t+1's layers ride along with step t's query / energy rounds (they only need cell_output[t]
-  // or mel[t+1]), which removes two dependent rounds from every step.
-  auto p1_epi = [&](int64_t btt) {
-    return [&, btt](int n, float y) {
-      y = fmaxf(y + S.bias[BO_P1 + n], 0.f) * S.km1[n];
+  // pre_net (tacotron.py:38-44, 64-71) of step tt: two layers, each an exchange round.  Step 0 runs them standalone here;
+  // step t+1's layers ride along with step t's OUT / E rounds, which removes two dependent rounds from every step.
+  // Layer 1 of a step fed by the previous cell_output (sampled / inference) is computed from (x + h3) with Wo[:, frame] W1.
+  auto p1_epi = [&](int64_t btt, int bofs) {
+    return [&, btt, bofs](int n, float y) {
+      y = fmaxf(y + S.bias[bofs + n], 0.f) * S.km1[n];
       if (a.stash) a.stash[btt * kStRec + kStP1 + n] = y;
       return y;
     };
@@ -453,17 +466,16 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
     };
   };
   auto p1_put = [&](int n, float v) { S.p1[n] = v; };
-  auto p2_put = [&](int n, float v) { S.xin[n] = v; };
+  auto p2_put = [&](int n, float v) { S.u0[n] = v; };
   Pref pf;   // next round's first weight rows, fetched during the current round's all-gather
-  const NextMv nx_in{w.in_w, kDec, kPre2 + kAtt, kDec}, nx_out{w.out_w, R80, kDec, R80}, nx_q{w.q_w, kAtt, R80, kAtt},
-      nx_att{w.att_w, kAtt, R80 + kAtt, kAtt};
+  const NextMv nx_x{cw.wx, kDec, KX, kDec}, nx_o{cw.wo, NO, kDec, NO};
   {
     const int64_t bt0 = (int64_t)b * Td;
     X.epoch = 0x7fffffffu;   // prologue tag, distinct from every step tag
     if (a.prein && lead && tid < kMel) a.prein[bt0 * kMel + tid] = S.fr[tid];
-    phase(w.pre_w1, kPre1, kMel, kPre1, S.fr, S.part, X, XF_P1, p1_epi(bt0), p1_put);
+    phase(w.pre_w1, kPre1, kMel, kPre1, S.fr, S.part, X, XF_P1, p1_epi(bt0, BO_P1), p1_put);
     lds_barrier();
-    phase(w.pre_w2, kPre2, kPre1, kPre2, S.p1, S.part, X, XF_P2, p2_epi(bt0), p2_put, pf, nx_in);
+    phase(w.pre_w2, kPre2, kPre1, kPre2, S.p1, S.part, X, XF_P2, p2_epi(bt0), p2_put, pf, nx_x);
     lds_barrier();
   }
   // parked one step ahead in registers: dropout multipliers and the teacher frame of step t+1
@@ -495,45 +507,75 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
     if (tid < kMel) S.fr[tid] = frn;
     park_next(t + 2);
 
-    // ---- InputProjectionWrapper: x = [pre_net ; attention] Wi + bi (tacotron.py:56-59) ----
-    phase(w.in_w, kDec, kPre2 + kAtt, kDec, S.xin, S.part, X, XF_X,
-          [&](int n, float y) {
-            y += S.bias[BO_IN + n];
-            if (st) st[kStX + n] = y;
-            return y;
-          },
-          [&](int n, float v) {
-            S.xs[n] = v;
-            S.cat[n] = v;
-            S.catc[n] = v;
-          },
-          pf, NextMv{w.gw[0], 2 * kDec, 2 * kDec, 2 * kDec});
+    // ---- round G0: InputProjectionWrapper x = [pre_net ; attention] Wi + bi (tacotron.py:56-59) with the attention layer
+    //      folded in, and GRU-1's gates straight from x's inputs ----
+    {
+      auto x_epi = [&](int n, float y) {
+        y += S.bias[BO_IN + n];
+        if (st) st[kStX + n] = y;
+        return y;
+      };
+      auto x_put = [&](int n, float v) {
+        S.xs[n] = v;
+        S.catc[n] = v;
+      };
+      auto g_epi = [&](int n, float y) {
+        const float g = sigmoid_fast(y + S.bias[BO_G + n]);
+        if (n < kDec) {
+          const float rh = g * h1[n];
+          if (st) { st[kStR + n] = g; st[kStRH + n] = rh; }
+          return rh;
+        }
+        if (st) st[kStU + n - kDec] = g;
+        return g;
+      };
+      auto g_put = [&](int n, float v) {
+        if (n < kDec) S.catc[kDec + n] = v;   // r * h
+        else S.us[n - kDec] = v;              // u
+      };
+      tstamp(X, 0);
+      phase_mv(cw.wx, kDec, KX, kDec, S.u0, S.part, X, pf);
+      phase_mv(cw.wg0, 2 * kDec, KX + kDec, 2 * kDec, S.u0, S.part + kPartRegion, X);
+      tstamp(X, 1);
+      lds_barrier();
+      phase_fin(kDec, S.part, X, XF_X, x_epi, x_put);
+      phase_fin(2 * kDec, S.part + kPartRegion, X, XF_G, g_epi, g_put);
+      tstamp(X, 2);
+      prefetch_w(pf, w.cw[0], kDec, 2 * kDec, kDec, X);
+      phase_gather(kDec, X, XF_X, x_put);
+      phase_gather(2 * kDec, X, XF_G, g_put);
+      tstamp(X, 3);
+      X.tslot++;
+    }
     lds_barrier();
     // ---- MultiRNNCell[GRUCell(256) x3] inside ONE ResidualWrapper (tacotron.py:54-58) ----
     for (int l = 0; l < 3; ++l) {
-      float* cl = S.cat + l * 512;
-      phase(w.gw[l], 2 * kDec, 2 * kDec, 2 * kDec, cl, S.part, X, XF_G + l * 768,
-            [&](int n, float y) {
-              const float g = sigmoid_fast(y + S.bias[BO_G + l * 768 + n]);
-              if (n < kDec) {
-                const float rh = g * cl[kDec + n];
-                if (st) { st[kStR + l * kDec + n] = g; st[kStRH + l * kDec + n] = rh; }
-                return rh;
-              }
-              if (st) st[kStU + l * kDec + n - kDec] = g;
-              return g;
-            },
-            [&](int n, float v) {
-              if (n < kDec) S.catc[kDec + n] = v;   // r * h
-              else S.us[n - kDec] = v;              // u
-            },
-            pf, NextMv{w.cw[l], kDec, 2 * kDec, kDec});
-      lds_barrier();
+      float* cl = S.cat + l * 512;                 // [layer input ; h_l] (l >= 1)
+      float* hl = l == 0 ? h1 : cl + kDec;
+      if (l > 0) {
+        phase(w.gw[l], 2 * kDec, 2 * kDec, 2 * kDec, cl, S.part, X, XF_G + l * 768,
+              [&](int n, float y) {
+                const float g = sigmoid_fast(y + S.bias[BO_G + l * 768 + n]);
+                if (n < kDec) {
+                  const float rh = g * hl[n];
+                  if (st) { st[kStR + l * kDec + n] = g; st[kStRH + l * kDec + n] = rh; }
+                  return rh;
+                }
+                if (st) st[kStU + l * kDec + n - kDec] = g;
+                return g;
+              },
+              [&](int n, float v) {
+                if (n < kDec) S.catc[kDec + n] = v;   // r * h
+                else S.us[n - kDec] = v;              // u
+              },
+              pf, NextMv{w.cw[l], kDec, 2 * kDec, kDec});
+        lds_barrier();
+      }
       phase(w.cw[l], kDec, 2 * kDec, kDec, S.catc, S.part, X, XF_C + l * 768,
             [&](int n, float y) {
               const float c = tanh_fast(y + S.bias[BO_C + l * 768 + n]);
               const float u = S.us[n];
-              const float hn = u * cl[kDec + n] + (1.f - u) * c;
+              const float hn = u * hl[n] + (1.f - u) * c;
               if (st) {
                 st[kStC + l * kDec + n] = c;
                 st[kStH + l * kDec + n] = hn;
@@ -542,7 +584,7 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
               return hn;
             },
             [&](int n, float hn) {
-              cl[kDec + n] = hn;
+              hl[n] = hn;
               if (l < 2) {
                 S.cat[(l + 1) * 512 + n] = hn;
                 S.catc[n] = hn;
@@ -550,47 +592,54 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
                 S.ys[n] = S.xs[n] + hn;
               }
             },
-            pf, l < 2 ? NextMv{w.gw[l + 1], 2 * kDec, 2 * kDec, 2 * kDec} : nx_out);
+            pf, l < 2 ? NextMv{w.gw[l + 1], 2 * kDec, 2 * kDec, 2 * kDec} : nx_o);
       lds_barrier();
     }
-    // ---- OutputProjectionWrapper: cell_output = (x + h3) Wo + bo (tacotron.py:54-60) ----
-    phase(w.out_w, R80, kDec, R80, S.ys, S.part, X, XF_O,
-          [&](int n, float y) {
-            y += S.bias[BO_O + n];
-            a.out[bt * R80 + n] = y;
-            return y;
-          },
-          [&](int n, float v) {
-            S.octx[n] = v;
-            if (from_out && n >= kMel * (r - 1)) S.fr[n - kMel * (r - 1)] = v;   // next pre-net input = last frame of the group
-          },
-          pf, nx_q);
-    lds_barrier();
-    if (a.prein && lead && has_next && tid < kMel) a.prein[(bt + 1) * kMel + tid] = S.fr[tid];
-    // ---- round: BahdanauAttention query layer (no bias)  +  pre_net layer 1 of step t+1 ----
+    // ---- round OUT: OutputProjectionWrapper cell_output = (x + h3) Wo + bo (tacotron.py:54-60), the BahdanauAttention
+    //      query layer q = cell_output Wq (no bias of its own) folded to (x + h3) Wo Wq + bo Wq, and pre_net layer 1 of
+    //      step t+1 ----
     {
-      auto q_epi = [&](int n, float y) {
-        if (st) st[kStQ + n] = y;
+      auto o_epi = [&](int n, float y) {
+        y += S.bias[BO_O + n];
+        if (n < kAtt) {
+          if (st) st[kStQ + n] = y;
+        } else if (n < kAtt + R80) {
+          a.out[bt * R80 + n - kAtt] = y;
+        }
         return y;
       };
-      auto q_put = [&](int n, float v) { S.qs[n] = v; };
+      auto o_put = [&](int n, float v) {
+        if (n < kAtt) {
+          S.qs[n] = v;
+        } else if (n < kAtt + R80) {
+          const int c = n - kAtt;
+          u_out[c] = v;
+          if (from_out && c >= kMel * (r - 1)) S.fr[c - kMel * (r - 1)] = v;   // next pre-net input = last frame of the group
+        }
+      };
+      const int p1b = from_out ? BO_P1O : BO_P1;
       tstamp(X, 0);
-      phase_mv(w.q_w, kAtt, R80, kAtt, S.octx, S.part, X, pf);
-      if (has_next) phase_mv(w.pre_w1, kPre1, kMel, kPre1, S.fr, S.part + kPartRegion, X);
+      phase_mv(cw.wo, NO, kDec, NO, S.ys, S.part, X, pf);
+      if (has_next) {
+        if (from_out) phase_mv(cw.wp1o, kPre1, kDec, kPre1, S.ys, S.part + kPartRegion, X);
+        else phase_mv(w.pre_w1, kPre1, kMel, kPre1, S.fr, S.part + kPartRegion, X);
+      }
       tstamp(X, 1);
       lds_barrier();
-      phase_fin(kAtt, S.part, X, XF_Q, q_epi, q_put);
-      if (has_next) phase_fin(kPre1, S.part + kPartRegion, X, XF_P1, p1_epi(bt + 1), p1_put);
+      phase_fin(NO, S.part, X, XF_O, o_epi, o_put);
+      if (has_next) phase_fin(kPre1, S.part + kPartRegion, X, XF_P1, p1_epi(bt + 1, p1b), p1_put);
       tstamp(X, 2);
       if (has_next) prefetch_w(pf, w.pre_w2, kPre2, kPre1, kPre2, X);
       else prefetch_w(pf, values, kAtt, len, kAtt, X);
-      phase_gather(kAtt, X, XF_Q, q_put);
+      phase_gather(NO, X, XF_O, o_put);
       if (has_next) phase_gather(kPre1, X, XF_P1, p1_put);
       tstamp(X, 3);
       X.tslot++;
     }
     lds_barrier();
-    // ---- energies e[s] = sum_u v_u tanh(keys[s,u] + q_u): one wave per memory row, rows dealt round-robin to peers ----
+    if (a.prein && lead && has_next && tid < kMel) a.prein[(bt + 1) * kMel + tid] = S.fr[tid];
+    // ---- round E: energies e[s] = sum_u v_u tanh(keys[s,u] + q_u): one wave per memory row, rows dealt round-robin to
+    //      peers;  same round: pre_net layer 2 of step t+1 ----
     {
       tstamp(X, 0);
       tmark(X, 0);
@@ -611,7 +660,6 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
       }
       for (int s = s_first + kAR * s_stride; s < len; s += s_stride)
         score(s, reinterpret_cast<const float4*>(keys + (int64_t)s * kAtt)[lane]);
-      // same round: pre_net layer 2 of step t+1 (reads the p1 gathered in the previous round)
       if (has_next) {
         phase_mv(w.pre_w2, kPre2, kPre1, kPre2, S.p1, S.part, X, pf);
         lds_barrier();
@@ -649,22 +697,14 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
     tmark(X, 4);
     lds_barrier();
     tmark(X, 5);
-    // ---- context = alignments . values ----
+    // ---- round CTX: context = alignments . values ----
     tstamp(X, 1);   // (slot of the ctx phase, stamp 1 is overwritten; the softmax end shows as stamp 0 of ctx)
     phase(values, kAtt, len, kAtt, S.als, S.part, X, XF_CTX,
           [&](int n, float y) {
             if (st) st[kStCtx + n] = y;
             return y;
           },
-          [&](int n, float v) { S.octx[R80 + n] = v; }, pf, nx_att);
-    lds_barrier();
-    // ---- attention = [cell_output ; context] Wa (attention_layer_size=256, no bias; tacotron.py:76) ----
-    phase(w.att_w, kAtt, R80 + kAtt, kAtt, S.octx, S.part, X, XF_ATT,
-          [&](int n, float y) {
-            if (st) st[kStAtt + n] = y;
-            return y;
-          },
-          [&](int n, float v) { S.xin[kPre2 + n] = v; }, pf, has_next ? nx_in : NextMv());
+          [&](int n, float v) { u_ctx[n] = v; }, pf, has_next ? nx_x : NextMv());
     lds_barrier();
   }
 }

@@ -124,6 +124,24 @@ int launch_bigru_bwd(const float* dout, const float* out, const float* ruc, cons
                      float* dxg, float* rh, float* dh0, int B, int T, hipStream_t s);
 
 // ---------------------------------------------------------------- decoder.hip
+// Columns of the decoder's merged [query | cell_output | pad] projection: a power of two so every cluster width slices it
+// into wave-reducible column groups.
+inline int dec_out_cols(int r) {
+  int n = 512;
+  while (n < kAtt + kMel * r) n *= 2;
+  return n;
+}
+// Composite forward weights (workspace; products of consecutive linear maps, see model.hip build_dec_composites)
+struct DecComposite {
+  const float* wx;     // (128+80r+256, 256)   x = [p2 ; out ; ctx] wx + in_b
+  const float* wg0;    // (128+80r+256+256, 512)  gates_0 pre-activation = [p2 ; out ; ctx ; h0] wg0 + bg0
+  const float* bg0;    // (512)
+  const float* wo;     // (256, NO)  [q | out | 0] = (x + h3) wo + bo
+  const float* bo;     // (NO)
+  const float* wp1o;   // (256, 256)  pre_net layer 1 of a step fed by the previous cell_output, straight from (x + h3)
+  const float* bp1o;   // (256)
+  int NO;
+};
 struct DecWeights {
   const float *pre_w1, *pre_b1, *pre_w2, *pre_b2;  // (80,256) (256,128)
   const float *in_w, *in_b;                        // (384,256)
@@ -161,6 +179,7 @@ constexpr int kGsRec = 4112;
 
 struct DecFwdArgs {
   DecWeights w;
+  DecComposite c;
   const float* keys;     // (B,Tt,256)
   const float* values;   // (B,Tt,256)
   const int32_t* text_length;

@@ -83,6 +83,8 @@ struct WsLayout {
   CbhgWs enc;
   int64_t values, keys;
   int64_t stash, prein, xchg, err;
+  // decoder composite weights (products of consecutive linear maps; rebuilt every call, see build_dec_composites)
+  int64_t dc_wx, dc_wg0, dc_bg0, dc_wo, dc_bo, dc_wp1o, dc_bp1o;
   CbhgWs post;
   int64_t wd_pad;
   int64_t loss;  // 4 floats

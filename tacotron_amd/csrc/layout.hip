@@ -216,6 +216,16 @@ void build_ws_layout(const TacoShape& s, bool train, const TransLayout& T, WsLay
   W.prein = train ? a.add("dec.prein", {MD, kMel}) : -1;
   W.xchg = a.add("dec.xchg", {decoder_xchg_bytes(s.B, s.Tt) / 4});
   W.err = a.add("dec.err", {512});   // [0],[1] error words; floats 16.. = optional phase trace
+  {
+    const int KX = kPre2 + R80 + kAtt, NO = dec_out_cols(s.r);
+    W.dc_wx = a.add("dec.comp.wx", {KX, kDec});                 // [Wi_p ; Wa Wi_a]: x = [p2 ; out ; ctx] Wx + bi
+    W.dc_wg0 = a.add("dec.comp.wg0", {KX + kDec, 2 * kDec});    // [Wx Wg0_x ; Wg0_h]
+    W.dc_bg0 = a.add("dec.comp.bg0", {2 * kDec});               // bg0 + bi Wg0_x
+    W.dc_wo = a.add("dec.comp.wo", {kDec, NO});                 // [Wo Wq | Wo | 0]
+    W.dc_bo = a.add("dec.comp.bo", {NO});                       // [bo Wq | bo | 0]
+    W.dc_wp1o = a.add("dec.comp.wp1o", {kDec, kPre1});          // Wo[:, last frame] W1
+    W.dc_bp1o = a.add("dec.comp.bp1o", {kPre1});                // bo[last frame] W1 + b1
+  }
   ws_cbhg(a, "post.", P.post, M2, s.B, train, W.post);
   W.wd_pad = a.add("post.wd_pad", {2 * kCb, 1028});   // post/dense kernel re-pitched to a 16-byte-aligned leading dimension
   W.loss = a.add("loss", {4});

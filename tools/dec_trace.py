@@ -17,7 +17,7 @@ torch.cuda.synchronize()
 tab = {n: (o, s) for n, o, s, d in lib.workspace_table(m.shape, True)}
 o, s = tab['dec.err']
 tr = m.workspace[o + 16:o + 16 + 4 * 2 * 20].view(torch.int64).cpu().numpy().reshape(-1, 4)
-names = ['x', 'g0', 'c0', 'g1', 'c1', 'g2', 'c2', 'out', 'q+p1n', 'e+p2n', 'ctx', 'att']
+names = ['g0+x', 'c0', 'g1', 'c1', 'g2', 'c2', 'out+q+p1n', 'e+p2n', 'ctx']
 t0 = tr[0, 0]
 print('phase   start_us  matvec  barrier+finalize  gather   total   (wall_clock64 = 100 MHz ticks)')
 for i, n in enumerate(names):
