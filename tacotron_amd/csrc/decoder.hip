@@ -75,47 +75,29 @@ __device__ __forceinline__ void tmark(const Xchg& X, int id) {
   }
 }
 
-// Sum of the P peers' partial values for element `idx` (own partial `own` already published at reg + peer*stride + idx).
-// All remote granules are polled concurrently; the sum runs in peer order so every peer gets the bit-identical result.
-__device__ __forceinline__ float xsum_partials(const Xchg& X, int reg, int stride, int idx, float own) {
-  constexpr int MAXP = 8;
-  float v[MAXP];
-  bool ok[MAXP];
-#pragma unroll
-  for (int p = 0; p < MAXP; ++p) {
-    ok[p] = (p >= X.P) || (p == X.peer);
-    v[p] = (p == X.peer) ? own : 0.f;
-  }
-  if (!*X.dead) {
-    for (unsigned spin = 0;; ++spin) {
-      bool all = true;
-#pragma unroll
-      for (int p = 0; p < MAXP; ++p) {
-        if (!ok[p]) {
-          const u64 x = __hip_atomic_load((gu64*)(X.base + reg + p * stride + idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((unsigned)(x >> 32) == X.epoch) {
-            v[p] = __uint_as_float((unsigned)x);
-            ok[p] = true;
-          } else {
-            all = false;
-          }
-        }
+// Two granules polled concurrently (a merged round gathers two vectors: polling them one after the other would cost two
+// dependent fabric round trips).  needA / needB: whether this thread has a granule to fetch at all.
+__device__ __forceinline__ void xget2(const Xchg& X, int idxA, bool needA, int idxB, bool needB, float& vA, float& vB) {
+  vA = vB = 0.f;
+  if (*X.dead) return;
+  gu64* gA = (gu64*)(X.base + idxA);
+  gu64* gB = (gu64*)(X.base + idxB);
+  for (unsigned spin = 0; needA || needB; ++spin) {
+    u64 xa = 0, xb = 0;
+    if (needA) xa = __hip_atomic_load(gA, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (needB) xb = __hip_atomic_load(gB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (needA && (unsigned)(xa >> 32) == X.epoch) { vA = __uint_as_float((unsigned)xa); needA = false; }
+    if (needB && (unsigned)(xb >> 32) == X.epoch) { vB = __uint_as_float((unsigned)xb); needB = false; }
+    if (!(needA || needB)) break;
+    if ((spin & 1023u) == 1023u) {
+      if (spin > (1u << 23) || __hip_atomic_load((gi32*)X.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        __hip_atomic_store((gi32*)X.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *X.dead = 1;
+        return;
       }
-      if (all) break;
-      if ((spin & 1023u) == 1023u) {
-        if (spin > (1u << 23) || __hip_atomic_load((gi32*)X.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-          __hip_atomic_store((gi32*)X.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          *X.dead = 1;
-          break;
-        }
-      }
-      __builtin_amdgcn_s_sleep(1);
     }
+    __builtin_amdgcn_s_sleep(1);
   }
-  float s = 0.f;
-#pragma unroll
-  for (int p = 0; p < MAXP; ++p) s += v[p];
-  return s;
 }
 
 // One mat-vec phase of the cluster:  y[n] = sum_k x[k] * W[k*ldw + n]  for this peer's column slice, then
@@ -284,6 +266,25 @@ __device__ __forceinline__ void phase_gather(int N, const Xchg& X, int reg, Put 
     for (int n = threadIdx.x; n < N; n += NT) {
       if (n >= S.nbeg && n < S.nbeg + S.nloc) continue;
       put(n, xget(X, reg + n));
+    }
+  }
+}
+
+// all-gather of two vectors published in the same round (NB <= NT); the two granules of a thread are polled concurrently
+template <class PutA, class PutB>
+__device__ __forceinline__ void phase_gather2(int NA, int regA, PutA putA, int NB, int regB, PutB putB, const Xchg& X) {
+  if (X.P > 1) {
+    const Slice SA = slice_of(X, NA), SB = slice_of(X, NB);
+    const int n = threadIdx.x;
+    const bool needA = n < NA && !(n >= SA.nbeg && n < SA.nbeg + SA.nloc);
+    const bool needB = n < NB && !(n >= SB.nbeg && n < SB.nbeg + SB.nloc);
+    float vA, vB;
+    xget2(X, regA + n, needA, regB + n, needB, vA, vB);
+    if (needA) putA(n, vA);
+    if (needB) putB(n, vB);
+    for (int m = n + NT; m < NA; m += NT) {
+      if (m >= SA.nbeg && m < SA.nbeg + SA.nloc) continue;
+      putA(m, xget(X, regA + m));
     }
   }
 }
@@ -542,8 +543,7 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
       phase_fin(2 * kDec, S.part + kPartRegion, X, XF_G, g_epi, g_put);
       tstamp(X, 2);
       prefetch_w(pf, w.cw[0], kDec, 2 * kDec, kDec, X);
-      phase_gather(kDec, X, XF_X, x_put);
-      phase_gather(2 * kDec, X, XF_G, g_put);
+      phase_gather2(2 * kDec, XF_G, g_put, kDec, XF_X, x_put, X);
       tstamp(X, 3);
       X.tslot++;
     }
@@ -631,8 +631,7 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
       tstamp(X, 2);
       if (has_next) prefetch_w(pf, w.pre_w2, kPre2, kPre1, kPre2, X);
       else prefetch_w(pf, values, kAtt, len, kAtt, X);
-      phase_gather(NO, X, XF_O, o_put);
-      if (has_next) phase_gather(kPre1, X, XF_P1, p1_put);
+      phase_gather2(NO, XF_O, o_put, has_next ? kPre1 : 0, XF_P1, p1_put, X);
       tstamp(X, 3);
       X.tslot++;
     }
@@ -668,11 +667,17 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
       }
       tstamp(X, 2);
       tmark(X, 1);
-      if (P > 1) {
-        for (int s = tid; s < len; s += NT)
+      if (P > 1) {   // energies of the other peers' rows and their slices of p2, polled concurrently
+        const Slice SB = slice_of(X, kPre2);
+        const bool needA = tid < len && tid % P != X.peer;
+        const bool needB = has_next && tid < kPre2 && !(tid >= SB.nbeg && tid < SB.nbeg + SB.nloc);
+        float vA, vB;
+        xget2(X, XF_E + tid, needA, XF_P2 + tid, needB, vA, vB);
+        if (needA) S.es[tid] = vA;
+        if (needB) p2_put(tid, vB);
+        for (int s = tid + NT; s < len; s += NT)
           if (s % P != X.peer) S.es[s] = xget(X, XF_E + s);
       }
-      if (has_next) phase_gather(kPre2, X, XF_P2, p2_put);
       tstamp(X, 3);
       tmark(X, 2);
       X.tslot++;
