@@ -329,8 +329,8 @@ __device__ __forceinline__ void phase(const float* __restrict__ W, int ldw, int 
 constexpr int XF_P1 = 0, XF_P2 = 256, XF_X = 384, XF_G = 640 /* +l*768 */, XF_C = 1152 /* +l*768 */, XF_O = 2944 /* NO <= 1024 */,
               XF_CTX = 3968, XF_E = 4224;
 // ---- backward exchange regions ----
-constexpr int XB_ATT = 0, XB_DQP = 656, XB_Q = 2704, XB_OUT = 3104, XB_C = 3360 /* +l*1024 */, XB_G = 3872 /* +l*1024 */,
-              XB_IN = 6432, XB_P2 = 6816, XB_P1 = 7072, XB_DAL = 7200;
+constexpr int XB_FA = 0 /* NO <= 1024 */, XB_DP2 = 1024, XB_P2 = 1152, XB_DQP = 1408, XB_OUT = 1664, XB_C = 1920 /* +l*1024 */,
+              XB_G = 2432 /* +l*1024 */, XB_DAL = 7200;
 constexpr int kXchgFixed = 7200;
 
 // Forward step, 9 exchange rounds (DecComposite folds the purely linear links of the reference's cell, tacotron.py:54-60,73-76):
@@ -717,24 +717,30 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
 // ------------------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------------------
+// Backward step, 10 exchange rounds, mirroring the folded forward step:
+//   FAN   [d ctx_t | d out_t] += dx_{t+1} [Wx_c^T | Wx_o^T]   and   d p2_{t+1} = dx_{t+1} Wi_p^T  (pre_net of step t+1, one step late)
+//   DAL   d alignments (all-gather)   and   d p1_{t+1} = d p2pre_{t+1} W2^T
+//   DQ    softmax / energy backward (unit split), dq all-gather
+//   OUT   d(x + h3) = [d out ; dq ; d p1pre_{t+1} (if step t+1 was fed out_t)] [Wo^T ; (Wo Wq)^T ; (Wo_f W1)^T]
+//   C2 G2 C1 G1 C0 G0   GRU layers top down; G0 leaves dx_t
+// The gradients the folded links skip (d attention, total d cell_output) are only needed for WEIGHT gradients and are
+// recovered there from small products (model.hip).
 struct DecBwdSmem {
   float* part;    // kPartFloats
   float* dh;      // 3*256 carried dL/dh_l
-  float* datt;    // 256 carried dL/d attention_{t}
-  float* dfr;     // 80  dL/d next step's pre-net input frame
-  float* dov;     // 656 [d cell_output (80r) ; d context (256)]
-  float* dq;      // 256
+  float* dx;      // 256  dL/dx of the step processed before (t+1) until round G0 overwrites it with this step's
+  float* vo;      // 80r+512  [d cell_output (direct) ; dq ; d p1pre_{t+1}]: input of round OUT
+  float* dctx;    // 256
   float* dy;      // 256 d(x + h3)
   float* dht;     // 256 total dL/dh_l at this step
   float* dcp;     // 256
   float* dgp;     // 512
   float* dinp;    // 256 gradient into the layer input
-  float* dx;      // 256
   float* dp2;     // 128
-  float* dp1;     // 256
   float* red;     // 8*256 cross-wave dq reduction
   float* rec;     // kRecFloats: this step's forward stash pieces (prefetched one step ahead)
-  float* p1prev;  // 256: pre-net layer-1 activations of the step processed before (its layer-2 backward runs one step late)
+  float* p1prev;  // 256: pre-net layer-1 activations of the step processed before (its backward runs one step late)
+  float* p2prev;  // 128: likewise layer 2
   float* als;     // TtP
   float* des;     // TtP
   int* dead;
@@ -742,29 +748,28 @@ struct DecBwdSmem {
 // LDS copy of the forward stash record of step t (+ h of step t-1):
 constexpr int RL_P1 = 0, RL_P2 = 256, RL_R = 384, RL_U = 1152, RL_C = 1920, RL_Q = 2688, RL_HP = 2944, kRecFloats = 3712;
 constexpr int kRecRegs = (kRecFloats + NT - 1) / NT;   // 8 registers per thread hold the next record in flight
-constexpr int kBwdSmemFixed = kPartFloats + 768 + 256 + 80 + 656 + 256 + 256 + 256 + 256 + 512 + 256 + 256 + 128 + 256 +
-                              8 * 256 + kRecFloats + 256 + 4;
+constexpr int kVoMax = kMel * 5 + 512;
+constexpr int kBwdSmemFixed = kPartFloats + 768 + 256 + kVoMax + 256 + 256 + 256 + 256 + 512 + 256 + 128 + 8 * 256 + kRecFloats +
+                              256 + 128 + 4;
 
 __device__ __forceinline__ DecBwdSmem carve_bwd(float* base, int TtP) {
   DecBwdSmem s;
   float* p = base;
   s.part = p; p += kPartFloats;
   s.dh = p; p += 768;
-  s.datt = p; p += 256;
-  s.dfr = p; p += 80;
-  s.dov = p; p += 656;
-  s.dq = p; p += 256;
+  s.dx = p; p += 256;
+  s.vo = p; p += kVoMax;
+  s.dctx = p; p += 256;
   s.dy = p; p += 256;
   s.dht = p; p += 256;
   s.dcp = p; p += 256;
   s.dgp = p; p += 512;
   s.dinp = p; p += 256;
-  s.dx = p; p += 256;
   s.dp2 = p; p += 128;
-  s.dp1 = p; p += 256;
   s.red = p; p += 8 * 256;
   s.rec = p; p += kRecFloats;
   s.p1prev = p; p += 256;
+  s.p2prev = p; p += 128;
   s.als = p; p += TtP;
   s.des = p; p += TtP;
   s.dead = reinterpret_cast<int*>(p); p += 4;
@@ -788,6 +793,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
   const int b = blockIdx.x / P;
   const int B = a.B, Tt = a.Tt, Td = a.Td, r = a.r;
   const int R80 = kMel * r;
+  const int NO = a.NO;
   const int TtP = (Tt + 3) & ~3;
   DecBwdSmem S = carve_bwd(smem, TtP);
   const DecWeights& w = a.wT;
@@ -801,6 +807,9 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
   X.trace = nullptr;
   X.tslot = 0;
   const bool lead = X.peer == 0;
+  float* const dov = S.vo;               // d cell_output (direct part)
+  float* const dq = S.vo + R80;
+  float* const dp1 = S.vo + R80 + kAtt;
 
   int len = a.text_length[b];
   len = len < 1 ? 1 : (len > Tt ? Tt : len);
@@ -809,8 +818,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
   float* dkeys = a.dkeys + (int64_t)b * Tt * kAtt;
 
   for (int i = tid; i < 768; i += NT) S.dh[i] = 0.f;
-  if (tid < 256) S.datt[tid] = 0.f;
-  if (tid < 80) S.dfr[tid] = 0.f;
+  if (tid < 256) S.dx[tid] = 0.f;
   for (int i = tid; i < TtP; i += NT) { S.als[i] = 0.f; S.des[i] = 0.f; }
   if (tid == 0) *S.dead = 0;
   // Register-resident attention memory.  d alignments (3a) is split by memory ROW: this wave's rows of `values` (as in the
@@ -851,23 +859,27 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
   }
   lds_barrier();
 
-  // The pre-net backward of a step (p2T, p1T) is off the critical path: it runs one step late, inside the attT / d-alignment
-  // exchange rounds of the next processed step.  `pend` = such a deferred pair exists (from step t+1).
+  // The pre-net backward of a step is off the critical path and runs one step late: its layer-2 input gradient comes out
+  // of the next processed step's FAN round (it needs the same dx), layer 1 rides in that step's DAL round.
+  // `pend` = such a deferred pre-net (of step t+1) exists.
   bool pend = false;
   float* gs_pend = nullptr;
-  const float km1c = a.keep1 ? 2.f : 1.f;
+  const float km1c = a.keep1 ? 2.f : 1.f, km2c = a.keep2 ? 2.f : 1.f;
+  auto dp2_epi = [&](int n, float y) {
+    const float g = S.p2prev[n] > 0.f ? km2c * y : 0.f;
+    gs_pend[kGsP2 + n] = g;
+    return g;
+  };
+  auto dp2_put = [&](int n, float v) { S.dp2[n] = v; };
   auto p2T_epi = [&](int n, float y) {
     const float g = S.p1prev[n] > 0.f ? km1c * y : 0.f;
     gs_pend[kGsP1 + n] = g;
     return g;
   };
-  auto p2T_put = [&](int n, float v) { S.dp1[n] = v; };
-  auto p1T_epi = [&](int n, float y) { return y; };
-  auto p1T_put = [&](int n, float v) { S.dfr[n] = v; };
+  auto p2T_put = [&](int n, float v) { dp1[n] = v; };
   Pref pf;   // next round's first weight rows, fetched during the current round's all-gather
-  const NextMv nx_att{w.att_w, R80 + kAtt, kAtt, R80 + kAtt}, nx_out{w.out_w, kDec, R80, kDec},
-      nx_in{w.in_w, kPre2 + kAtt, kDec, kPre2 + kAtt};
-  prefetch_w(pf, nx_att.W, nx_att.ldw, nx_att.K, nx_att.N, X);
+  const NextMv nx_fa{a.fa, NO, kDec, NO}, nx_p2T{w.pre_w2, kPre1, kPre2, kPre1};
+  prefetch_w(pf, nx_fa.W, nx_fa.ldw, nx_fa.K, nx_fa.N, X);
 
   for (int t = Td - 1; t >= 0; --t) {
     X.epoch = (unsigned)(Td - t);
@@ -876,18 +888,14 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
     const int64_t bt = (int64_t)b * Td + t;
     float* gs = a.gstash + bt * kGsRec;
     const bool next_from_out = (t + 1 < Td) && a.sample && a.sample[(int64_t)t * B + b];
-    const bool this_from_out = (t > 0) && a.sample && a.sample[(int64_t)(t - 1) * B + b];
-    const float km1 = a.keep1 ? 2.f : 1.f, km2 = a.keep2 ? 2.f : 1.f;
 
     // 0. land the prefetched record in LDS, start fetching the one for step t-1
 #pragma unroll
     for (int i = 0; i < kRecRegs; ++i)
       if (tid + i * NT < kRecFloats) S.rec[tid + i * NT] = pre[i];
-    // 1. d cell_output: direct (loss + post-net) + sampled next-input path (replicated on every peer)
-    if (tid < R80) S.dov[tid] = pre_dout;   // the sampled next-input path (dfr of step t+1) is added after round 2
+    if (tid < R80) dov[tid] = pre_dout;   // direct part: loss + post-net
     if (tid < Tt) S.als[tid] = pre_al;
     for (int s = tid + NT; s < Tt; s += NT) S.als[s] = a.align[bt * Tt + s];
-    if (lead && tid < kAtt) gs[kGsAtt + tid] = S.datt[tid];
     if (t > 0) {
 #pragma unroll
       for (int i = 0; i < kRecRegs; ++i) pre[i] = rec_load(a.stash, bt - 1, t - 1, tid + i * NT);
@@ -895,39 +903,50 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
       if (tid < Tt) pre_al = a.align[(bt - 1) * Tt + tid];
     }
     lds_barrier();
-    // 2. round: attention layer d[o ; ctx] += datt . Wa^T (wT.att_w is (256, 80r+256))  +  deferred pre-net layer 2 of
-    //    step t+1: dp1 = dp2pre . W2^T (wT.pre_w2 is (128, 256))
+    // 1. round FAN: dx_{t+1} through [Wx_c^T | Wx_o^T | 0] (a.fa, (256, NO)) -> [d ctx_t | d cell_output_t (added to the direct
+    //    part)], and through Wi_p^T (wT.in_w columns [0,128)) -> d p2_{t+1}
     {
-      auto att_epi = [&](int n, float y) {
-        if (n < R80) return S.dov[n] + y;
-        gs[kGsCtx + n - R80] = y;
-        return y;
+      auto fa_epi = [&](int n, float y) {
+        if (n < kAtt) {
+          gs[kGsCtx + n] = y;
+          return y;
+        }
+        if (n < kAtt + R80) {
+          const float g = dov[n - kAtt] + y;
+          gs[kGsO + n - kAtt] = g;
+          return g;
+        }
+        return 0.f;
       };
-      auto att_put = [&](int n, float v) { S.dov[n] = v; };
+      auto fa_put = [&](int n, float v) {
+        if (n < kAtt) S.dctx[n] = v;
+        else if (n < kAtt + R80) dov[n - kAtt] = v;
+      };
       tstamp(X, 0);
-      phase_mv(w.att_w, R80 + kAtt, kAtt, R80 + kAtt, S.datt, S.part, X, pf);
-      if (pend) phase_mv(w.pre_w2, kPre1, kPre2, kPre1, S.dp2, S.part + kPartRegion, X);
+      phase_mv(a.fa, NO, kDec, NO, S.dx, S.part, X, pf);
+      if (pend) phase_mv(w.in_w, kPre2 + kAtt, kDec, kPre2, S.dx, S.part + kPartRegion, X);
       tstamp(X, 1);
       lds_barrier();
-      phase_fin(R80 + kAtt, S.part, X, XB_ATT, att_epi, att_put);
-      if (pend) phase_fin(kPre1, S.part + kPartRegion, X, XB_P2, p2T_epi, p2T_put);
+      phase_fin(NO, S.part, X, XB_FA, fa_epi, fa_put);
+      if (pend) phase_fin(kPre2, S.part + kPartRegion, X, XB_DP2, dp2_epi, dp2_put);
       tstamp(X, 2);
-      phase_gather(R80 + kAtt, X, XB_ATT, att_put);
-      if (pend) phase_gather(kPre1, X, XB_P2, p2T_put);
+      if (pend) prefetch_w(pf, nx_p2T.W, nx_p2T.ldw, nx_p2T.K, nx_p2T.N, X);
+      phase_gather2(NO, XB_FA, fa_put, pend ? kPre2 : 0, XB_DP2, dp2_put, X);
       tstamp(X, 3);
       X.tslot++;
     }
     lds_barrier();
-    // 3a. d alignments[s] = values[s] . dctx   (memory rows dealt round-robin to peers)
+    // 2. round DAL: d alignments[s] = values[s] . dctx (memory rows dealt round-robin to peers);  same round: deferred
+    //    pre-net layer 2 of step t+1: d p1 = d p2pre . W2^T (wT.pre_w2 is (128, 256))
     {
       tmark(X, 10);
-      const float4 c4 = reinterpret_cast<const float4*>(S.dov + R80)[lane];
+      const float4 c4 = reinterpret_cast<const float4*>(S.dctx)[lane];
       auto dal = [&](int s, float4 x4) {
-        float d = x4.x * c4.x + x4.y * c4.y + x4.z * c4.z + x4.w * c4.w;
-        d = wave_sum(d);
+        float dd = x4.x * c4.x + x4.y * c4.y + x4.z * c4.z + x4.w * c4.w;
+        dd = wave_sum(dd);
         if (lane == 0) {
-          S.des[s] = d;
-          if (P > 1) xput(X, XB_DAL + s, d);
+          S.des[s] = dd;
+          if (P > 1) xput(X, XB_DAL + s, dd);
         }
       };
 #pragma unroll
@@ -937,25 +956,31 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
       }
       for (int s = s_first + kAR * s_stride; s < len; s += s_stride)
         dal(s, reinterpret_cast<const float4*>(values + (int64_t)s * kAtt)[lane]);
-      // same round: deferred pre-net layer 1 input gradient of step t+1 (only when step t+1 was fed cell_output[t])
-      const bool do_p1T = pend && next_from_out;
-      if (do_p1T) {
-        phase_mv(w.pre_w1, kMel, kPre1, kMel, S.dp1, S.part, X);
+      if (pend) {
+        phase_mv(w.pre_w2, kPre1, kPre2, kPre1, S.dp2, S.part, X, pf);
         lds_barrier();
-        phase_fin(kMel, S.part, X, XB_P1, p1T_epi, p1T_put);
+        phase_fin(kPre1, S.part, X, XB_P2, p2T_epi, p2T_put);
       }
       tmark(X, 11);
-      if (P > 1) {
-        for (int s = tid; s < len; s += NT)
+      if (P > 1) {   // the other peers' rows and their slices of d p1, polled concurrently
+        const Slice SB = slice_of(X, kPre1);
+        const bool needA = tid < len && tid % P != X.peer;
+        const bool needB = pend && tid < kPre1 && !(tid >= SB.nbeg && tid < SB.nbeg + SB.nloc);
+        float vA, vB;
+        xget2(X, XB_DAL + tid, needA, XB_P2 + tid, needB, vA, vB);
+        if (needA) S.des[tid] = vA;
+        if (needB) p2T_put(tid, vB);
+        for (int s = tid + NT; s < len; s += NT)
           if (s % P != X.peer) S.des[s] = xget(X, XB_DAL + s);
       }
-      if (do_p1T) phase_gather(kMel, X, XB_P1, p1T_put);
       tmark(X, 12);
     }
     lds_barrier();
     tmark(X, 13);
-    // d cell_output[t] += d(pre-net input of step t+1) on the last frame of the group (sampled rows only)
-    if (pend && next_from_out && tid < kMel) S.dov[kMel * (r - 1) + tid] += S.dfr[tid];
+    // d p1pre of step t+1 reaches this step's cell_output only if that step was fed by it (sampled rows); record it (or 0)
+    // for the output projection's weight gradient
+    const bool use_p1 = pend && next_from_out;
+    if (lead && tid < kPre1) gs[kGsP1S + tid] = use_p1 ? dp1[tid] : 0.f;
     // 3b. softmax backward: de = al * (dal - sum al*dal)   (every wave computes the dot redundantly)
     {
       float dot = 0.f;
@@ -999,32 +1024,23 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
     lds_barrier();
     tmark(X, 16);
     {
-      auto dq_put = [&](int n, float v) { S.dq[n] = v; };
+      auto dq_put = [&](int n, float v) { dq[n] = v; };
       if (tid < un) {
         float dsum = 0.f;
         for (int g = 0; g < NSG; ++g) dsum += S.red[g * un + tid];
         const int n = ub + tid;
-        S.dq[n] = dsum;
+        dq[n] = dsum;
         gs[kGsQ + n] = dsum;
         if (P > 1) xput(X, XB_DQP + n, dsum);
       }
-      prefetch_w(pf, w.q_w, R80, kAtt, R80, X);
+      prefetch_w(pf, a.wot, kDec, R80 + kAtt + (use_p1 ? kPre1 : 0), kDec, X);
       phase_gather(kAtt, X, XB_DQP, dq_put);
     }
     tmark(X, 17);
     lds_barrier();
     tmark(X, 18);
-    // 4. query layer: do += dq . Wq^T   (wT.q_w is (256, 80r))
-    phase(w.q_w, R80, kAtt, R80, S.dq, S.part, X, XB_Q,
-          [&](int n, float y) {
-            const float g = S.dov[n] + y;
-            gs[kGsO + n] = g;
-            return g;
-          },
-          [&](int n, float v) { S.dov[n] = v; }, pf, nx_out);
-    lds_barrier();
-    // 5. output projection: dy = do . Wo^T   (wT.out_w is (80r, 256))
-    phase(w.out_w, kDec, R80, kDec, S.dov, S.part, X, XB_OUT, [&](int n, float y) { return y; },
+    // 4. round OUT: dy = [d cell_output ; dq ; d p1pre_{t+1}] . [Wo^T ; (Wo Wq)^T ; (Wo_f W1)^T]   (a.wot, (80r+512, 256))
+    phase(a.wot, kDec, R80 + kAtt + (use_p1 ? kPre1 : 0), kDec, S.vo, S.part, X, XB_OUT, [&](int n, float y) { return y; },
           [&](int n, float v) {
             S.dy[n] = v;
             S.dht[n] = S.dh[2 * kDec + n] + v;   // dL/dh3' = carried + residual path
@@ -1086,36 +1102,23 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
                 S.dh[l * kDec + n - kDec] += y;
               }
             },
-            pf, l > 0 ? NextMv{w.cw[l - 1], 2 * kDec, kDec, 2 * kDec} : nx_in);
+            pf, l > 0 ? NextMv{w.cw[l - 1], 2 * kDec, kDec, 2 * kDec} : (t > 0 ? nx_fa : NextMv{w.in_w, kPre2 + kAtt, kDec, kPre2}));
       lds_barrier();
     }
     if (lead && tid < kDec) gs[kGsX + tid] = S.dx[tid];
-    // 7. input projection: d[p2 ; att_{t-1}] = dx . Wi^T   (wT.in_w is (256, 384))
-    phase(w.in_w, kPre2 + kAtt, kDec, kPre2 + kAtt, S.dx, S.part, X, XB_IN,
-          [&](int n, float y) {
-            if (n < kPre2) {
-              const float g = S.rec[RL_P2 + n] > 0.f ? km2 * y : 0.f;
-              gs[kGsP2 + n] = g;
-              return g;
-            }
-            return y;
-          },
-          [&](int n, float v) {
-            if (n < kPre2) S.dp2[n] = v;
-            else S.datt[n - kPre2] = v;
-          },
-          pf, t > 0 ? nx_att : NextMv());
-    lds_barrier();
-    // 8./9. pre-net layers 2 and 1 backward of THIS step are deferred into the next processed step's rounds 2 and 3a
+    // the pre-net backward of THIS step is deferred into the next processed step's FAN / DAL rounds
     if (tid < kPre1) S.p1prev[tid] = S.rec[RL_P1 + tid];
+    if (tid < kPre2) S.p2prev[tid] = S.rec[RL_P2 + tid];
     pend = true;
     gs_pend = gs;
     lds_barrier();
   }
-  // deferred pre-net layer 2 of step 0 (its layer-1 input gradient is not needed: nothing precedes step 0)
+  // deferred pre-net of step 0 (its layer-1 input gradient is not needed: nothing precedes step 0)
   if (pend) {
     X.epoch = (unsigned)(Td + 1);
-    phase(w.pre_w2, kPre1, kPre2, kPre1, S.dp2, S.part, X, XB_P2, p2T_epi, p2T_put);
+    phase(w.in_w, kPre2 + kAtt, kDec, kPre2, S.dx, S.part, X, XB_DP2, dp2_epi, dp2_put, pf, nx_p2T);
+    lds_barrier();
+    phase(w.pre_w2, kPre1, kPre2, kPre1, S.dp2, S.part, X, XB_P2, p2T_epi, p2T_put, pf, NextMv());
     lds_barrier();
   }
   // resident dkeys accumulators -> memory (each (row, unit) is owned by exactly one thread of one peer)

@@ -315,14 +315,15 @@ __global__ void transpose_batch_kernel(TransposeBatch b) {
   const float* src = J.in + (int64_t)(J.taps - 1 - tp) * J.K * J.N;
   float* dst = J.out + (int64_t)tp * J.K * J.N;
   const int n0 = bx * 32, k0 = by * 32;
+  const int ldi = J.ldi ? J.ldi : J.N, ldo = J.ldo ? J.ldo : J.K;
   for (int j = threadIdx.y; j < 32; j += 8) {
     const int k = k0 + j, n = n0 + threadIdx.x;
-    tile[j][threadIdx.x] = (k < J.K && n < J.N) ? src[(int64_t)k * J.N + n] : 0.f;
+    tile[j][threadIdx.x] = (k < J.K && n < J.N) ? src[(int64_t)k * ldi + n] : 0.f;
   }
   __syncthreads();
   for (int j = threadIdx.y; j < 32; j += 8) {
     const int n = n0 + j, k = k0 + threadIdx.x;
-    if (n < J.N && k < J.K) dst[(int64_t)n * J.K + k] = tile[threadIdx.x][j];
+    if (n < J.N && k < J.K) dst[(int64_t)n * ldo + k] = tile[threadIdx.x][j];
   }
 }
 

@@ -91,6 +91,7 @@ struct TransposeJob {
   const float* in;
   float* out;
   int taps, K, N, tile0;   // tile0 = first linear tile index of this job (filled by the launcher)
+  int ldi = 0, ldo = 0;    // input / output pitch (0: dense, N / K); sub-blocks of larger matrices when set (taps must be 1)
 };
 struct TransposeBatch {
   TransposeJob j[kMaxTransposeBatch];
@@ -170,7 +171,7 @@ constexpr int kGsG = 0;                   // 3*512 gates pre-act grads
 constexpr int kGsC = 1536;                // 3*256 candidate pre-act grads
 constexpr int kGsX = 2304;                // 256 dx (in-proj output grad)
 constexpr int kGsQ = 2560;                // 256 dq
-constexpr int kGsAtt = 2816;              // 256 d attention (att-proj output grad)
+constexpr int kGsP1S = 2816;              // 256 d prenet-1 pre-act of step t+1 if that step was fed cell_output[t], else 0
 constexpr int kGsCtx = 3072;              // 256 d context
 constexpr int kGsP2 = 3328;               // 128 d prenet-2 pre-act
 constexpr int kGsP1 = 3456;               // 256 d prenet-1 pre-act
@@ -202,6 +203,9 @@ int launch_decoder_fwd(DecFwdArgs a, hipStream_t s);
 
 struct DecBwdArgs {
   DecWeights wT;         // every matrix TRANSPOSED (out,in); biases unused
+  const float* fa;       // (256, NO)  [Wx_c^T | Wx_o^T | 0]: dx_{t+1} -> [d context | d cell_output]
+  const float* wot;      // (80r+512, 256)  [Wo^T ; (Wo Wq)^T ; (Wo[:, last frame] W1)^T]
+  int NO;
   const float* att_v;    // (256)
   const float* keys;
   const float* values;

@@ -238,6 +238,13 @@ void build_ws_layout(const TacoShape& s, bool train, const TransLayout& T, WsLay
     W.dkeys = a.add("bwd.dkeys", {M1, kAtt});
     W.dvalues = a.add("bwd.dvalues", {M1, kAtt});
     W.ds2s_tot = a.add("bwd.ds2s_tot", {MD, R80});
+    W.bc_fa = a.add("bwd.comp.fa", {kDec, dec_out_cols(s.r)});      // [Wx_c^T | Wx_o^T | 0]
+    W.bc_wot = a.add("bwd.comp.wot", {R80 + 2 * kAtt, kDec});       // [Wo^T ; (Wo Wq)^T ; (Wo_f W1)^T]
+    W.bc_g = a.add("bwd.comp.g", {R80 + kAtt, kDec});               // sum_t [out_t ; ctx_t]^T dx_{t+1}
+    W.bc_h1 = a.add("bwd.comp.h1", {kDec, kAtt});                   // sum_t (x + h3)_t^T dq_t
+    W.bc_h2 = a.add("bwd.comp.h2", {kDec, kPre1});                  // sum_t (x + h3)_t^T dp1s_t
+    W.bc_cq = a.add("bwd.comp.cq", {kAtt});                         // sum_t dq_t
+    W.bc_cp = a.add("bwd.comp.cp", {kPre1});                        // sum_t dp1s_t
     W.gA = a.add("bwd.gA", {Mx, 16 * kCb});
     W.gB = a.add("bwd.gB", {Mx, 16 * kCb});
     W.gC = a.add("bwd.gC", {Mx, 6 * kCb});
@@ -248,6 +255,7 @@ void build_ws_layout(const TacoShape& s, bool train, const TransLayout& T, WsLay
     W.scratch = a.add("bwd.scratch", {64});
   } else {
     W.ds2s = W.dout_pad = W.paramsT = W.gstash = W.dkeys = W.dvalues = W.ds2s_tot = -1;
+    W.bc_fa = W.bc_wot = W.bc_g = W.bc_h1 = W.bc_h2 = W.bc_cq = W.bc_cp = -1;
     W.gA = W.gB = W.gC = W.gD = W.gE = W.gF = W.gG = W.scratch = -1;
   }
   W.total = (a.off + 63) / 64 * 64;

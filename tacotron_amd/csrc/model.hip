@@ -315,17 +315,6 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
     TACO_TRY(launch_decoder_fwd(da, s));
     prof_end(0, slot, s);
   }
-  if (train) {
-    // attention vector of every step for the backward pass (the kernel itself folds Wa into the next step's input
-    // projection and never forms it): att = [cell_output ; context] Wa
-    float* st = ws + W.stash;
-    const int MD = B * Td;
-    TACO_TRY(launch_conv_gemm(dense_problem(s2s, R80, P + PL.att_w, kAtt, nullptr, st + kStAtt, kStRec, MD, kAtt, R80, TACO_ACT_NONE), s));
-    ConvGemmProblem p2 = dense_problem(st + kStCtx, kStRec, P + PL.att_w + (int64_t)R80 * kAtt, kAtt, nullptr, st + kStAtt, kStRec, MD,
-                                       kAtt, kAtt, TACO_ACT_NONE);
-    p2.residual = st + kStAtt; p2.ldr = kStRec;
-    TACO_TRY(launch_conv_gemm(p2, s));
-  }
   // post-net (tacotron.py:142-152): (B,Td,80r) reinterpreted as (B, Td*r, 80)
   CbhgBufs pb = cbhg_bufs(ws, W.post);
   TACO_TRY(cbhg_fwd(P, PL.post, s2s, B, Td * r, pb, train, s));
@@ -434,6 +423,30 @@ int prepare_transposes(const float* P, const ParamLayout& L, const TransLayout& 
     taco_set_error("prepare_transposes: memset: %s", hipGetErrorString(e));
     return TACO_ELAUNCH;
   }
+  return launch_transpose_batch(tb, s);
+}
+
+// Transposed composites of the decoder backward kernel (from the forward composites, still in the workspace since
+// taco_forward, and the out-projection kernel).
+int build_dec_composites_bwd(const float* P, const ParamLayout& PL, const WsLayout& W, float* ws, int r, hipStream_t s) {
+  const int R80 = kMel * r, NO = dec_out_cols(r);
+  float *fa = ws + W.bc_fa, *wot = ws + W.bc_wot;
+  hipError_t e = hipMemsetAsync(fa, 0, sizeof(float) * kDec * NO, s);
+  if (e != hipSuccess) {
+    taco_set_error("build_dec_composites_bwd: memset: %s", hipGetErrorString(e));
+    return TACO_ELAUNCH;
+  }
+  TransposeBatch tb;
+  auto job = [&](const float* in, int ldi, float* out, int ldo, int K, int N) {
+    TransposeJob& j = tb.j[tb.n++];
+    j.in = in; j.out = out; j.taps = 1; j.K = K; j.N = N; j.tile0 = 0; j.ldi = ldi; j.ldo = ldo;
+  };
+  const float* wx = ws + W.dc_wx;
+  job(wx + (int64_t)(kPre2 + R80) * kDec, kDec, fa, NO, kAtt, kDec);                 // Wx_c^T -> fa[:, 0:256]
+  job(wx + (int64_t)kPre2 * kDec, kDec, fa + kAtt, NO, R80, kDec);                   // Wx_o^T -> fa[:, 256:256+80r]
+  job(P + PL.out_proj.w, R80, wot, kDec, kDec, R80);                                 // Wo^T
+  job(ws + W.dc_wo, NO, wot + (int64_t)R80 * kDec, kDec, kDec, kAtt);                // (Wo Wq)^T
+  job(ws + W.dc_wp1o, kPre1, wot + (int64_t)(R80 + kAtt) * kDec, kDec, kDec, kPre1); // (Wo_f W1)^T
   return launch_transpose_batch(tb, s);
 }
 
@@ -703,6 +716,14 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
   TACO_TRY(launch_add(ws + W.ds2s, dPostIn, dS2S, (int64_t)MD * R80, s));
 
   // ---- decoder BPTT ----
+  TACO_TRY(build_dec_composites_bwd(P, PL, W, ws, r, s));
+  {
+    hipError_t e2 = hipMemsetAsync(ws + W.bc_g, 0, sizeof(float) * (size_t)(W.bc_cp + kPre1 - W.bc_g), s);
+    if (e2 != hipSuccess) {
+      taco_set_error("taco_backward: memset: %s", hipGetErrorString(e2));
+      return TACO_ELAUNCH;
+    }
+  }
   float* gs = ws + W.gstash;
   const float* st = ws + W.stash;
   {
@@ -715,6 +736,7 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     }
     w.out_w = PT + TL.out_proj; w.q_w = PT + TL.q_w; w.att_w = PT + TL.att_w; w.att_v = P + PL.att_v;
     a.att_v = P + PL.att_v;
+    a.fa = ws + W.bc_fa; a.wot = ws + W.bc_wot; a.NO = dec_out_cols(r);
     a.keys = ws + W.keys; a.values = ws + W.values; a.text_length = text_length;
     a.keep1 = dec_keep1; a.keep2 = dec_keep2; a.sample = sample;
     a.dout = dS2S; a.out = seq2seq_output; a.align = alignments; a.stash = st; a.gstash = gs;
@@ -732,9 +754,11 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     const float* prein = ws + W.prein;
     TACO_TRY(tn(prein, kMel, kMel, gs + kGsP1, kGsRec, kPre1, G + PL.dec_pre1.w, kPre1, MD, Td, 0, s, 1, G + PL.dec_pre1.b));
     TACO_TRY(tn(st + kStP1, kStRec, kPre1, gs + kGsP2, kGsRec, kPre2, G + PL.dec_pre2.w, kPre2, MD, Td, 0, s, 1, G + PL.dec_pre2.b));
-    // in-proj: rows [0,128) pre-net output of step t, rows [128,384) attention of step t-1
+    // in-proj rows [0,128): pre-net output of step t.  Rows [128,384) (attention of step t-1) and the attention layer follow
+    // from Gx = sum_t [cell_output ; context]_{t-1}^T dx_t below: the kernel never forms the attention vector or its gradient.
     TACO_TRY(tn(st + kStP2, kStRec, kPre2, gs + kGsX, kGsRec, kDec, G + PL.in_proj.w, kDec, MD, Td, 0, s, 1, G + PL.in_proj.b));
-    TACO_TRY(tn(st + kStAtt, kStRec, kAtt, gs + kGsX, kGsRec, kDec, G + PL.in_proj.w + (int64_t)kPre2 * kDec, kDec, MD, Td, 1, s));
+    TACO_TRY(tn(seq2seq_output, R80, R80, gs + kGsX, kGsRec, kDec, ws + W.bc_g, kDec, MD, Td, 1, s));
+    TACO_TRY(tn(st + kStCtx, kStRec, kAtt, gs + kGsX, kGsRec, kDec, ws + W.bc_g + (int64_t)R80 * kDec, kDec, MD, Td, 1, s));
     for (int l = 0; l < 3; ++l) {
       const float* inp = l == 0 ? st + kStX : st + kStH + (l - 1) * kDec;
       const float* dG = gs + kGsG + l * 512;
@@ -745,11 +769,38 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
       TACO_TRY(tn(inp, kStRec, kDec, dC, kGsRec, kDec, G + PL.gru[l].wc, kDec, MD, Td, 0, s, 1, G + PL.gru[l].bc));
       TACO_TRY(tn(st + kStRH + l * kDec, kStRec, kDec, dC, kGsRec, kDec, G + PL.gru[l].wc + (int64_t)kDec * kDec, kDec, MD, Td, 0, s));
     }
+    // out-proj: d cell_output(total) = direct + dq Wq^T + (sampled) dp1s W1^T on the last frame; the kernel stashes only the
+    // direct part, the rest follows from H1 = sum_t y_t^T dq_t, H2 = sum_t y_t^T dp1s_t  (y = x + h3)
     TACO_TRY(tn(st + kStY, kStRec, kDec, gs + kGsO, kGsRec, R80, G + PL.out_proj.w, R80, MD, Td, 0, s, 1, G + PL.out_proj.b));
+    TACO_TRY(tn(st + kStY, kStRec, kDec, gs + kGsQ, kGsRec, kAtt, ws + W.bc_h1, kAtt, MD, Td, 0, s, 1, ws + W.bc_cq));
+    TACO_TRY(tn(st + kStY, kStRec, kDec, gs + kGsP1S, kGsRec, kPre1, ws + W.bc_h2, kPre1, MD, Td, 0, s, 1, ws + W.bc_cp));
     TACO_TRY(tn(seq2seq_output, R80, R80, gs + kGsQ, kGsRec, kAtt, G + PL.q_w, kAtt, MD, Td, 0, s));
-    TACO_TRY(tn(seq2seq_output, R80, R80, gs + kGsAtt, kGsRec, kAtt, G + PL.att_w, kAtt, MD, Td, 0, s));
-    TACO_TRY(tn(st + kStCtx, kStRec, kAtt, gs + kGsAtt, kGsRec, kAtt, G + PL.att_w + (int64_t)R80 * kAtt, kAtt, MD, Td, 0, s));
     TACO_TRY(dec_group.flush());
+    const float* Gx = ws + W.bc_g;
+    ConvGemmBatch b1;
+    b1.n = 4;
+    // d att_w = Gx Wi_a^T
+    b1.p[0] = dense_problem(Gx, kDec, PT + TL.in_proj + kPre2, kPre2 + kAtt, nullptr, G + PL.att_w, kAtt, R80 + kAtt, kAtt, kDec,
+                            TACO_ACT_NONE);
+    // d in_proj rows [128,384) = Wa^T Gx
+    b1.p[1] = dense_problem(PT + TL.att_w, R80 + kAtt, Gx, kDec, nullptr, G + PL.in_proj.w + (int64_t)kPre2 * kDec, kDec, kAtt, kDec,
+                            R80 + kAtt, TACO_ACT_NONE);
+    // d out_proj += H1 Wq^T ;  d out_proj bias += (sum dq) Wq^T
+    b1.p[2] = dense_problem(ws + W.bc_h1, kAtt, PT + TL.q_w, R80, nullptr, G + PL.out_proj.w, R80, kDec, R80, kAtt, TACO_ACT_NONE);
+    b1.p[2].residual = G + PL.out_proj.w; b1.p[2].ldr = R80;
+    b1.p[3] = dense_problem(ws + W.bc_cq, kAtt, PT + TL.q_w, R80, nullptr, G + PL.out_proj.b, R80, 1, R80, kAtt, TACO_ACT_NONE);
+    b1.p[3].residual = G + PL.out_proj.b; b1.p[3].ldr = R80;
+    TACO_TRY(launch_conv_gemm_batch(b1, s));
+    ConvGemmBatch b2;
+    b2.n = 2;
+    // last-frame columns: += H2 W1^T ; bias += (sum dp1s) W1^T
+    b2.p[0] = dense_problem(ws + W.bc_h2, kPre1, PT + TL.dec_pre1, kMel, nullptr, G + PL.out_proj.w + (R80 - kMel), R80, kDec, kMel,
+                            kPre1, TACO_ACT_NONE);
+    b2.p[0].residual = G + PL.out_proj.w + (R80 - kMel); b2.p[0].ldr = R80;
+    b2.p[1] = dense_problem(ws + W.bc_cp, kPre1, PT + TL.dec_pre1, kMel, nullptr, G + PL.out_proj.b + (R80 - kMel), R80, 1, kMel,
+                            kPre1, TACO_ACT_NONE);
+    b2.p[1].residual = G + PL.out_proj.b + (R80 - kMel); b2.p[1].ldr = R80;
+    TACO_TRY(launch_conv_gemm_batch(b2, s));
   }
   // ---- attention memory: dvalues[b] = alignments[b]^T . dctx[b] ; keys = values . Wm ----
   {
