@@ -23,7 +23,6 @@ namespace {
 constexpr int NT = 512;
 constexpr int kPartFloats = NT * 8;   // two partial-sum regions of NT*4 floats (merged rounds run two mat-vecs per barrier)
 constexpr int kPartRegion = NT * 4;
-constexpr int kMaxKG = 64;
 constexpr int kAR = 4;   // attention memory rows kept register-resident per wave
 constexpr int kKR = 13;  // rows per thread kept resident by the unit-split energy backward (NSG = 16: Tt <= 208)
 
@@ -35,6 +34,7 @@ struct Xchg {
   u64* base;        // this row's granule area
   unsigned epoch;   // step tag, never 0
   int P, peer;
+  int lgP;          // log2(P)
   int* err;         // global error word
   int* dead;        // LDS: set once this workgroup has given up polling
   long long* trace; // optional: 4 wall_clock64 stamps per phase (enabled for one workgroup at one step), else null
@@ -117,21 +117,24 @@ __device__ __forceinline__ int opaque_tid() {
 }
 struct Slice {
   int g0, n4, nloc, nbeg, rows;
+  int lg4;    // log2(n4)
+  int lgKG;   // log2(k-groups)
   bool shfl;
 };
+// Every mat-vec width N in these kernels is a power of two >= 4*P and P is a power of two (pick_cluster), so slices are
+// shifts: no integer division anywhere on the step path.
 __device__ __forceinline__ Slice slice_of(const Xchg& X, int N) {
   Slice s;
-  const int N4 = N >> 2;
-  s.g0 = (X.peer * N4) / X.P;
-  s.n4 = ((X.peer + 1) * N4) / X.P - s.g0;
+  s.lg4 = (31 - __builtin_clz(N >> 2)) - X.lgP;
+  s.n4 = 1 << s.lg4;
+  s.g0 = X.peer << s.lg4;
   s.nloc = s.n4 * 4;
   s.nbeg = s.g0 * 4;
-  // k-groups: threads with equal c4 split K.  When n4 divides 64 the lanes of a wave that share c4 are reduced with
-  // __shfl_xor and only 8 per-wave partials reach LDS; otherwise up to kMaxKG partial rows go through LDS.
-  s.shfl = (64 % s.n4) == 0;
-  int KG = NT / s.n4;
-  if (!s.shfl && KG > kMaxKG) KG = kMaxKG;
-  s.rows = s.shfl ? NT / 64 : KG;
+  // k-groups: the NT / n4 threads with equal c4 split K.  n4 <= 64: the lanes of a wave that share c4 are reduced with
+  // __shfl_xor and only 8 per-wave partials reach LDS; wider slices (small clusters) keep NT / n4 <= 4 partial rows.
+  s.shfl = s.lg4 <= 6;
+  s.lgKG = 9 - s.lg4;   // NT = 512
+  s.rows = s.shfl ? NT / 64 : (1 << s.lgKG);
   return s;
 }
 
@@ -146,11 +149,10 @@ struct Pref {
 __device__ __forceinline__ void prefetch_w(Pref& pf, const float* __restrict__ W, int ldw, int K, int N, const Xchg& X) {
   const int tid = opaque_tid();
   const Slice S = slice_of(X, N);
-  const int KG = S.shfl ? NT / S.n4 : S.rows;
-  const int kg = tid / S.n4, c4 = tid - kg * S.n4;
+  const int kg = tid >> S.lg4, c4 = tid & (S.n4 - 1);
   pf.W = W;
-  if (kg < KG) {
-    const int Kc = (((K + KG - 1) / KG) + 3) & ~3;
+  {
+    const int Kc = (((K + (1 << S.lgKG) - 1) >> S.lgKG) + 3) & ~3;
     const int k0 = kg * Kc;
     const int k1 = min(K, k0 + Kc);
     const float* wp = W + (S.g0 + c4) * 4;
@@ -169,11 +171,10 @@ __device__ __forceinline__ void phase_mv_impl(const float* __restrict__ W, int l
   const int tid = opaque_tid();
   const Slice S = slice_of(X, N);
   const int n4 = S.n4, nloc = S.nloc;
-  const int KG = S.shfl ? NT / n4 : S.rows;
-  const int kg = tid / n4, c4 = tid - kg * n4;
+  const int kg = tid >> S.lg4, c4 = tid & (n4 - 1);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (kg < KG) {
-    const int Kc = (((K + KG - 1) / KG) + 3) & ~3;
+  {
+    const int Kc = (((K + (1 << S.lgKG) - 1) >> S.lgKG) + 3) & ~3;
     const int k0 = kg * Kc;
     const int k1 = min(K, k0 + Kc);
     const float* wp = W + (int64_t)k0 * ldw + (S.g0 + c4) * 4;
@@ -222,7 +223,7 @@ __device__ __forceinline__ void phase_mv_impl(const float* __restrict__ W, int l
     }
     if ((tid & 63) < n4) *reinterpret_cast<float4*>(part + (tid >> 6) * nloc + c4 * 4) = acc;
   } else {
-    if (kg < KG) *reinterpret_cast<float4*>(part + kg * nloc + c4 * 4) = acc;
+    *reinterpret_cast<float4*>(part + kg * nloc + c4 * 4) = acc;
   }
 }
 
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int P = a.P;
-  const int b = blockIdx.x / P;
+  const int b = blockIdx.x >> (31 - __builtin_clz(P));
   const int B = a.B, Tt = a.Tt, Td = a.Td, r = a.r;
   const int R80 = kMel * r;
   const int KX = kPre2 + R80 + kAtt;   // rows of Wx;  u0 = [p2 (0) ; out (128) ; ctx (128+R80) ; h1 (KX)]
@@ -403,6 +404,7 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
   const DecComposite& cw = a.c;
   Xchg X;
   X.P = P;
+  X.lgP = 31 - __builtin_clz(P);
   X.peer = blockIdx.x - b * P;
   X.base = reinterpret_cast<u64*>(a.xchg) + (int64_t)b * (kXchgFixed + TtP);
   X.err = a.err;
@@ -669,14 +671,14 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
       tmark(X, 1);
       if (P > 1) {   // energies of the other peers' rows and their slices of p2, polled concurrently
         const Slice SB = slice_of(X, kPre2);
-        const bool needA = tid < len && tid % P != X.peer;
+        const bool needA = tid < len && (tid & (P - 1)) != X.peer;
         const bool needB = has_next && tid < kPre2 && !(tid >= SB.nbeg && tid < SB.nbeg + SB.nloc);
         float vA, vB;
         xget2(X, XF_E + tid, needA, XF_P2 + tid, needB, vA, vB);
         if (needA) S.es[tid] = vA;
         if (needB) p2_put(tid, vB);
         for (int s = tid + NT; s < len; s += NT)
-          if (s % P != X.peer) S.es[s] = xget(X, XF_E + s);
+          if ((s & (P - 1)) != X.peer) S.es[s] = xget(X, XF_E + s);
       }
       tstamp(X, 3);
       tmark(X, 2);
@@ -790,7 +792,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int P = a.P;
-  const int b = blockIdx.x / P;
+  const int b = blockIdx.x >> (31 - __builtin_clz(P));
   const int B = a.B, Tt = a.Tt, Td = a.Td, r = a.r;
   const int R80 = kMel * r;
   const int NO = a.NO;
@@ -799,6 +801,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
   const DecWeights& w = a.wT;
   Xchg X;
   X.P = P;
+  X.lgP = 31 - __builtin_clz(P);
   X.peer = blockIdx.x - b * P;
   X.base = reinterpret_cast<u64*>(a.xchg) + (int64_t)b * (kXchgFixed + TtP);
   X.err = a.err;
@@ -834,9 +837,9 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
   }
   const Slice US = slice_of(X, kAtt);
   const int ub = US.nbeg, un = US.nloc;
-  const int NSG = NT / un;                       // row groups
-  const int ul = tid % un, sg = tid / un;        // sg >= NSG: idle thread (un does not divide NT)
-  const bool uact = sg < NSG;
+  const int NSG = NT >> (US.lg4 + 2);            // row groups (un = 256 / P divides NT)
+  const int ul = tid & (un - 1), sg = tid >> (US.lg4 + 2);
+  const bool uact = true;
   const float vu = a.att_v[ub + ul];
   float kr[kKR], dkr[kKR];
 #pragma unroll
@@ -964,14 +967,14 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
       tmark(X, 11);
       if (P > 1) {   // the other peers' rows and their slices of d p1, polled concurrently
         const Slice SB = slice_of(X, kPre1);
-        const bool needA = tid < len && tid % P != X.peer;
+        const bool needA = tid < len && (tid & (P - 1)) != X.peer;
         const bool needB = pend && tid < kPre1 && !(tid >= SB.nbeg && tid < SB.nbeg + SB.nloc);
         float vA, vB;
         xget2(X, XB_DAL + tid, needA, XB_P2 + tid, needB, vA, vB);
         if (needA) S.des[tid] = vA;
         if (needB) p2T_put(tid, vB);
         for (int s = tid + NT; s < len; s += NT)
-          if (s % P != X.peer) S.des[s] = xget(X, XB_DAL + s);
+          if ((s & (P - 1)) != X.peer) S.des[s] = xget(X, XB_DAL + s);
       }
       tmark(X, 12);
     }
