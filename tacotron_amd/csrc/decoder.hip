@@ -389,6 +389,8 @@ __device__ __forceinline__ DecSmem carve(float* base, int TtP) {
 constexpr int kFwdSmemFixed =
     kPartFloats + 80 + 256 + kU0Max + 256 + 3 * 512 + 512 + 256 + 256 + 256 + kBiasFloats + 256 + 128 + 4;
 
+// TR: per-phase time stamps compiled in (TACO_DEC_TRACE=1 launches); the production instantiation carries none of it
+template <bool TR>
 __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
 
   for (int t = 0; t < Td; ++t) {
     X.epoch = (unsigned)(t + 1);
-    X.trace = (a.trace && blockIdx.x == 0 && t == Td / 2) ? a.trace : nullptr;
+    X.trace = (TR && a.trace && blockIdx.x == 0 && t == Td / 2) ? a.trace : nullptr;
     X.tslot = 0;
     const int64_t bt = (int64_t)b * Td + t;
     float* st = a.stash ? a.stash + bt * kStRec : nullptr;
@@ -692,11 +694,11 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
       for (int s = lane; s < len; s += 64) m = fmaxf(m, S.es[s]);
       m = wave_max(m);
       float z = 0.f;
-      for (int s = lane; s < len; s += 64) z += expf(S.es[s] - m);
+      for (int s = lane; s < len; s += 64) z += __expf(S.es[s] - m);
       z = wave_sum(z);
       const float inv = 1.0f / z;
       for (int s = tid; s < Tt; s += NT) {
-        const float al = s < len ? expf(S.es[s] - m) * inv : 0.f;
+        const float al = s < len ? __expf(S.es[s] - m) * inv : 0.f;
         S.als[s] = al;
         if (lead) a.align[bt * Tt + s] = al;
       }
@@ -788,6 +790,7 @@ __device__ __forceinline__ float rec_load(const float* stash, int64_t bt, int t,
   return t > 0 ? (st - kStRec)[kStH + (j - 2944)] : 0.f;       // H of the previous step
 }
 
+template <bool TR>
 __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -886,7 +889,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
 
   for (int t = Td - 1; t >= 0; --t) {
     X.epoch = (unsigned)(Td - t);
-    X.trace = (a.trace && blockIdx.x == 0 && t == Td / 2) ? a.trace : nullptr;
+    X.trace = (TR && a.trace && blockIdx.x == 0 && t == Td / 2) ? a.trace : nullptr;
     X.tslot = 0;
     const int64_t bt = (int64_t)b * Td + t;
     float* gs = a.gstash + bt * kGsRec;
@@ -1176,15 +1179,16 @@ int launch_decoder_fwd(DecFwdArgs a, hipStream_t s) {
   const int TtP = (a.Tt + 3) & ~3;
   const size_t smem = (size_t)(kFwdSmemFixed + 2 * TtP) * sizeof(float);
   TACO_REQUIRE(smem <= 160 * 1024, "decoder_fwd: Tt=%d needs %zu bytes of LDS (> 160 KiB)", a.Tt, smem);
+  void (*kern)(DecFwdArgs) = a.trace ? decoder_fwd_kernel<true> : decoder_fwd_kernel<false>;
   if (smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_fwd_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) {
       taco_set_error("decoder_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
       return TACO_ELAUNCH;
     }
   }
-  a.P = pick_cluster(decoder_fwd_kernel, smem, a.B, env_cluster());
+  a.P = pick_cluster(kern, smem, a.B, env_cluster());
   if (a.P > 1) {
     hipError_t e = hipMemsetAsync(a.xchg, 0, (size_t)decoder_xchg_bytes(a.B, a.Tt), s);
     if (e != hipSuccess) {
@@ -1192,7 +1196,7 @@ int launch_decoder_fwd(DecFwdArgs a, hipStream_t s) {
       return TACO_ELAUNCH;
     }
   }
-  hipLaunchKernelGGL(decoder_fwd_kernel, dim3(a.B * a.P), dim3(NT), smem, s, a);
+  hipLaunchKernelGGL(kern, dim3(a.B * a.P), dim3(NT), smem, s, a);
   TACO_LAUNCH_CHECK("decoder_fwd");
   return TACO_OK;
 }
@@ -1203,15 +1207,16 @@ int launch_decoder_bwd(DecBwdArgs a, hipStream_t s) {
   const int TtP = (a.Tt + 3) & ~3;
   const size_t smem = (size_t)(kBwdSmemFixed + 2 * TtP) * sizeof(float);
   TACO_REQUIRE(smem <= 160 * 1024, "decoder_bwd: Tt=%d needs %zu bytes of LDS (> 160 KiB)", a.Tt, smem);
+  void (*kern)(DecBwdArgs) = a.trace ? decoder_bwd_kernel<true> : decoder_bwd_kernel<false>;
   if (smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_bwd_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) {
       taco_set_error("decoder_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
       return TACO_ELAUNCH;
     }
   }
-  a.P = pick_cluster(decoder_bwd_kernel, smem, a.B, env_cluster());
+  a.P = pick_cluster(kern, smem, a.B, env_cluster());
   if (a.P > 1) {
     hipError_t e = hipMemsetAsync(a.xchg, 0, (size_t)decoder_xchg_bytes(a.B, a.Tt), s);
     if (e != hipSuccess) {
@@ -1219,7 +1224,7 @@ int launch_decoder_bwd(DecBwdArgs a, hipStream_t s) {
       return TACO_ELAUNCH;
     }
   }
-  hipLaunchKernelGGL(decoder_bwd_kernel, dim3(a.B * a.P), dim3(NT), smem, s, a);
+  hipLaunchKernelGGL(kern, dim3(a.B * a.P), dim3(NT), smem, s, a);
   TACO_LAUNCH_CHECK("decoder_bwd");
   return TACO_OK;
 }

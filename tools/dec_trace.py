@@ -34,7 +34,7 @@ print('shader clock during the decoder kernel: %.0f MHz' % ((ck[1] - ck[0]) / ((
 m.backward()
 torch.cuda.synchronize()
 tb = m.workspace[o + 16 + 256:o + 16 + 256 + 4 * 2 * 20].view(torch.int64).cpu().numpy().reshape(-1, 4)
-bn = ['attT', 'qT', 'outT', 'c2T', 'g2T', 'c1T', 'g1T', 'c0T', 'g0T', 'inT', 'p2T', 'p1T']
+bn = ['fan+dp2', 'outT', 'c2T', 'g2T', 'c1T', 'g1T', 'c0T', 'g0T']
 t0 = tb[0, 0]
 print('BACKWARD phase start_us matvec finalize gather total')
 for i, n in enumerate(bn):
