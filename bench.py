@@ -87,6 +87,7 @@ def main():
     ap.add_argument('--text-len', type=int, default=200)
     ap.add_argument('--dec-steps', type=int, default=180)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-inference', action='store_true', help='skip the inference timing (clean per-kernel profiles of the train step)')
     ap.add_argument('--speakers', type=int, default=1, help='>1: VCTK-shaped multi-speaker model (BASELINE configs[4])')
     args = ap.parse_args()
 
@@ -137,7 +138,7 @@ def main():
 
     # ---- inference (BASELINE configs[3]: prompt -> mel -> linear, Tt=140 as data_input.MAX_TEXT_LEN, always Td steps) ----
     infer = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_inference:
         ci = Config()
         ci.r, ci.vocab_size, ci.num_speakers = 2, 60, args.speakers
         ci.max_decode_iter = Td

@@ -260,7 +260,15 @@ int launch_bigru_fwd(const float* xg, const BiGruWeights& w, const float* h0, fl
 int launch_bigru_bwd(const float* dout, const float* out, const float* ruc, const BiGruBwdWeights& w, const float* h0,
                      float* dxg, float* rh, float* dh0, int B, int T, hipStream_t s) {
   TACO_REQUIRE(B > 0 && T > 0, "bigru_bwd: bad dims");
-  hipLaunchKernelGGL(bigru_bwd_kernel, dim3(B, 2), dim3(NTG), 0, s, dout, out, ruc, w, h0, dxg, rh, dh0, B, T);
+  // The recurrence is latency bound and runs on only 2B workgroups.  Independent GEMMs are scheduled beside it on a side
+  // stream (model.hip); padding this kernel's LDS request to ~148 KB leaves < 16 KB per CU, less than any GEMM tile
+  // needs, so those GEMM workgroups fill the OTHER CUs and never share an issue port with the recurrence.
+  static const size_t pad = [] {
+    const size_t want = 107 * 1024;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(bigru_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)want) == hipSuccess ? want : (size_t)0;
+  }();
+  hipLaunchKernelGGL(bigru_bwd_kernel, dim3(B, 2), dim3(NTG), pad, s, dout, out, ruc, w, h0, dxg, rh, dh0, B, T);
   TACO_LAUNCH_CHECK("bigru_bwd");
   return TACO_OK;
 }

@@ -203,6 +203,46 @@ DecWeights dec_weights(const float* P, const ParamLayout& L) {
   return w;
 }
 
+// Side stream: work that is independent of the main chain runs here while a 64-workgroup recurrent kernel (bi-GRU) or the
+// encoder leaves most of the chip idle.  side_fork(): the side stream waits for everything enqueued on `s` so far;
+// side_join(): `s` waits for the side work.  No host synchronisation; TACO_NO_OVERLAP=1 keeps everything on `s`.
+struct SideStream {
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool off = false;
+};
+SideStream& side_stream() {
+  static thread_local SideStream ss[16];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  SideStream& x = ss[dev & 15];
+  if (!x.side && !x.off) {
+    const char* e = getenv("TACO_NO_OVERLAP");
+    if ((e && atoi(e) != 0) || hipStreamCreateWithFlags(&x.side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&x.ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&x.ev_join, hipEventDisableTiming) != hipSuccess) {
+      x.side = nullptr;
+      x.off = true;
+    }
+  }
+  return x;
+}
+hipStream_t side_fork(hipStream_t s) {
+  SideStream& x = side_stream();
+  if (x.off) return s;
+  if (hipEventRecord(x.ev_fork, s) != hipSuccess || hipStreamWaitEvent(x.side, x.ev_fork, 0) != hipSuccess) return s;
+  return x.side;
+}
+int side_join(hipStream_t s, hipStream_t side) {
+  if (side == s) return TACO_OK;
+  SideStream& x = side_stream();
+  if (hipEventRecord(x.ev_join, side) != hipSuccess || hipStreamWaitEvent(s, x.ev_join, 0) != hipSuccess) {
+    taco_set_error("side_join: event record/wait failed");
+    return TACO_ELAUNCH;
+  }
+  return TACO_OK;
+}
+
 // Decoder composite weights.  The decoder step is a chain of linear maps with few nonlinearities in between; wherever two
 // linear maps follow each other (attention layer -> input projection -> GRU-1 gates; output projection -> query layer /
 // next step's pre_net) their product is formed here once per call, so that the persistent kernel needs one exchange
@@ -266,6 +306,9 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
   const ParamLayout& PL = L.P;
   const int B = sh.B, Tt = sh.Tt, Td = sh.Td, r = sh.r, R80 = kMel * r;
   const int M1 = B * Tt, M2 = B * Td * r;
+  // decoder composites depend on the parameters only: side stream, concurrent with the encoder
+  hipStream_t sd = side_fork(s);
+  TACO_TRY(build_dec_composites(P, PL, W, ws, r, sd));
   // embedding + encoder pre_net (tacotron.py:111-114, 128)
   TACO_TRY(launch_embedding(P + PL.emb, text, ws + W.emb, M1, sh.V, s));
   {
@@ -290,7 +333,7 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
   TACO_TRY(launch_conv_gemm(dense_problem(ws + W.values, kAtt, P + PL.mem_w, kAtt, nullptr, ws + W.keys, kAtt, M1, kAtt,
                                           2 * kCb, TACO_ACT_NONE), s));
   // decoder (tacotron.py:134-138)
-  TACO_TRY(build_dec_composites(P, PL, W, ws, r, s));
+  TACO_TRY(side_join(s, sd));
   DecFwdArgs da;
   da.w = dec_weights(P, PL);
   da.c = dec_composite(ws, W, r);
@@ -704,10 +747,13 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
 
   // ---- final dense (tacotron.py:148): output = post_out . Wd + bd ----
   const float* dOutPad = ws + W.dout_pad;  // (M2, 1028) = sign(output - stft), written by taco_forward
-  TACO_TRY(tn(pb.out, 2 * kCb, 2 * kCb, dOutPad, 1028, kFft, G + PL.post_dense.w, kFft, M2, M2, 0, s, 1, G + PL.post_dense.b, 1028));
   float* dPostOut = sc.gG;  // (M2,256); consumed by the bi-GRU backward before gG is reused
   TACO_TRY(launch_conv_gemm(dense_problem(dOutPad, 1028, PT + TL.post_dense, 2 * kCb, nullptr, dPostOut, 2 * kCb, M2, 2 * kCb,
                                           1028 /* K padded: dOutPad pad columns and WdT pad rows are zero */, TACO_ACT_NONE), s));
+  // (weight gradient on the side stream, forked here: it runs beside the post-net bi-GRU backward -- the first kernel of
+  // cbhg_bwd -- which occupies 64 of 256 CUs)
+  hipStream_t side = side_fork(s);
+  TACO_TRY(tn(pb.out, 2 * kCb, 2 * kCb, dOutPad, 1028, kFft, G + PL.post_dense.w, kFft, M2, M2, 0, side, 1, G + PL.post_dense.b, 1028));
   // ---- post-net CBHG (input = seq2seq_output viewed as (B, Td*r, 80)) ----
   float* dPostIn = sc.gC;   // (M2, 80)
   TACO_TRY(cbhg_bwd(P, PT, G, PL.post, TL.post, seq2seq_output, dPostOut, B, F, pb, sc, dPostIn, s));
@@ -748,8 +794,31 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     TACO_TRY(launch_decoder_bwd(a, s));
     prof_end(1, slot, s);
   }
-  // ---- decoder weight gradients: dense GEMMs over the B*Td stashed rows, all independent -> one grouped launch ----
+  // ---- attention memory: dvalues[b] = alignments[b]^T . dctx[b] ; keys = values . Wm ----
   {
+    GemmTnArgs a;
+    a.A = alignments; a.lda = Tt; a.Y = gs + kGsCtx; a.ldy = kGsRec; a.W = ws + W.dvalues; a.ldw = kAtt;
+    a.M = Td; a.N = kAtt; a.K = Tt; a.taps = 1; a.T = Td; a.pad_l = 0; a.batch = B;
+    a.strideA = (int64_t)Td * Tt; a.strideY = (int64_t)Td * kGsRec; a.strideW = (int64_t)Tt * kAtt;
+    TACO_TRY(launch_gemm_tn(a, false, s));
+  }
+  TACO_TRY(tn(ws + W.values, kAtt, 2 * kCb, ws + W.dkeys, kAtt, kAtt, G + PL.mem_w, kAtt, M1, M1, 0, s));
+  float* dValTot = sc.gE;   // (M1,256)
+  {
+    ConvGemmProblem p = dense_problem(ws + W.dkeys, kAtt, PT + TL.mem_w, 2 * kCb, nullptr, dValTot, 2 * kCb, M1, 2 * kCb, kAtt,
+                                      TACO_ACT_NONE);
+    p.residual = ws + W.dvalues;
+    p.ldr = kAtt;
+    TACO_TRY(launch_conv_gemm(p, s));
+  }
+  float* dEnc = sc.gG;      // (M1,256)
+  TACO_TRY(launch_mask_rows(dValTot, text_length, dEnc, B, Tt, 2 * kCb, s));
+  // ---- decoder weight gradients: dense GEMMs over the B*Td stashed rows, all independent -> one grouped launch, on the
+  //      side stream, forked HERE so that they start together with the encoder bi-GRU backward (first kernel of cbhg_bwd),
+  //      which occupies only 64 CUs; nothing below depends on them ----
+  {
+    hipStream_t main_s = s;
+    hipStream_t s = side_fork(main_s);   // shadows the main stream inside this block
     TnGroup dec_group(s);
     const float* prein = ws + W.prein;
     TACO_TRY(tn(prein, kMel, kMel, gs + kGsP1, kGsRec, kPre1, G + PL.dec_pre1.w, kPre1, MD, Td, 0, s, 1, G + PL.dec_pre1.b));
@@ -802,25 +871,6 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     b2.p[1].residual = G + PL.out_proj.b + (R80 - kMel); b2.p[1].ldr = R80;
     TACO_TRY(launch_conv_gemm_batch(b2, s));
   }
-  // ---- attention memory: dvalues[b] = alignments[b]^T . dctx[b] ; keys = values . Wm ----
-  {
-    GemmTnArgs a;
-    a.A = alignments; a.lda = Tt; a.Y = gs + kGsCtx; a.ldy = kGsRec; a.W = ws + W.dvalues; a.ldw = kAtt;
-    a.M = Td; a.N = kAtt; a.K = Tt; a.taps = 1; a.T = Td; a.pad_l = 0; a.batch = B;
-    a.strideA = (int64_t)Td * Tt; a.strideY = (int64_t)Td * kGsRec; a.strideW = (int64_t)Tt * kAtt;
-    TACO_TRY(launch_gemm_tn(a, false, s));
-  }
-  TACO_TRY(tn(ws + W.values, kAtt, 2 * kCb, ws + W.dkeys, kAtt, kAtt, G + PL.mem_w, kAtt, M1, M1, 0, s));
-  float* dValTot = sc.gE;   // (M1,256)
-  {
-    ConvGemmProblem p = dense_problem(ws + W.dkeys, kAtt, PT + TL.mem_w, 2 * kCb, nullptr, dValTot, 2 * kCb, M1, 2 * kCb, kAtt,
-                                      TACO_ACT_NONE);
-    p.residual = ws + W.dvalues;
-    p.ldr = kAtt;
-    TACO_TRY(launch_conv_gemm(p, s));
-  }
-  float* dEnc = sc.gG;      // (M1,256)
-  TACO_TRY(launch_mask_rows(dValTot, text_length, dEnc, B, Tt, 2 * kCb, s));
   // ---- encoder CBHG ----
   float* dP2 = sc.gC;       // (M1,128)
   if (PL.enc.spk) {
@@ -843,6 +893,7 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
   TACO_TRY(launch_conv_gemm(dense_problem(dz1, kPre1, PT + TL.enc_pre1, kEmbed, nullptr, dEmb, kEmbed, M1, kEmbed, kPre1,
                                           TACO_ACT_NONE), s));
   TACO_TRY(launch_embedding_bwd(dEmb, text, G + PL.emb, M1, shape->V, s));
+  TACO_TRY(side_join(s, side));
   return TACO_OK;
 }
 
