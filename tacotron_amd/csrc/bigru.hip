@@ -32,7 +32,10 @@ __device__ __forceinline__ float quad_sum(float v) {
   return v;
 }
 
-constexpr int NTG = 512;      // 8 waves = 2 per SIMD: a lone wave per SIMD only issues ~1 instruction per 4 cycles
+constexpr int NTG = 512;
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }   // v_pk_fma_f32
+__device__ __forceinline__ float hsum(f2 v) { return v.x + v.y; }      // 8 waves = 2 per SIMD: a lone wave per SIMD only issues ~1 instruction per 4 cycles
 constexpr int CH = 8;         // time steps per DMA chunk
 
 // Forward.  grid = (B, 2 directions); block = 512.
@@ -52,15 +55,16 @@ __global__ __launch_bounds__(NTG, 2) void bigru_fwd_kernel(const float* __restri
   __shared__ float us[H];
   __shared__ __attribute__((aligned(16))) float xgs[2][CH][3 * H];
 
-  float wr[H / 4], wu[H / 4], wcand[H / 4];   // Wg_h[32kq + k][cp], Wg_h[..][128 + cp], Wc_h[32kq + k][cp]
+  // Wg_h[32kq + k][cp], Wg_h[..][128 + cp], Wc_h[32kq + k][cp], held as k-pairs so the dot products run on v_pk_fma_f32
+  f2 wr[H / 8], wu[H / 8], wcand[H / 8];
   {
     const float* wg = w.wg[d] + (int64_t)(H + kq * (H / 4)) * (2 * H) + cp;
     const float* wc = w.wc[d] + (int64_t)(H + kq * (H / 4)) * H + cp;
 #pragma unroll
-    for (int k = 0; k < H / 4; ++k) {
-      wr[k] = wg[(int64_t)k * (2 * H)];
-      wu[k] = wg[(int64_t)k * (2 * H) + H];
-      wcand[k] = wc[(int64_t)k * H];
+    for (int k = 0; k < H / 8; ++k) {
+      wr[k] = f2{wg[(int64_t)(2 * k) * (2 * H)], wg[(int64_t)(2 * k + 1) * (2 * H)]};
+      wu[k] = f2{wg[(int64_t)(2 * k) * (2 * H) + H], wg[(int64_t)(2 * k + 1) * (2 * H) + H]};
+      wcand[k] = f2{wc[(int64_t)(2 * k) * H], wc[(int64_t)(2 * k + 1) * H]};
     }
   }
   if (t_ < H) hs[t_] = h0 ? h0[(int64_t)b * H + t_] : 0.f;   // initial_state_fw = initial_state_bw = s (ops.py:123-124)
@@ -86,17 +90,16 @@ __global__ __launch_bounds__(NTG, 2) void bigru_fwd_kernel(const float* __restri
     if (i == 0 && (c + 1) * CH < T) dma_chunk(c + 1);
     const float* xrow = &xgs[c & 1][i][0];
     // ---- gates ----
-    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+    f2 a0 = {0.f, 0.f}, a1 = a0, b0 = a0, b1 = a0;
 #pragma unroll
     for (int k4 = 0; k4 < H / 16; ++k4) {
       const float4 hv = reinterpret_cast<const float4*>(hs)[kq * (H / 16) + k4];
-      a0 = fmaf(hv.x, wr[4 * k4 + 0], a0); b0 = fmaf(hv.x, wu[4 * k4 + 0], b0);
-      a1 = fmaf(hv.y, wr[4 * k4 + 1], a1); b1 = fmaf(hv.y, wu[4 * k4 + 1], b1);
-      a0 = fmaf(hv.z, wr[4 * k4 + 2], a0); b0 = fmaf(hv.z, wu[4 * k4 + 2], b0);
-      a1 = fmaf(hv.w, wr[4 * k4 + 3], a1); b1 = fmaf(hv.w, wu[4 * k4 + 3], b1);
+      const f2 h01 = {hv.x, hv.y}, h23 = {hv.z, hv.w};
+      a0 = pk_fma(h01, wr[2 * k4], a0); b0 = pk_fma(h01, wu[2 * k4], b0);
+      a1 = pk_fma(h23, wr[2 * k4 + 1], a1); b1 = pk_fma(h23, wu[2 * k4 + 1], b1);
     }
-    const float rg = sigmoid_fast(quad_sum(a0 + a1) + xrow[cp]);
-    const float ug = sigmoid_fast(quad_sum(b0 + b1) + xrow[H + cp]);
+    const float rg = sigmoid_fast(quad_sum(hsum(a0 + a1)) + xrow[cp]);
+    const float ug = sigmoid_fast(quad_sum(hsum(b0 + b1)) + xrow[H + cp]);
     const float hprev = hs[cp];
     if (kq == 0) {
       rhs[cp] = rg * hprev;
@@ -104,16 +107,14 @@ __global__ __launch_bounds__(NTG, 2) void bigru_fwd_kernel(const float* __restri
     }
     lds_barrier();
     // ---- candidate ----
-    float p0 = 0.f, p1 = 0.f;
+    f2 p0 = {0.f, 0.f}, p1 = p0;
 #pragma unroll
     for (int k4 = 0; k4 < H / 16; ++k4) {
       const float4 rv = reinterpret_cast<const float4*>(rhs)[kq * (H / 16) + k4];
-      p0 = fmaf(rv.x, wcand[4 * k4 + 0], p0);
-      p1 = fmaf(rv.y, wcand[4 * k4 + 1], p1);
-      p0 = fmaf(rv.z, wcand[4 * k4 + 2], p0);
-      p1 = fmaf(rv.w, wcand[4 * k4 + 3], p1);
+      p0 = pk_fma(f2{rv.x, rv.y}, wcand[2 * k4], p0);
+      p1 = pk_fma(f2{rv.z, rv.w}, wcand[2 * k4 + 1], p1);
     }
-    const float cpre = quad_sum(p0 + p1) + xrow[2 * H + cp];
+    const float cpre = quad_sum(hsum(p0 + p1)) + xrow[2 * H + cp];
     // every wave's share of the next chunk has had CH-1 steps to land; wait before this step's (younger) stores are issued
     if (i == CH - 1) wait_vm0();
     if (kq == 0) {
@@ -145,20 +146,22 @@ __global__ __launch_bounds__(NTG, 2) void bigru_bwd_kernel(const float* __restri
                                                            int T) {
   const int b = blockIdx.x, d = blockIdx.y, t_ = threadIdx.x;
   const int cp = t_ >> 2, kq = t_ & 3, lane = t_ & 63, wv = t_ >> 6;
-  __shared__ __attribute__((aligned(16))) float dcp_s[H];
-  __shared__ __attribute__((aligned(16))) float dgp_s[2 * H];
+  // double buffered by step parity: the next step's writes never race with this step's reads, so a step needs only the two
+  // barriers its own dependences require
+  __shared__ __attribute__((aligned(16))) float dcp_s2[2][H];
+  __shared__ __attribute__((aligned(16))) float dgp_s2[2][2 * H];
   __shared__ __attribute__((aligned(16))) float in_s[2][CH][5 * H];   // [r | u | c | dout | h_prev]
 
   // wchT (128 [c], 128 [k]): d(rh)[cp] = sum_c dcp[c] * wchT[c][cp]      -> this lane: c in [32kq, 32kq+32)
   // wghT (256 [j], 128 [k]): dh[cp]   += sum_j dgp[j] * wghT[j][cp]      -> this lane: j in [64kq, 64kq+64)
-  float wc_r[H / 4], wg_r[H / 2];
+  f2 wc_r[H / 8], wg_r[H / 4];   // row pairs, for v_pk_fma_f32
   {
     const float* p = w.wchT[d] + (int64_t)(kq * (H / 4)) * H + cp;
 #pragma unroll
-    for (int i = 0; i < H / 4; ++i) wc_r[i] = p[(int64_t)i * H];
+    for (int i = 0; i < H / 8; ++i) wc_r[i] = f2{p[(int64_t)(2 * i) * H], p[(int64_t)(2 * i + 1) * H]};
     const float* q = w.wghT[d] + (int64_t)(kq * (H / 2)) * H + cp;
 #pragma unroll
-    for (int i = 0; i < H / 2; ++i) wg_r[i] = q[(int64_t)i * H];
+    for (int i = 0; i < H / 4; ++i) wg_r[i] = f2{q[(int64_t)(2 * i) * H], q[(int64_t)(2 * i + 1) * H]};
   }
 
   const int64_t row0 = (int64_t)b * T;
@@ -197,6 +200,8 @@ __global__ __launch_bounds__(NTG, 2) void bigru_bwd_kernel(const float* __restri
   for (int s = 0, t = tstart; s < T; ++s, t += tstep) {
     const int c = s / CH, i = s - c * CH;
     if (i == 0 && (c + 1) * CH < T) dma_chunk(c + 1);
+    float* dcp_s = dcp_s2[s & 1];
+    float* dgp_s = dgp_s2[s & 1];
     const float* in = &in_s[c & 1][i][0];
     const float r = in[cp], u = in[H + cp], cc = in[2 * H + cp], hp = in[4 * H + cp];
     const float dht = dh + in[3 * H + cp];
@@ -214,34 +219,32 @@ __global__ __launch_bounds__(NTG, 2) void bigru_bwd_kernel(const float* __restri
     }
     lds_barrier();
     // d(rh)[cp]
-    float p0 = 0.f, p1 = 0.f;
+    f2 p0 = {0.f, 0.f}, p1 = p0;
 #pragma unroll
     for (int i4 = 0; i4 < H / 16; ++i4) {
       const float4 v = reinterpret_cast<const float4*>(dcp_s)[kq * (H / 16) + i4];
-      p0 = fmaf(v.x, wc_r[4 * i4 + 0], p0);
-      p1 = fmaf(v.y, wc_r[4 * i4 + 1], p1);
-      p0 = fmaf(v.z, wc_r[4 * i4 + 2], p0);
-      p1 = fmaf(v.w, wc_r[4 * i4 + 3], p1);
+      p0 = pk_fma(f2{v.x, v.y}, wc_r[2 * i4], p0);
+      p1 = pk_fma(f2{v.z, v.w}, wc_r[2 * i4 + 1], p1);
     }
-    const float drh = quad_sum(p0 + p1);
+    const float drh = quad_sum(hsum(p0 + p1));
     const float drp = drh * hp * r * (1.f - r);
     if (kq == 0) {
       dgp_s[cp] = drp;
       dxg[(row0 + t) * (6 * H) + d * 3 * H + cp] = drp;
     }
     lds_barrier();
-    float q0 = 0.f, q1 = 0.f;
+    f2 q0 = {0.f, 0.f}, q1 = q0;
 #pragma unroll
     for (int i4 = 0; i4 < H / 8; ++i4) {
       const float4 v = reinterpret_cast<const float4*>(dgp_s)[kq * (H / 8) + i4];
-      q0 = fmaf(v.x, wg_r[4 * i4 + 0], q0);
-      q1 = fmaf(v.y, wg_r[4 * i4 + 1], q1);
-      q0 = fmaf(v.z, wg_r[4 * i4 + 2], q0);
-      q1 = fmaf(v.w, wg_r[4 * i4 + 3], q1);
+      q0 = pk_fma(f2{v.x, v.y}, wg_r[2 * i4], q0);
+      q1 = pk_fma(f2{v.z, v.w}, wg_r[2 * i4 + 1], q1);
     }
-    dh = dht * u + drh * r + quad_sum(q0 + q1);
-    if (i == CH - 1) wait_vm0();   // next chunk landed (one store-latency wait per CH steps)
-    lds_barrier();                             // dcp_s / dgp_s are rewritten by the next step
+    dh = dht * u + drh * r + quad_sum(hsum(q0 + q1));
+    if (i == CH - 1) {   // chunk boundary: the next chunk has landed (one store-latency wait per CH steps) and is published
+      wait_vm0();
+      lds_barrier();
+    }
   }
   if (dh0 && kq == 0) dh0[((int64_t)d * B + b) * H + cp] = dh;   // gradient w.r.t. the initial state
 }
