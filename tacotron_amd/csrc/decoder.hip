@@ -1145,7 +1145,8 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
   }
 }
 
-// Largest cluster width in {8,4,2,1} whose B*P workgroups are all co-resident (the all-gather needs every peer running).
+// Largest cluster width in {32,...,2,1} whose B*P workgroups are all co-resident (the all-gather needs every peer running).
+// The mat-vecs are bound by the per-CU vector-memory path (64 B/clk), so small batches spread a row over more CUs.
 template <class K>
 int pick_cluster(K kernel, size_t smem, int B, int want) {
   int dev = 0, cus = 0, per_cu = 0;
@@ -1153,16 +1154,19 @@ int pick_cluster(K kernel, size_t smem, int B, int want) {
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 1;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, NT, smem) != hipSuccess) return 1;
   const int64_t cap = (int64_t)cus * per_cu;
-  for (int p = 8; p >= 2; p >>= 1)
+  for (int p = 32; p >= 2; p >>= 1)
     if (p <= want && (int64_t)B * p <= cap) return p;
   return 1;
 }
 
-int env_cluster() {
+// Training uses at most 8 peers so that results are bit-identical for every per-GPU batch <= 32 (the summation order
+// depends on the cluster width; data-parallel shards of a batch must reproduce the unsharded gradients exactly).  Inference
+// has no such contract and takes 16 peers when they fit (B <= 16): -7 % per decoder step.  TACO_DEC_CLUSTER overrides.
+int env_cluster(int dflt) {
   const char* e = getenv("TACO_DEC_CLUSTER");
-  if (!e) return 8;
+  if (!e) return dflt;
   const int v = atoi(e);
-  return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 8;
+  return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) ? v : dflt;
 }
 
 }  // namespace
@@ -1188,7 +1192,7 @@ int launch_decoder_fwd(DecFwdArgs a, hipStream_t s) {
       return TACO_ELAUNCH;
     }
   }
-  a.P = pick_cluster(kern, smem, a.B, env_cluster());
+  a.P = pick_cluster(kern, smem, a.B, env_cluster(a.mel ? 8 : 16));
   if (a.P > 1) {
     hipError_t e = hipMemsetAsync(a.xchg, 0, (size_t)decoder_xchg_bytes(a.B, a.Tt), s);
     if (e != hipSuccess) {
@@ -1216,7 +1220,7 @@ int launch_decoder_bwd(DecBwdArgs a, hipStream_t s) {
       return TACO_ELAUNCH;
     }
   }
-  a.P = pick_cluster(kern, smem, a.B, env_cluster());
+  a.P = pick_cluster(kern, smem, a.B, env_cluster(8));
   if (a.P > 1) {
     hipError_t e = hipMemsetAsync(a.xchg, 0, (size_t)decoder_xchg_bytes(a.B, a.Tt), s);
     if (e != hipSuccess) {

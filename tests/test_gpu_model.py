@@ -244,7 +244,7 @@ def test_backward_without_masks_and_ragged_lengths(built_lib):
     assert not bad, bad
 
 
-@pytest.mark.parametrize('cluster', ['8', '4', '2', '1'])
+@pytest.mark.parametrize('cluster', ['32', '16', '8', '4', '2', '1'])
 def test_long_text_and_cluster_widths(built_lib, cluster, monkeypatch):
     """Tt = 300 (> 256) leaves the register-resident attention rows and exercises the streamed fall-back paths of both
     decoder kernels; TACO_DEC_CLUSTER forces the narrower cluster widths used when B * 8 workgroups are not co-resident;
