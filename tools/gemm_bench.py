@@ -23,6 +23,8 @@ NN = [  # name, M, T, N, K, taps
     ('bank k=16 alone', 6400, 200, 128, 128, 16),
     ('highway 128', 6400, 6400, 128, 128, 1),
     ('enc prenet', 6400, 6400, 256, 256, 1),
+    ('square 4096', 4096, 4096, 4096, 4096, 1),
+    ('enc bank k=8 alone', 6400, 200, 128, 128, 8),
 ]
 for name, M, T, N, K, taps in NN:
     A = torch.randn(M, K, device='cuda'); W = torch.randn(taps, K, N, device='cuda') * 0.05; C = torch.empty(M, N, device='cuda')
