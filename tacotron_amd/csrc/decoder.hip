@@ -3,15 +3,20 @@
 // in SURVEY.md §8a rows a11-a15).
 //
 // ONE launch replaces the reference's 180-iteration tf.while_loop (~13k op launches).  A CLUSTER of P workgroups
-// (512 threads each) owns ONE batch row for ALL Td steps; workgroup `peer` of the cluster computes the column slice
-// [peer*N/P, (peer+1)*N/P) of every mat-vec phase.  Block b -> (row = b / P, peer = b % P); the dispatcher places block b
-// on XCD b % 8 (a speed assumption only), so with P = 8 every XCD's L2 holds just its 1/8 slice (0.8 MB) of the
-// 6.35 MB decoder weight set, shared by all rows, instead of thrashing on the whole set (round-1 v0 measured
-// 10.5 GB/launch of L2 misses).  All recurrent state is replicated in each peer's LDS; after every phase the peers
-// all-gather the phase's output vector (<= 512 floats) through 8-byte {epoch tag, value} granules written with ONE
+// (512 threads each; P = 8, or 16 at inference when they fit) owns ONE batch row for ALL Td steps; workgroup `peer` of the
+// cluster computes the column slice [peer*N/P, (peer+1)*N/P) of every mat-vec.  Block b -> (row = b / P, peer = b % P);
+// the dispatcher places block b on XCD b % 8 (measured, tools/micro/pingpong.hip; a speed assumption only), so every XCD's
+// L2 holds just its 1/8 slice of the decoder weight set, shared by all rows, instead of thrashing on the whole set
+// (round-1 v0 measured 10.5 GB/launch of L2 misses).  All recurrent state is replicated in each peer's LDS; after every
+// round the peers all-gather the round's output vectors through 8-byte {epoch tag, value} granules written with ONE
 // agent-scope store and polled with agent-scope loads (MI355X guide, Guideline 16 recipe R2: the data is the flag, no
-// fence, placement independent).  Every spin is bounded; a timeout raises `err` and the launch drains.
-// Attention energies/softmax/context are a fused wave-reduction phase (one wave per memory row, __shfl_xor).
+// fence, placement independent; one hop measures 0.3-0.5 us).  Every spin is bounded; a timeout raises `err` and the
+// launch drains.
+//
+// A step is 9 exchange rounds forward and 10 backward: wherever two linear maps of the reference's cell follow each other
+// without a nonlinearity (attention layer -> input projection -> GRU-1 gates, output projection -> query layer / next
+// pre_net), the host forms their product once per call (DecComposite, model.hip) and the kernel runs them as one round.
+// The next round's first weight rows are prefetched into registers while the all-gather is in flight.
 //
 // The backward kernel walks the steps in reverse with the same structure on pre-transposed weights and emits the
 // per-step pre-activation gradients ("gstash"); all weight gradients are then dense MFMA GEMMs over B*Td rows.
