@@ -271,7 +271,8 @@ int launch_bigru_bwd(const float* dout, const float* out, const float* ruc, cons
     return hipFuncSetAttribute(reinterpret_cast<const void*>(bigru_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)want) == hipSuccess ? want : (size_t)0;
   }();
-  hipLaunchKernelGGL(bigru_bwd_kernel, dim3(B, 2), dim3(NTG), pad, s, dout, out, ruc, w, h0, dxg, rh, dh0, B, T);
+  // (only while the recurrence leaves CUs free for those GEMMs: with more sequences it needs every CU slot itself)
+  hipLaunchKernelGGL(bigru_bwd_kernel, dim3(B, 2), dim3(NTG), 2 * B <= 128 ? pad : 0, s, dout, out, ruc, w, h0, dxg, rh, dh0, B, T);
   TACO_LAUNCH_CHECK("bigru_bwd");
   return TACO_OK;
 }
