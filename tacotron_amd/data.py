@@ -35,6 +35,35 @@ def pad(text, max_len, pad_val):
                      for t in text], dtype=np.int32)
 
 
+class Vocab:
+    """preprocess.py:19-22,130-135: the character vocabulary grows in first-seen order, '<pad>' is id 0.
+    `process_char` is the reference's function of the same name; `ivocab` is what `load_prompts` consumes."""
+
+    def __init__(self):
+        self.vocab = {'<pad>': 0}
+        self.ivocab = {0: '<pad>'}
+
+    def process_char(self, char):
+        if char not in self.vocab:
+            nxt = len(self.vocab)
+            self.vocab[char] = nxt
+            self.ivocab[nxt] = char
+        return self.vocab[char]
+
+    def encode(self, prompt):
+        return [self.process_char(ch) for ch in prompt]
+
+
+def pad_to_dense(inputs):
+    """preprocess.pad_to_dense (preprocess.py:137-146): ragged 1-D / 2-D arrays -> one zero-padded dense stack."""
+    max_len = max(r.shape[0] for r in inputs)
+    if inputs[0].ndim == 1:
+        padded = [np.pad(a, (0, max_len - a.shape[0]), 'constant', constant_values=0) for a in inputs]
+    else:
+        padded = [np.pad(a, ((0, max_len - a.shape[0]), (0, 0)), 'constant', constant_values=0) for a in inputs]
+    return np.stack(padded)
+
+
 def load_prompts(prompts, ivocab, batch_size=32):
     """data_input.load_prompts (data_input.py:92-108) without the TF queue: unknown characters are dropped,
     `text_length = len(raw line)` (it counts the newline and dropped characters -- reproduced as is), prompts are padded

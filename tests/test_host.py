@@ -8,7 +8,7 @@ import torch
 
 from tacotron_amd import config as cfg
 from tacotron_amd.audio import reshape_frames
-from tacotron_amd.data import load_prompts, pad, synthetic_batch
+from tacotron_amd.data import Vocab, load_prompts, pad, pad_to_dense, synthetic_batch
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
@@ -84,3 +84,32 @@ def test_param_init_rules(built_lib):
     d = pb.to_dict()
     pb2 = ParamBuffer(pb.shape).load_dict_(d)
     assert torch.equal(pb.flat, pb2.flat)
+
+
+def test_text_frontend_matches_reference_vectors():
+    """data_input.pad, preprocess.process_char and preprocess.pad_to_dense pinned by vectors generated from the
+    REFERENCE's own functions (tests/golden/make_text_golden.py)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'text_frontend.npz'))
+    lens = g['pad_lens'].tolist()
+    flat = g['pad_flat'].tolist()
+    rows, o = [], 0
+    for n in lens:
+        rows.append(flat[o:o + n])
+        o += n
+    a = pad(rows, 140, 0)
+    assert a.dtype == g['pad_out_140_0'].dtype and np.array_equal(a, g['pad_out_140_0'])
+    assert np.array_equal(pad(rows, 12, 9), g['pad_out_12_9'])
+    v = Vocab()
+    ids = [v.encode(str(p)) for p in g['prompts']]
+    assert [i for r in ids for i in r] == g['char_ids_flat'].tolist()
+    assert [len(r) for r in ids] == g['char_lens'].tolist()
+    items = sorted(v.vocab.items(), key=lambda kv: kv[1])
+    assert [k for k, _ in items] == [str(c) for c in g['vocab_chars']]
+    assert [i for _, i in items] == g['vocab_ids'].tolist()
+    d1 = pad_to_dense([np.array(r, dtype=np.int32) for r in ids])
+    assert d1.dtype == g['dense_1d'].dtype and np.array_equal(d1, g['dense_1d'])
+    d2 = pad_to_dense([g['mat_0'], g['mat_1'], g['mat_2']])
+    assert d2.dtype == g['dense_2d'].dtype and np.array_equal(d2, g['dense_2d'])
+    # the vocabulary feeds load_prompts exactly as the reference's pickled ivocab does
+    b = next(load_prompts(['Hello'], v.ivocab, batch_size=4))
+    assert b['text'][0, :5].tolist() == ids[0][:5]
