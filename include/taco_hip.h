@@ -111,7 +111,8 @@ int taco_forward(const TacoShape* shape, const float* params, const int32_t* tex
                  float* output, float* alignments, float* loss, void* workspace, void* stream);
 
 /* Gradient of loss w.r.t. every parameter (opt.compute_gradients, tacotron.py:172), after taco_forward on the same
- * workspace with the same inputs / masks.  seq2seq_output and alignments are the tensors taco_forward produced.
+ * workspace with the same PARAMETERS, inputs and masks (taco_forward also leaves the transposed weight copies the
+ * backward pass reads in the workspace).  seq2seq_output and alignments are the tensors taco_forward produced.
  * grads has taco_param_count floats and is overwritten. */
 int taco_backward(const TacoShape* shape, const float* params, const int32_t* text, const int32_t* text_length,
                   const int32_t* speaker, const float* seq2seq_output, const float* alignments, const uint8_t* enc_keep1,

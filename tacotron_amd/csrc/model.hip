@@ -298,6 +298,9 @@ DecComposite dec_composite(const float* ws, const WsLayout& W, int r) {
   return c;
 }
 
+int prepare_transposes(const float* P, const ParamLayout& L, const TransLayout& T, float* PT, int r, hipStream_t s);
+int build_dec_composites_bwd(const float* P, const ParamLayout& PL, const WsLayout& W, float* ws, int r, hipStream_t s);
+
 // encoder + attention memory + decoder + post-net; shared by train and inference forward.
 int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const float* P, const int32_t* text,
                  const int32_t* text_length, const int32_t* speaker, const float* mel, const uint8_t* ek1, const uint8_t* ek2, const uint8_t* dk1,
@@ -309,6 +312,12 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
   // decoder composites depend on the parameters only: side stream, concurrent with the encoder
   hipStream_t sd = side_fork(s);
   TACO_TRY(build_dec_composites(P, PL, W, ws, r, sd));
+  if (train) {
+    // everything the backward pass derives from the parameters alone (transposed / tap-flipped weight copies, transposed
+    // composites) is built here, beside the encoder, instead of at the head of taco_backward's critical path
+    TACO_TRY(prepare_transposes(P, PL, L.T, ws + W.paramsT, r, sd));
+    TACO_TRY(build_dec_composites_bwd(P, PL, W, ws, r, sd));
+  }
   // embedding + encoder pre_net (tacotron.py:111-114, 128)
   TACO_TRY(launch_embedding(P + PL.emb, text, ws + W.emb, M1, sh.V, s));
   {
@@ -741,7 +750,7 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     taco_set_error("taco_backward: memset: %s", hipGetErrorString(e));
     return TACO_ELAUNCH;
   }
-  TACO_TRY(prepare_transposes(P, PL, TL, PT, r, s));
+  // (the transposed weights PT and the transposed decoder composites were built by taco_forward on this workspace)
   BwdScratch sc{ws + W.gA, ws + W.gB, ws + W.gC, ws + W.gD, ws + W.gE, ws + W.gF, ws + W.gG};
   CbhgBufs pb = cbhg_bufs(ws, W.post), eb = cbhg_bufs(ws, W.enc);
 
@@ -762,7 +771,6 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
   TACO_TRY(launch_add(ws + W.ds2s, dPostIn, dS2S, (int64_t)MD * R80, s));
 
   // ---- decoder BPTT ----
-  TACO_TRY(build_dec_composites_bwd(P, PL, W, ws, r, s));
   {
     hipError_t e2 = hipMemsetAsync(ws + W.bc_g, 0, sizeof(float) * (size_t)(W.bc_cp + kPre1 - W.bc_g), s);
     if (e2 != hipSuccess) {
