@@ -150,7 +150,7 @@ struct DecWeights {
   const float *out_w, *out_b;                      // (256,80r)
   const float* q_w;                                // (80r,256)
   const float* att_v;                              // (256)
-  const float* att_w;                              // (80r+256,256)
+  const float* att_w;                              // (80r+256,256)  host side only (composites); the kernels read DecComposite
 };
 // per-(b,t) forward stash record (floats)
 constexpr int kStP1 = 0;                  // 256  pre-net layer 1 (post relu, post dropout)
@@ -162,7 +162,7 @@ constexpr int kStU = 2176;                // 3*256
 constexpr int kStC = 2944;                // 3*256
 constexpr int kStRH = 3712;               // 3*256 r*h_prev
 constexpr int kStCtx = 4480;              // 256
-constexpr int kStAtt = 4736;              // 256
+constexpr int kStAtt = 4736;              // 256  (slot kept for layout stability; the attention vector is no longer formed)
 constexpr int kStQ = 4992;                // 256
 constexpr int kStY = 5248;                // 256  x + h3 (out-proj input)
 constexpr int kStRec = 5504;
