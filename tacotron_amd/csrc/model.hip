@@ -367,6 +367,17 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
     TACO_TRY(launch_decoder_fwd(da, s));
     prof_end(0, slot, s);
   }
+  hipStream_t sl = s;
+  if (train) {
+    // seq2seq half of add_loss_op (tacotron.py:158) only needs the decoder output: side stream, beside the post-net
+    sl = side_fork(s);
+    hipError_t e = hipMemsetAsync(ws + W.loss, 0, 4 * sizeof(float), sl);
+    if (e != hipSuccess) {
+      taco_set_error("forward: memset: %s", hipGetErrorString(e));
+      return TACO_ELAUNCH;
+    }
+    TACO_TRY(launch_l1(s2s, mel, ws + W.ds2s, R80, ws + W.loss + 1, (int64_t)B * Td, R80, sl));
+  }
   // post-net (tacotron.py:142-152): (B,Td,80r) reinterpreted as (B, Td*r, 80)
   CbhgBufs pb = cbhg_bufs(ws, W.post);
   TACO_TRY(cbhg_fwd(P, PL.post, s2s, B, Td * r, pb, train, s));
@@ -383,7 +394,7 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
     p.Nld = 1028;
     TACO_TRY(launch_conv_gemm(p, s));
   }
-  (void)R80;
+  TACO_TRY(side_join(s, sl));
   return TACO_OK;
 }
 
@@ -697,15 +708,11 @@ extern "C" int taco_forward(const TacoShape* shape, const float* params, const i
   // add_loss_op (tacotron.py:156-165) + sign gradients for the backward pass
   const int R80 = kMel * shape->r;
   const int64_t MD = (int64_t)shape->B * shape->Td, M2 = MD * shape->r;
-  hipError_t e = hipMemsetAsync(ws + W.loss, 0, 4 * sizeof(float), s);
-  if (e != hipSuccess) {
-    taco_set_error("taco_forward: memset: %s", hipGetErrorString(e));
-    return TACO_ELAUNCH;
-  }
-  TACO_TRY(launch_l1(seq2seq_output, mel, ws + W.ds2s, R80, ws + W.loss + 1, MD, R80, s));
+  // (the seq2seq term and the zeroing of the loss slots were issued by forward_impl beside the post-net)
+  (void)R80; (void)MD;
   TACO_TRY(launch_l1(output, stft, ws + W.dout_pad, 1028, ws + W.loss + 2, M2, kFft, s));
   TACO_TRY(launch_finish_loss(ws + W.loss, s));
-  e = hipMemcpyAsync(loss, ws + W.loss, 3 * sizeof(float), hipMemcpyDeviceToDevice, s);
+  hipError_t e = hipMemcpyAsync(loss, ws + W.loss, 3 * sizeof(float), hipMemcpyDeviceToDevice, s);
   if (e != hipSuccess) {
     taco_set_error("taco_forward: memcpy: %s", hipGetErrorString(e));
     return TACO_ELAUNCH;
