@@ -46,13 +46,18 @@ class Tacotron(object):
             self.adam_v = torch.zeros(n, device=dev)
             self._scratch = torch.zeros(8, device=dev)
             self._gnorm = torch.zeros(1, device=dev)
-            self._mask_buf = {
-                'enc_keep1': torch.empty(B, Tt, 256, dtype=torch.uint8, device=dev),
-                'enc_keep2': torch.empty(B, Tt, 128, dtype=torch.uint8, device=dev),
-                'dec_keep1': torch.empty(B, Td, 256, dtype=torch.uint8, device=dev),
-                'dec_keep2': torch.empty(B, Td, 128, dtype=torch.uint8, device=dev),
-                'sample': torch.empty(Td, B, dtype=torch.uint8, device=dev),
-            }
+            # the five mask tensors are views of ONE byte buffer (16-byte aligned pieces), so that neighbours with the same
+            # Bernoulli parameter are filled by a single launch (all five, with the reference's default rates)
+            shapes = (('enc_keep1', (B, Tt, 256)), ('enc_keep2', (B, Tt, 128)), ('dec_keep1', (B, Td, 256)),
+                      ('dec_keep2', (B, Td, 128)), ('sample', (Td, B)))
+            sizes = [((s[0] * s[1] * (s[2] if len(s) > 2 else 1)) + 15) // 16 * 16 for _, s in shapes]
+            self._mask_flat = torch.empty(sum(sizes), dtype=torch.uint8, device=dev)
+            self._mask_buf, self._mask_span, off = {}, {}, 0
+            for (k, s), sz in zip(shapes, sizes):
+                n = s[0] * s[1] * (s[2] if len(s) > 2 else 1)
+                self._mask_buf[k] = self._mask_flat[off:off + n].view(*s)
+                self._mask_span[k] = (off, sz)
+                off += sz
             self._seed = seed * 1000003 + 17
         self.set_inputs(inputs)
 
@@ -75,14 +80,26 @@ class Tacotron(object):
         c = self.config
         m = {}
         self._seed += 5
-        for i, (k, rate) in enumerate((('enc_keep1', c.char_dropout_prob), ('enc_keep2', c.char_dropout_prob),
-                                       ('dec_keep1', c.audio_dropout_prob), ('dec_keep2', c.audio_dropout_prob))):
-            if rate:
-                lib.fill_bernoulli(self._mask_buf[k], 1.0 - rate, self._seed + i)
-                m[k] = self._mask_buf[k]
-        if c.scheduled_sample:
-            lib.fill_bernoulli(self._mask_buf['sample'], c.scheduled_sample, self._seed + 4)
-            m['sample'] = self._mask_buf['sample']
+        want = [('enc_keep1', 1.0 - c.char_dropout_prob if c.char_dropout_prob else None),
+                ('enc_keep2', 1.0 - c.char_dropout_prob if c.char_dropout_prob else None),
+                ('dec_keep1', 1.0 - c.audio_dropout_prob if c.audio_dropout_prob else None),
+                ('dec_keep2', 1.0 - c.audio_dropout_prob if c.audio_dropout_prob else None),
+                ('sample', c.scheduled_sample if c.scheduled_sample else None)]
+        i = 0
+        while i < len(want):
+            k, p = want[i]
+            if p is None:
+                i += 1
+                continue
+            j = i
+            while j + 1 < len(want) and want[j + 1][1] == p:   # run of neighbours with the same parameter: one launch
+                j += 1
+            off = self._mask_span[k][0]
+            end = self._mask_span[want[j][0]][0] + self._mask_span[want[j][0]][1]
+            lib.fill_bernoulli(self._mask_flat[off:end], p, self._seed + i)
+            for q in range(i, j + 1):
+                m[want[q][0]] = self._mask_buf[want[q][0]]
+            i = j + 1
         return m
 
     # -- train ------------------------------------------------------------------------------------------
