@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmBatch batch) {
       const int n = n0 + wn * (32 * WN) + j * 32 + li;
       if (n >= P.N) continue;
       const float bias0 = (P.bias && P.bias_stride == 0) ? P.bias[n] : 0.f;
-      const float sc = P.scale ? P.scale[n] : 1.f;
+      const float sc = P.scale ? P.scale[n] * P.scale_mul : 1.f;
       const float sf = P.shift ? P.shift[n] : 0.f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {

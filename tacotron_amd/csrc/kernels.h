@@ -20,6 +20,7 @@ struct ConvGemmProblem {
   int bias_stride = 0; // 0: one bias vector; else bias[(m / T) * bias_stride + n] (per-sequence bias, e.g. speaker sites)
   int Nld = 0;         // loadable W columns (>= N, multiple of 4, <= ldw) when the storage is padded; 0 = derive from N
   int atomic_out = 0;  // C += result with fp32 atomics (C pre-zeroed by the caller); several problems may share C
+  float scale_mul = 1.f;   // scale[n] is multiplied by this (BN inference: scale = gamma, scale_mul = 1/sqrt(1+eps))
 };
 struct ConvGemmBatch {
   ConvGemmProblem p[kMaxGemmBatch];

@@ -130,18 +130,17 @@ int cbhg_fwd(const float* P, const CbhgP& c, const float* x, int B, int T, const
   // BN-affine + max-pool(2,1,same) (ops.py:64-71)
   TACO_TRY(launch_bn_maxpool(w.bank, P + c.bank_g, P + c.bank_be, w.pool, B, T, KC, s));
   // conv projections (ops.py:75-87) + residual (ops.py:92)
-  TACO_TRY(launch_bn_fold(P + c.p1_g, w.s_p1, c.c1, s));
-  TACO_TRY(launch_bn_fold(P + c.p2_g, w.s_p2, c.c2, s));
+  const float bn_rs = 1.0f / sqrtf(1.0f + kBnEps);   // BN in inference mode: gamma / sqrt(moving_var(=1) + eps), folded in the epilogue
   {
     ConvGemmProblem p;
-    p.A = w.pool; p.lda = KC; p.W = P + c.p1_w; p.ldw = c.c1; p.bias = P + c.p1_b; p.scale = w.s_p1; p.shift = P + c.p1_be;
+    p.A = w.pool; p.lda = KC; p.W = P + c.p1_w; p.ldw = c.c1; p.bias = P + c.p1_b; p.scale = P + c.p1_g; p.scale_mul = bn_rs; p.shift = P + c.p1_be;
     p.C = w.pj1; p.Cpre = w.pj1pre; p.ldc = c.c1; p.M = M; p.N = c.c1; p.K = KC; p.taps = 3; p.T = T; p.pad_l = 1;
     p.act = TACO_ACT_RELU;
     TACO_TRY(launch_conv_gemm(p, s));
   }
   {
     ConvGemmProblem p;
-    p.A = w.pj1; p.lda = c.c1; p.W = P + c.p2_w; p.ldw = c.c2; p.bias = P + c.p2_b; p.scale = w.s_p2; p.shift = P + c.p2_be;
+    p.A = w.pj1; p.lda = c.c1; p.W = P + c.p2_w; p.ldw = c.c2; p.bias = P + c.p2_b; p.scale = P + c.p2_g; p.scale_mul = bn_rs; p.shift = P + c.p2_be;
     p.residual = x; p.ldr = c.cin; p.C = w.res; p.Cpre = w.pj2pre; p.ldc = c.c2; p.M = M; p.N = c.c2; p.K = c.c1;
     p.taps = 3; p.T = T; p.pad_l = 1; p.act = TACO_ACT_NONE;
     TACO_TRY(launch_conv_gemm(p, s));
