@@ -331,10 +331,24 @@ __global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __re
   __shared__ float red[8];
   float acc = 0.f;
   const int64_t n4 = n / 4;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (; i + 3 * stride < n4; i += 4 * stride) {   // four independent 16-byte loads in flight per thread
+    const float4 v0 = reinterpret_cast<const float4*>(x)[i];
+    const float4 v1 = reinterpret_cast<const float4*>(x)[i + stride];
+    const float4 v2 = reinterpret_cast<const float4*>(x)[i + 2 * stride];
+    const float4 v3 = reinterpret_cast<const float4*>(x)[i + 3 * stride];
+    acc += v0.x * v0.x + v0.y * v0.y + v0.z * v0.z + v0.w * v0.w;
+    a1 += v1.x * v1.x + v1.y * v1.y + v1.z * v1.z + v1.w * v1.w;
+    a2 += v2.x * v2.x + v2.y * v2.y + v2.z * v2.z + v2.w * v2.w;
+    a3 += v3.x * v3.x + v3.y * v3.y + v3.z * v3.z + v3.w * v3.w;
+  }
+  for (; i < n4; i += stride) {
     const float4 v = reinterpret_cast<const float4*>(x)[i];
     acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
   }
+  acc += (a1 + a2) + a3;
   if (blockIdx.x == 0 && threadIdx.x < (n - n4 * 4)) {
     const float v = x[n4 * 4 + threadIdx.x];
     acc += v * v;
@@ -406,8 +420,8 @@ int launch_bn_maxpool(const float* x, const float* gamma, const float* beta, flo
   return TACO_OK;
 }
 static inline void col_grid(int64_t M, int N, dim3& grid, int& rpb) {
-  int chunks = (int)((M + 127) / 128);
-  if (chunks > 512) chunks = 512;
+  int chunks = (int)((M + 31) / 32);   // 8 rows per thread: enough blocks to cover 256 CUs even for 128-column tensors
+  if (chunks > 2048) chunks = 2048;
   if (chunks < 1) chunks = 1;
   rpb = (int)((M + chunks - 1) / chunks);
   grid = dim3((N + 63) / 64, (unsigned)((M + rpb - 1) / rpb));
