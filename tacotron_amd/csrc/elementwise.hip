@@ -476,7 +476,8 @@ int launch_add(const float* a, const float* b, float* y, int64_t n, hipStream_t 
 }
 int launch_l1(const float* a, const float* b, float* grad, int ldg, float* loss_slot, int64_t M, int N, hipStream_t s) {
   TACO_REQUIRE(ldg >= N, "l1: ldg < N");
-  hipLaunchKernelGGL(l1_kernel, dim3(grid_for(M * ldg, kThreads, 2048)), dim3(kThreads), 0, s, a, b, grad, ldg, loss_slot, M, N);
+  // <= 512 blocks: every block ends with an atomicAdd on the one loss word, and same-address atomics serialise
+  hipLaunchKernelGGL(l1_kernel, dim3(grid_for(M * ldg, kThreads, 512)), dim3(kThreads), 0, s, a, b, grad, ldg, loss_slot, M, N);
   TACO_LAUNCH_CHECK("l1");
   return TACO_OK;
 }
@@ -509,7 +510,8 @@ int launch_transpose_batch(TransposeBatch& b, hipStream_t s) {
 }
 int launch_sumsq(const float* x, int64_t n, float* out, hipStream_t s) {
   TACO_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "sumsq: x must be 16-byte aligned");
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4 + 1, kThreads, 1024)), dim3(kThreads), 0, s, x, n, out);
+  // one block per CU: the per-block atomicAdd on the single result word serialises (~15 ns each)
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4 + 1, kThreads, 256)), dim3(kThreads), 0, s, x, n, out);
   TACO_LAUNCH_CHECK("sumsq");
   return TACO_OK;
 }
