@@ -39,6 +39,7 @@ class Tacotron(object):
         self._loss = torch.zeros(3, device=dev)
         self.workspace = torch.empty(lib.workspace_bytes(self.shape, train) // 4, dtype=torch.float32, device=dev)
         self.masks = None
+        self._err_off = None
         if train:
             n = params.numel
             self.grads = torch.zeros(n, device=dev)
@@ -129,6 +130,16 @@ class Tacotron(object):
         if self.reducer is not None:
             self.reducer.all_reduce(self.grads, self._loss)
         self.apply_gradients(self.lr if lr is None else lr)
+
+    def check(self):
+        """Raises TacoError if a decoder kernel reported a timed-out cluster exchange (the kernels never hang: every spin is
+        bounded and a time-out sets an error word in the workspace).  This is a host synchronisation -- the drivers call
+        it where they already synchronise (loss logging, after inference), not every step."""
+        if self._err_off is None:
+            self._err_off = [o for name, o, s, d in lib.workspace_table(self.shape, self.train) if name == 'dec.err'][0]
+        flags = self.workspace[self._err_off:self._err_off + 2].view(torch.int32).tolist()
+        if flags[0] or flags[1]:
+            raise lib.TacoError('decoder cluster exchange timed out (forward=%d, backward=%d)' % (flags[0], flags[1]))
 
     @property
     def loss(self):

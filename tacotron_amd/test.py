@@ -40,6 +40,7 @@ def test(config, prompts, out_dir='log/test', checkpoint=None):
                 params.flat.copy_(torch.load(checkpoint)['params'])
         model = Tacotron(config, batch, train=False, params=params)
         out, al = model.run()
+        model.check()
         out, al = out.cpu().numpy(), al.cpu().numpy()
         for o, a_ in zip(out, al):
             np.save(os.path.join(out_dir, 'prompt_%03d_spec.npy' % n), reshape_frames(o, config.r, forward=False))

@@ -66,6 +66,7 @@ def train(config, num_steps=1000000, log_every=50):
         gs = model.global_step
         if gs % log_every == 0 or gs % SAVE_EVERY == 0:
             loss = float(model.loss)                      # the only host sync, every log_every steps
+            model.check()                                 # decoder exchange time-outs surface here
             if rank == 0:
                 print('step %d loss %.1f gnorm %.2f' % (gs, loss, float(model.global_gradient_norm)))
             if loss > 1e8 and gs > 500:                   # train.py:77-80

@@ -383,6 +383,7 @@ def test_model_class_train_steps_reduce_loss(built_lib):
     for _ in range(8):
         m.step(lr=1e-3)
         losses.append(float(m.loss))
+    m.check()   # no decoder exchange time-out was flagged
     print('  losses', ['%.1f' % l for l in losses], 'gnorm', float(m.global_gradient_norm))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
     assert m.global_step == 8
