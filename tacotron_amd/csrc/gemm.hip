@@ -197,6 +197,32 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmBatch batch) {
   }
 }
 
+// second pass of launch_conv_gemm_tapsplit: C = epilogue(slab_0 + slab_1 + ... in tap order); 4 columns per thread
+__global__ void conv_gemm_tapsum_kernel(ConvGemmProblem P, const float* __restrict__ slabs, int taps) {
+  const int64_t total4 = (int64_t)P.M * P.N / 4;
+  const int64_t slab = (int64_t)P.M * P.N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i * 4 / P.N), n0 = (int)(i * 4 - (int64_t)m * P.N);
+    float4 s = reinterpret_cast<const float4*>(slabs)[i];
+    for (int t = 1; t < taps; ++t) {
+      const float4 v = reinterpret_cast<const float4*>(slabs + t * slab)[i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float r[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + j;
+      const float bias = P.bias ? (P.bias_stride ? P.bias[(int64_t)(m / P.T) * P.bias_stride + n] : P.bias[n]) : 0.f;
+      float v = apply_act(r[j] + bias, P.act);
+      if (P.keep) v = P.keep[(int64_t)m * P.N + n] ? v * 2.0f : 0.0f;
+      if (P.Cpre) P.Cpre[(int64_t)m * P.ldc + n] = v;
+      if (P.scale || P.shift) v = v * (P.scale ? P.scale[n] * P.scale_mul : 1.f) + (P.shift ? P.shift[n] : 0.f);
+      if (P.residual) v += P.residual[(int64_t)m * P.ldr + n];
+      P.C[(int64_t)m * P.ldc + n] = v;
+    }
+  }
+}
+
 // dW[z][tap][k][n] += sum_m A[z][row(m,tap)][k] * dY[z][m][n]; reduction over m split across blockIdx.z slices.
 template <int WM, int WN, bool VA, bool VB>
 __device__ __forceinline__ void gemm_tn_body(const GemmTnArgs& P, const int bx, const int by, const int bz_) {
@@ -453,6 +479,31 @@ int launch_conv_gemm_batch(ConvGemmBatch& batch, hipStream_t stream) {
     dispatch_nn<1, 1>(flags, dim3(cdiv(maxM, 64), cdiv(maxN, 64), batch.n), stream, batch);
   }
   TACO_LAUNCH_CHECK("conv_gemm");
+  return TACO_OK;
+}
+
+int launch_conv_gemm_tapsplit(const ConvGemmProblem& p, float* slabs, hipStream_t stream) {
+  const double tiles64 = (double)cdiv(p.M, 64) * cdiv(p.N, 64);
+  // worth it only while the 64x64 grid leaves CUs idle (encoder proj1: 200 tiles, 241 -> 163 + 12 us; the post-net's 720 tiles
+  // are better off unsplit), and every tap still has a deep K loop
+  if (!slabs || p.taps < 2 || p.taps > kMaxGemmBatch || p.N % 4 != 0 || p.atomic_out || tiles64 > 320 || p.K < 512)
+    return launch_conv_gemm(p, stream);
+  ConvGemmBatch b;
+  b.n = p.taps;
+  const int64_t slab = (int64_t)p.M * p.N;
+  for (int t = 0; t < p.taps; ++t) {
+    ConvGemmProblem q;
+    q.A = p.A; q.lda = p.lda; q.W = p.W + (int64_t)t * p.K * p.ldw; q.ldw = p.ldw; q.Nld = p.Nld;
+    q.C = slabs + t * slab; q.ldc = p.N;
+    q.M = p.M; q.N = p.N; q.K = p.K; q.taps = 1; q.T = p.T; q.pad_l = p.pad_l - t;   // row shift of tap t: t - pad_l
+    q.act = TACO_ACT_NONE;
+    b.p[t] = q;
+  }
+  TACO_TRY(launch_conv_gemm_batch(b, stream));
+  const int64_t total4 = slab / 4;
+  const int grid = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
+  hipLaunchKernelGGL(conv_gemm_tapsum_kernel, dim3(grid), dim3(256), 0, stream, p, slabs, p.taps);
+  TACO_LAUNCH_CHECK("conv_gemm_tapsum");
   return TACO_OK;
 }
 

@@ -41,6 +41,11 @@ struct GemmTnArgs {
 
 int launch_conv_gemm_batch(ConvGemmBatch& batch, hipStream_t stream);
 int launch_conv_gemm(const ConvGemmProblem& p, hipStream_t stream);
+// A taps-wide convolution whose tile grid cannot fill the chip (tall-skinny: N <= 256) run as `taps` independent one-tap
+// problems into `slabs` (taps x M x N floats) plus ONE elementwise pass that adds the slabs in tap order and applies the
+// epilogue: taps x the workgroups, results independent of scheduling (no atomics).  Falls back to launch_conv_gemm when the
+// split does not pay.
+int launch_conv_gemm_tapsplit(const ConvGemmProblem& p, float* slabs, hipStream_t stream);
 int launch_gemm_tn(GemmTnArgs a, bool zero_first, hipStream_t stream);
 constexpr int kMaxTnBatch = 26;
 struct GemmTnBatch {

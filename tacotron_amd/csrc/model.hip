@@ -68,7 +68,7 @@ void prof_end(int which, int slot, hipStream_t s) {
 }
 
 struct CbhgBufs {
-  float *bank, *pool, *pj1pre, *pj1, *pj2pre, *res, *h[5], *hx[4], *th[4], *xg, *out, *ruc, *s_bank, *s_p1, *s_p2;
+  float *bank, *pool, *pj1pre, *pj1, *pj2pre, *res, *h[5], *hx[4], *th[4], *xg, *out, *ruc, *s_bank, *s_p1, *s_p2, *tapsplit = nullptr;
   float *sv[4], *rowb[4], *h0, *dh0, *dsmall, *dsmall2;   // speaker sites (null without speakers)
   const float* spk_e;   // (B,16) gathered speaker embeddings
   float* dspk_e;        // (B,16) their gradient (accumulated)
@@ -136,7 +136,7 @@ int cbhg_fwd(const float* P, const CbhgP& c, const float* x, int B, int T, const
     p.A = w.pool; p.lda = KC; p.W = P + c.p1_w; p.ldw = c.c1; p.bias = P + c.p1_b; p.scale = P + c.p1_g; p.scale_mul = bn_rs; p.shift = P + c.p1_be;
     p.C = w.pj1; p.Cpre = w.pj1pre; p.ldc = c.c1; p.M = M; p.N = c.c1; p.K = KC; p.taps = 3; p.T = T; p.pad_l = 1;
     p.act = TACO_ACT_RELU;
-    TACO_TRY(launch_conv_gemm(p, s));
+    TACO_TRY(launch_conv_gemm_tapsplit(p, w.tapsplit, s));
   }
   {
     ConvGemmProblem p;
@@ -330,6 +330,7 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
     TACO_TRY(launch_conv_gemm(q, s));
   }
   CbhgBufs eb = cbhg_bufs(ws, W.enc);
+  eb.tapsplit = ws + W.tapsplit;
   if (PL.enc.spk) {   // speaker embedding lookup (tacotron.py:117-124)
     TACO_REQUIRE(speaker != nullptr, "num_speakers=%d but no speaker ids were given", sh.S);
     TACO_TRY(launch_embedding(P + PL.spk_embed, speaker, ws + W.spk_e, B, sh.S, s, 16));
@@ -379,6 +380,7 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
   }
   // post-net (tacotron.py:142-152): (B,Td,80r) reinterpreted as (B, Td*r, 80)
   CbhgBufs pb = cbhg_bufs(ws, W.post);
+  pb.tapsplit = ws + W.tapsplit;
   TACO_TRY(cbhg_fwd(P, PL.post, s2s, B, Td * r, pb, train, s));
   {
     // (256, 1025) kernel -> pitch 1028 so the W tile loads are 16-byte aligned float4 (pad columns are never stored)
