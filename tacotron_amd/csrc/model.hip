@@ -573,10 +573,14 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
   float* gh2 = sc.gF;    // ping-pong
   TACO_TRY(launch_conv_gemm(dense_problem(dxg, 6 * kCb, PT + t.gru_x, kCb, nullptr, gh, kCb, M, kCb, 6 * kCb, TACO_ACT_NONE), s));
   // ---- highway layers 3..0 (with their input adapters / speaker sites) ----
-  float* dth = sc.gD;    // (M,256) (rh no longer needed)
+  // d[T|H] of every layer gets its own (M,256) slice of gA (free until dpool below), so the T / H weight gradients of all
+  // four layers can wait for ONE grouped launch after the loop; only adapter layers, whose operands live in the ping-pong
+  // buffers, flush early.
   float* dxd = sc.gG;    // (M,128)
+  {
+  TnGroup hw_group(s);
   for (int l = 3; l >= 0; --l) {
-    TnGroup hw_group(s);   // this layer's weight gradients (T, H, adapter) share one grid, flushed before buffers are reused
+    float* dth = sc.gA + (int64_t)l * M * 2 * kCb;
     TACO_TRY(launch_highway_combine_bwd(w.th[l], w.hx[l], gh, dth, dxd, M, s));
     TACO_TRY(tn(w.hx[l], kCb, kCb, dth, 2 * kCb, kCb, G + c.hwT[l].w, kCb, M, M, 0, s, 1, G + c.hwT[l].b));
     TACO_TRY(tn(w.hx[l], kCb, kCb, dth + kCb, 2 * kCb, kCb, G + c.hwH[l].w, kCb, M, M, 0, s, 1, G + c.hwH[l].b));
@@ -585,7 +589,6 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
     p.ldr = kCb;
     TACO_TRY(launch_conv_gemm(p, s));        // gh2 = d hx[l]
     if (!c.has_adapt[l]) {
-      TACO_TRY(hw_group.flush());
       float* tmp = gh; gh = gh2; gh2 = tmp;  // hx[l] == h[l]
       continue;
     }
@@ -603,7 +606,10 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
       TACO_TRY(spk_dense_bwd(w.dsmall2, c.spkd[l], t.spkd[l]));
     }
     TACO_TRY(hw_group.flush());
+    hw_group.batch.n = 0;
   }
+  TACO_TRY(hw_group.flush());
+  }   // (group scope: later weight gradients launch on their own again)
   float* dres = gh;      // (M, c2) gradient wrt `res`
   // ---- res = bn(conv(pj1)) + x ----
   float* dz2 = sc.gG;    // (M,c2)
