@@ -57,13 +57,13 @@ int prof_begin(int which, hipStream_t s) {
     r.created = true;
   }
   if (r.n >= ProfRing::kCap) return -1;
-  hipEventRecord(r.start[r.n], s);
+  (void)hipEventRecord(r.start[r.n], s);
   return r.n;
 }
 void prof_end(int which, int slot, hipStream_t s) {
   if (slot < 0) return;
   ProfRing& r = g_prof[which];
-  hipEventRecord(r.stop[slot], s);
+  (void)hipEventRecord(r.stop[slot], s);
   r.n = slot + 1;
 }
 
