@@ -208,19 +208,6 @@ __global__ void affine_act_bwd_kernel(const float* __restrict__ pre, const float
   }
 }
 
-__global__ void colsum_kernel(const float* __restrict__ x, int ld, float* __restrict__ out, int64_t M, int N,
-                              int rows_per_block) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
-  const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
-  float a = 0.f;
-  if (c < N)
-    for (int64_t row = r0 + threadIdx.y; row < r1; row += 4) a += x[row * ld + c];
-  __shared__ float red[4][64];
-  red[threadIdx.y][threadIdx.x] = a;
-  __syncthreads();
-  if (threadIdx.y == 0 && c < N) atomicAdd(&out[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
-}
 
 // grid = (N/64 ceil, B); block = (64, 4)
 __global__ void colsum_batched_kernel(const float* __restrict__ x, int ld, float* __restrict__ out, int T, int N) {
@@ -276,30 +263,6 @@ __global__ void l1_kernel(const float* __restrict__ a, const float* __restrict__
 
 __global__ void finish_loss_kernel(float* loss) { loss[0] = loss[1] + loss[2]; }
 
-__global__ void bn_fold_kernel(const float* __restrict__ gamma, float* __restrict__ scale, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) scale[i] = gamma[i] * (1.0f / sqrtf(1.0f + kBnEps));
-}
-
-// out[tp][n][k] = in[taps-1-tp][k][n]; 32x32 tiles through LDS.  grid = (N/32, K/32, taps), block = (32, 8)
-__global__ void transpose_flip_kernel(const float* __restrict__ in, float* __restrict__ out, int taps, int K, int N) {
-  __shared__ float tile[32][33];
-  const int tp = blockIdx.z;
-  const float* src = in + (int64_t)(taps - 1 - tp) * K * N;
-  float* dst = out + (int64_t)tp * K * N;
-  const int n0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
-  for (int j = threadIdx.y; j < 32; j += 8) {
-    const int k = k0 + j, n = n0 + threadIdx.x;
-    tile[j][threadIdx.x] = (k < K && n < N) ? src[(int64_t)k * N + n] : 0.f;
-  }
-  __syncthreads();
-  for (int j = threadIdx.y; j < 32; j += 8) {
-    const int n = n0 + j, k = k0 + threadIdx.x;
-    if (n < N && k < K) dst[(int64_t)n * K + k] = tile[threadIdx.x][j];
-  }
-}
-
-// Batched transposes: block -> job by linear tile index (jobs sorted by tile0).  block = (32, 8)
 __global__ void transpose_batch_kernel(TransposeBatch b) {
   __shared__ float tile[32][33];
   const int t = blockIdx.x;
@@ -457,14 +420,6 @@ int launch_affine_act_bwd(const float* pre, const float* gamma, const float* dy,
   TACO_LAUNCH_CHECK("affine_act_bwd");
   return TACO_OK;
 }
-int launch_colsum(const float* x, int ld, float* out, int64_t M, int N, hipStream_t s) {
-  dim3 grid;
-  int rpb;
-  col_grid(M, N, grid, rpb);
-  hipLaunchKernelGGL(colsum_kernel, grid, dim3(64, 4), 0, s, x, ld, out, M, N, rpb);
-  TACO_LAUNCH_CHECK("colsum");
-  return TACO_OK;
-}
 int launch_mask_rows(const float* x, const int32_t* len, float* y, int B, int T, int C, hipStream_t s) {
   TACO_REQUIRE(C % 4 == 0, "mask_rows: C %% 4 != 0");
   EW_LAUNCH(mask_rows_kernel, (int64_t)B * T * (C / 4), s, x, len, y, B, T, C);
@@ -484,17 +439,6 @@ int launch_l1(const float* a, const float* b, float* grad, int ldg, float* loss_
 int launch_finish_loss(float* loss, hipStream_t s) {
   hipLaunchKernelGGL(finish_loss_kernel, dim3(1), dim3(1), 0, s, loss);
   TACO_LAUNCH_CHECK("finish_loss");
-  return TACO_OK;
-}
-int launch_bn_fold(const float* gamma, float* scale, int n, hipStream_t s) {
-  hipLaunchKernelGGL(bn_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, s, gamma, scale, n);
-  TACO_LAUNCH_CHECK("bn_fold");
-  return TACO_OK;
-}
-int launch_transpose_flip(const float* in, float* out, int taps, int K, int N, hipStream_t s) {
-  dim3 grid((N + 31) / 32, (K + 31) / 32, taps);
-  hipLaunchKernelGGL(transpose_flip_kernel, grid, dim3(32, 8), 0, s, in, out, taps, K, N);
-  TACO_LAUNCH_CHECK("transpose_flip");
   return TACO_OK;
 }
 int launch_transpose_batch(TransposeBatch& b, hipStream_t s) {

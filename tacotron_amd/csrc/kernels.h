@@ -77,8 +77,6 @@ int launch_act_bwd(const float* y, const float* dy, const uint8_t* keep, float* 
 //   dgamma += sum_m dy*pre*rs, dbeta += sum_m dy, dz = dy*gamma*rs*act'(pre)   (rs = 1/sqrt(1+eps); act in {none, relu})
 int launch_affine_act_bwd(const float* pre, const float* gamma, const float* dy, float* dz, float* dgamma, float* dbeta,
                           int64_t M, int N, int act, hipStream_t s);
-// out[n] += sum_m x[m*ld + n]
-int launch_colsum(const float* x, int ld, float* out, int64_t M, int N, hipStream_t s);
 // out[b*N + n] = sum_{t<T} x[(b*T + t)*ld + n]   (overwrites)
 int launch_colsum_batched(const float* x, int ld, float* out, int B, int T, int N, hipStream_t s);
 // values = enc * (t < len[b])
@@ -87,10 +85,6 @@ int launch_add(const float* a, const float* b, float* y, int64_t n, hipStream_t 
 // L1 losses + sign gradients.  loss[1] += sum|a-b| (slot given).  grad (ldg >= N) = sign(a-b), pad columns zeroed.
 int launch_l1(const float* a, const float* b, float* grad, int ldg, float* loss_slot, int64_t M, int N, hipStream_t s);
 int launch_finish_loss(float* loss, hipStream_t s);  // loss[0] = loss[1] + loss[2]
-// bn scale/shift vectors: scale = gamma/sqrt(1+eps), shift = beta
-int launch_bn_fold(const float* gamma, float* scale, int n, hipStream_t s);
-// transposes: out[tap'][n][k] = in[taps-1-tap'][k][n]
-int launch_transpose_flip(const float* in, float* out, int taps, int K, int N, hipStream_t s);
 // Batched form: up to kMaxTransposeBatch (in, out, taps, K, N) jobs in ONE launch.
 constexpr int kMaxTransposeBatch = 96;
 struct TransposeJob {

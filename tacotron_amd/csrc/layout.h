@@ -73,7 +73,6 @@ struct TransLayout {
 
 struct CbhgWs {
   int64_t bank, pool, pj1pre, pj1, pj2pre, res, hx[4], h[5], th[4], xg, out, ruc;
-  int64_t s_bank, s_p1, s_p2;  // folded BN scales
   int64_t sv[4], rowb[4], h0;  // speaker sites: relu(dense(spk)) (B,128), per-sequence adapter bias (B,128), GRU init (B,128)
   int64_t dh0, dsmall, dsmall2; // backward: (2,B,128), (B,128), (B,128)
 };

@@ -183,9 +183,6 @@ static void ws_cbhg(Adder& a, const std::string& p, const CbhgP& c, int64_t M, i
   w.xg = a.add(p + "xg", {M, 6 * kCb});
   w.out = a.add(p + "out", {M, 2 * kCb});
   w.ruc = a.add(p + "ruc", {M, 6 * kCb});
-  w.s_bank = a.add(p + "s_bank", {c.K * kCb});
-  w.s_p1 = a.add(p + "s_p1", {c.c1});
-  w.s_p2 = a.add(p + "s_p2", {c.c2});
   for (int l = 0; l < 4; ++l) {
     w.sv[l] = c.spk ? a.add(p + "sv" + std::to_string(l), {B, kCb}) : -1;
     w.rowb[l] = c.spk ? a.add(p + "rowb" + std::to_string(l), {B, kCb}) : -1;

@@ -68,7 +68,7 @@ void prof_end(int which, int slot, hipStream_t s) {
 }
 
 struct CbhgBufs {
-  float *bank, *pool, *pj1pre, *pj1, *pj2pre, *res, *h[5], *hx[4], *th[4], *xg, *out, *ruc, *s_bank, *s_p1, *s_p2, *tapsplit = nullptr;
+  float *bank, *pool, *pj1pre, *pj1, *pj2pre, *res, *h[5], *hx[4], *th[4], *xg, *out, *ruc, *tapsplit = nullptr;
   float *sv[4], *rowb[4], *h0, *dh0, *dsmall, *dsmall2;   // speaker sites (null without speakers)
   const float* spk_e;   // (B,16) gathered speaker embeddings
   float* dspk_e;        // (B,16) their gradient (accumulated)
@@ -91,7 +91,6 @@ CbhgBufs cbhg_bufs(float* ws, const CbhgWs& w) {
   b.dspk_e = nullptr;
   for (int l = 0; l < 4; ++l) b.th[l] = ws + w.th[l];
   b.xg = ws + w.xg; b.out = ws + w.out; b.ruc = ws + w.ruc;
-  b.s_bank = ws + w.s_bank; b.s_p1 = ws + w.s_p1; b.s_p2 = ws + w.s_p2;
   return b;
 }
 
