@@ -40,6 +40,16 @@ struct GemmTnArgs {
 };
 
 int launch_conv_gemm_batch(ConvGemmBatch& batch, hipStream_t stream);
+// The CBHG's highway layers as one launch (highway.hip).  Layer l: th[l] = [sigmoid(x Wt+bt) | relu(x Wh+bh)] (M,256),
+// y[l] = H*T + x*(1-T) (M,128) feeds layer l+1.
+struct HighwayStackArgs {
+  const float* x = nullptr;    // (M,128) input of the first layer
+  const float* wt[4]; const float* bt[4]; const float* wh[4]; const float* bh[4];
+  float* th[4];
+  float* y[4];
+  int M = 0, nl = 0;
+};
+int launch_highway_stack_fwd(const HighwayStackArgs& a, hipStream_t s);
 int launch_conv_gemm(const ConvGemmProblem& p, hipStream_t stream);
 // A taps-wide convolution whose tile grid cannot fill the chip (tall-skinny: N <= 256) run as `taps` independent one-tap
 // problems into `slabs` (taps x M x N floats) plus ONE elementwise pass that adds the slabs in tap order and applies the

@@ -146,7 +146,20 @@ int cbhg_fwd(const float* P, const CbhgP& c, const float* x, int B, int T, const
   }
   // highway x4 (ops.py:27-46, 97-107) with the optional input adapter and the per-layer speaker site (ops.py:101-105):
   // concat([h, tile(s)]) . Wa + ba  ==  h . Wa[:128] + (s . Wa[128:] + ba), i.e. a per-sequence bias -- no (B,T,256) concat.
-  for (int l = 0; l < 4; ++l) {
+  if (!c.spk) {
+    // single-speaker: at most layer 0 has an input adapter (post-net 80 -> 128); the four layers then run as ONE launch
+    if (c.has_adapt[0])
+      TACO_TRY(launch_conv_gemm(dense_problem(w.h[0], c.c2, P + c.adapt[0].w, kCb, P + c.adapt[0].b, w.hx[0], kCb, M, kCb, c.c2,
+                                              TACO_ACT_NONE), s));
+    HighwayStackArgs ha;
+    ha.x = w.hx[0]; ha.M = M; ha.nl = 4;
+    for (int l = 0; l < 4; ++l) {
+      ha.wt[l] = P + c.hwT[l].w; ha.bt[l] = P + c.hwT[l].b; ha.wh[l] = P + c.hwH[l].w; ha.bh[l] = P + c.hwH[l].b;
+      ha.th[l] = w.th[l]; ha.y[l] = w.h[l + 1];
+    }
+    TACO_TRY(launch_highway_stack_fwd(ha, s));
+  }
+  for (int l = 0; l < 4 && c.spk; ++l) {
     if (c.has_adapt[l]) {
       if (c.spk) {
         TACO_TRY(launch_conv_gemm(dense_problem(w.spk_e, 16, P + c.spkd[l].w, kCb, P + c.spkd[l].b, w.sv[l], kCb, B, kCb, 16,
