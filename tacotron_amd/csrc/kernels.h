@@ -50,6 +50,16 @@ struct HighwayStackArgs {
   int M = 0, nl = 0;
 };
 int launch_highway_stack_fwd(const HighwayStackArgs& a, hipStream_t s);
+struct HighwayStackBwdArgs {
+  const float* g = nullptr;    // (M,128) dL/d output of the last layer
+  const float* wT[4];          // (256,128) [Wt^T ; Wh^T] per layer
+  const float* th[4];          // forward stash [T | H]
+  const float* x[4];           // layer inputs
+  float* dth[4];               // (M,256) d[T|H] pre-activation gradients (operands of the weight-gradient GEMMs)
+  float* gout = nullptr;       // (M,128) dL/d input of layer 0
+  int M = 0, nl = 0;
+};
+int launch_highway_stack_bwd(const HighwayStackBwdArgs& a, hipStream_t s);
 int launch_conv_gemm(const ConvGemmProblem& p, hipStream_t stream);
 // A taps-wide convolution whose tile grid cannot fill the chip (tall-skinny: N <= 256) run as `taps` independent one-tap
 // problems into `slabs` (taps x M x N floats) plus ONE elementwise pass that adds the slabs in tap order and applies the

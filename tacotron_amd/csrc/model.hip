@@ -589,7 +589,29 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
   // four layers can wait for ONE grouped launch after the loop; only adapter layers, whose operands live in the ping-pong
   // buffers, flush early.
   float* dxd = sc.gG;    // (M,128)
-  {
+  if (!c.spk) {
+    // single-speaker: the activation-gradient chain of the four layers is ONE launch (highway.hip), their T / H weight
+    // gradients one grouped launch; only layer 0 may have an input adapter (post-net 80 -> 128), handled after it
+    HighwayStackBwdArgs hb;
+    hb.g = gh; hb.gout = gh2; hb.M = M; hb.nl = 4;
+    for (int l = 0; l < 4; ++l) {
+      hb.wT[l] = PT + t.hw[l]; hb.th[l] = w.th[l]; hb.x[l] = w.hx[l];
+      hb.dth[l] = sc.gA + (int64_t)l * M * 2 * kCb;
+    }
+    TACO_TRY(launch_highway_stack_bwd(hb, s));
+    TnGroup hw_group(s);
+    for (int l = 0; l < 4; ++l) {
+      TACO_TRY(tn(w.hx[l], kCb, kCb, hb.dth[l], 2 * kCb, kCb, G + c.hwT[l].w, kCb, M, M, 0, s, 1, G + c.hwT[l].b));
+      TACO_TRY(tn(w.hx[l], kCb, kCb, hb.dth[l] + kCb, 2 * kCb, kCb, G + c.hwH[l].w, kCb, M, M, 0, s, 1, G + c.hwH[l].b));
+    }
+    if (c.has_adapt[0]) {   // gh2 = d hx[0]: adapter weight / bias gradients and d h[0] = d hx[0] . Wa^T -> gh
+      TACO_TRY(tn(w.h[0], c.c2, c.c2, gh2, kCb, kCb, G + c.adapt[0].w, kCb, M, M, 0, s, 1, G + c.adapt[0].b));
+      TACO_TRY(launch_conv_gemm(dense_problem(gh2, kCb, PT + t.adapt[0], c.c2, nullptr, gh, c.c2, M, c.c2, kCb, TACO_ACT_NONE), s));
+    } else {
+      float* tmp = gh; gh = gh2; gh2 = tmp;
+    }
+    TACO_TRY(hw_group.flush());
+  } else {
   TnGroup hw_group(s);
   for (int l = 3; l >= 0; --l) {
     float* dth = sc.gA + (int64_t)l * M * 2 * kCb;
