@@ -43,18 +43,20 @@ __global__ __launch_bounds__(256) void highway_stack_fwd_kernel(HighwayStackArgs
   }
   // W loader: 16 rows x 64 float4 per k-tile = 4 float4 per thread
   const int w_c4 = tid & 63, w_r = tid >> 6;   // rows w_r + 4*i
-  float4 rw[4];
-  auto load_w = [&](const float* wt, const float* wh, int k0) {
+  // two register sets: a k-tile is fetched TWO iterations before it is written to LDS (one iteration of 16 MFMAs is shorter
+  // than an L2 round trip)
+  float4 rw[2][4];
+  auto load_w = [&](float4 (&r)[4], const float* wt, const float* wh, int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int k = k0 + w_r + 4 * i;
       const float* src = w_c4 < 32 ? wt + (int64_t)k * HC + w_c4 * 4 : wh + (int64_t)k * HC + (w_c4 - 32) * 4;
-      rw[i] = *reinterpret_cast<const float4*>(src);
+      r[i] = *reinterpret_cast<const float4*>(src);
     }
   };
-  auto store_w = [&](int buf) {
+  auto store_w = [&](const float4 (&r)[4], int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&Ws[buf][w_r + 4 * i][w_c4 * 4]) = rw[i];
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&Ws[buf][w_r + 4 * i][w_c4 * 4]) = r[i];
   };
 
 #pragma unroll
@@ -65,13 +67,15 @@ __global__ __launch_bounds__(256) void highway_stack_fwd_kernel(HighwayStackArgs
     f32x16 accT, accH;
 #pragma unroll
     for (int e = 0; e < 16; ++e) accT[e] = accH[e] = 0.f;
-    load_w(wt, wh, 0);
-    store_w(0);
-    __syncthreads();   // also publishes hT (first layer: the input tile; later layers: the previous layer's output)
     constexpr int NKT = HC / HK;
+    load_w(rw[0], wt, wh, 0);
+    store_w(rw[0], 0);
+    load_w(rw[1], wt, wh, HK);        // tile 1 -> set 1
+    load_w(rw[0], wt, wh, 2 * HK);    // tile 2 -> set 0
+    __syncthreads();   // also publishes hT (first layer: the input tile; later layers: the previous layer's output)
+#pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       const int buf = kt & 1;
-      if (kt + 1 < NKT) load_w(wt, wh, (kt + 1) * HK);
 #pragma unroll
       for (int kk = 0; kk < HK; kk += 2) {
         const float av = hT[kt * HK + kk + lk][li];
@@ -80,7 +84,8 @@ __global__ __launch_bounds__(256) void highway_stack_fwd_kernel(HighwayStackArgs
         accT = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bt, accT, 0, 0, 0);
         accH = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bh, accH, 0, 0, 0);
       }
-      if (kt + 1 < NKT) store_w(buf ^ 1);
+      if (kt + 1 < NKT) store_w(rw[(kt + 1) & 1], buf ^ 1);                       // tile kt+1 (fetched two iterations ago)
+      if (kt + 3 < NKT) load_w(rw[(kt + 1) & 1], wt, wh, (kt + 3) * HK);          // tile kt+3 into the freed set
       __syncthreads();
     }
     // epilogue: C layout col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
@@ -136,14 +141,14 @@ __global__ __launch_bounds__(256) void highway_stack_bwd_kernel(HighwayStackBwdA
     gT[pc4 * 4 + 3][r] = v.w;
   }
   const int w_c4 = tid & 31, w_r = tid >> 5;   // k-tile loader: 16 rows x 32 float4 = 2 float4 per thread
-  float4 rw[2];
-  auto load_w = [&](const float* w, int k0) {
+  float4 rw[2][2];   // two register sets, tiles fetched two iterations ahead (see the forward kernel)
+  auto load_w = [&](float4 (&r)[2], const float* w, int k0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) rw[i] = *reinterpret_cast<const float4*>(w + (int64_t)(k0 + w_r + 8 * i) * HC + w_c4 * 4);
+    for (int i = 0; i < 2; ++i) r[i] = *reinterpret_cast<const float4*>(w + (int64_t)(k0 + w_r + 8 * i) * HC + w_c4 * 4);
   };
-  auto store_w = [&](int buf) {
+  auto store_w = [&](const float4 (&r)[2], int buf) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&Ws[buf][w_r + 8 * i][w_c4 * 4]) = rw[i];
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&Ws[buf][w_r + 8 * i][w_c4 * 4]) = r[i];
   };
   __syncthreads();
 
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(256) void highway_stack_bwd_kernel(HighwayStackBwdA
   for (int l = 3; l >= 0; --l) {
     if (l >= a.nl) continue;
     const float* w = a.wT[l];
-    load_w(w, 0);
+    load_w(rw[0], w, 0);
     // ---- pre-processing: d[T|H] of this layer from g, the stashed gates and the layer input ----
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -177,23 +182,26 @@ __global__ __launch_bounds__(256) void highway_stack_bwd_kernel(HighwayStackBwdA
         *reinterpret_cast<float4*>(a.dth[l] + (int64_t)m * 2 * HC + HC + pc4 * 4) = make_float4(dh[0], dh[1], dh[2], dh[3]);
       }
     }
-    store_w(0);
+    store_w(rw[0], 0);
+    load_w(rw[1], w, HK);
+    load_w(rw[0], w, 2 * HK);
     __syncthreads();
     // ---- g' = d[T|H] . wT  (K = 256) ----
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     constexpr int NKT = 2 * HC / HK;
+#pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       const int buf = kt & 1;
-      if (kt + 1 < NKT) load_w(w, (kt + 1) * HK);
 #pragma unroll
       for (int kk = 0; kk < HK; kk += 2) {
         const float av = dT[kt * HK + kk + lk][li];
         const float bv = Ws[buf][kk + lk][32 * wave + li];
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
       }
-      if (kt + 1 < NKT) store_w(buf ^ 1);
+      if (kt + 1 < NKT) store_w(rw[(kt + 1) & 1], buf ^ 1);
+      if (kt + 3 < NKT) load_w(rw[(kt + 1) & 1], w, (kt + 3) * HK);
       __syncthreads();
     }
     // ---- epilogue: + g (1 - T); the result is the next (lower) layer's g ----
