@@ -65,10 +65,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmBatch batch) {
   const int ktiles = (P.K + BK - 1) / BK;
   const int nit = P.taps * ktiles;
 
-  float4 ra[A_PER], rb[B_PER];
-  bool oka[A_PER], okb[B_PER];   // VEC paths: validity of the raw float4 in flight; applied when it is written to LDS
+  // One k-tile in flight: raw float4s plus (VEC paths) their validity, applied when the tile is written to LDS.  TWO stages
+  // alternate, so a tile is fetched two iterations before it is stored: with 64x64 tiles an iteration is 8 MFMAs per wave
+  // (512 matrix-pipe cycles), shorter than an L2 round trip, and a one-deep prefetch stalled every iteration.
+  struct Stage {
+    float4 ra[A_PER], rb[B_PER];
+    bool oka[A_PER], okb[B_PER];
+  };
+  Stage st0, st1;
 
-  auto load_tile = [&](int it) {
+  auto load_tile = [&](Stage& S, int it) {
     const int tap = it / ktiles;
     const int k0 = (it - tap * ktiles) * BK;
     const int sh = tap - P.pad_l;
@@ -81,7 +87,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmBatch batch) {
         const bool ok = ar[i].ok && (unsigned)st < (unsigned)P.T && k < P.K;
         const int64_t off = (int64_t)ok * ((int64_t)(ar[i].m + sh) * P.lda + k);
         v = *reinterpret_cast<const float4*>(P.A + off);
-        oka[i] = ok;
+        S.oka[i] = ok;
       } else if (ar[i].ok && st >= 0 && st < P.T) {
         const float* p = P.A + (int64_t)(ar[i].m + sh) * P.lda + k;
         if (k < P.K) v.x = p[0];
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmBatch batch) {
         if (k + 2 < P.K) v.z = p[2];
         if (k + 3 < P.K) v.w = p[3];
       }
-      ra[i] = v;
+      S.ra[i] = v;
     }
     const float* Wt = P.W + (int64_t)tap * P.K * P.ldw;
 #pragma unroll
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmBatch batch) {
         const bool ok = k < P.K && n < P.Nld;
         const int64_t off = (int64_t)ok * ((int64_t)k * P.ldw + n);
         v = *reinterpret_cast<const float4*>(Wt + off);
-        okb[i] = ok;
+        S.okb[i] = ok;
       } else if (k < P.K) {
         const float* p = Wt + (int64_t)k * P.ldw + n;
         if (n < P.N) v.x = p[0];
@@ -109,14 +115,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmBatch batch) {
         if (n + 2 < P.N) v.z = p[2];
         if (n + 3 < P.N) v.w = p[3];
       }
-      rb[i] = v;
+      S.rb[i] = v;
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](const Stage& S, int buf) {
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
       const int r = a_row + 64 * i;
-      const float4 v = VA ? sel4(oka[i], ra[i]) : ra[i];
+      const float4 v = VA ? sel4(S.oka[i], S.ra[i]) : S.ra[i];
       As[buf][a_kq * 4 + 0][r] = v.x;
       As[buf][a_kq * 4 + 1][r] = v.y;
       As[buf][a_kq * 4 + 2][r] = v.z;
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmBatch batch) {
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
       const int k = b_k + i * B_KSTEP;
-      if (k < BK) *reinterpret_cast<float4*>(&Bs[buf][k][b_c4 * 4]) = VB ? sel4(okb[i], rb[i]) : rb[i];
+      if (k < BK) *reinterpret_cast<float4*>(&Bs[buf][k][b_c4 * 4]) = VB ? sel4(S.okb[i], S.rb[i]) : S.rb[i];
     }
   };
 
@@ -137,37 +143,49 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmBatch batch) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  load_tile(0);
-  store_tile(0);
+  load_tile(st0, 0);
+  store_tile(st0, 0);
+  if (1 < nit) load_tile(st1, 1);   // tile 1 -> stage 1, tile 2 -> stage 0
+  if (2 < nit) load_tile(st0, 2);
   __syncthreads();
 
   const int lk = lane >> 5, li = lane & 31;
-  for (int it = 0; it < nit; ++it) {
-    const int buf = it & 1;
-    if (it + 1 < nit) load_tile(it + 1);
+  auto compute = [&](int buf) {
     // LDS operands are fetched one k-pair ahead of the MFMAs that consume them
-    float a[2][WM], b[2][WN];
+      float a[2][WM], b[2][WN];
 #pragma unroll
-    for (int i = 0; i < WM; ++i) a[0][i] = As[buf][lk][wm * (32 * WM) + i * 32 + li];
+      for (int i = 0; i < WM; ++i) a[0][i] = As[buf][lk][wm * (32 * WM) + i * 32 + li];
 #pragma unroll
-    for (int j = 0; j < WN; ++j) b[0][j] = Bs[buf][lk][wn * (32 * WN) + j * 32 + li];
+      for (int j = 0; j < WN; ++j) b[0][j] = Bs[buf][lk][wn * (32 * WN) + j * 32 + li];
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
-      if (kk + 2 < BK) {
+      for (int kk = 0; kk < BK; kk += 2) {
+        const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+        if (kk + 2 < BK) {
 #pragma unroll
-        for (int i = 0; i < WM; ++i) a[nxt][i] = As[buf][kk + 2 + lk][wm * (32 * WM) + i * 32 + li];
+          for (int i = 0; i < WM; ++i) a[nxt][i] = As[buf][kk + 2 + lk][wm * (32 * WM) + i * 32 + li];
 #pragma unroll
-        for (int j = 0; j < WN; ++j) b[nxt][j] = Bs[buf][kk + 2 + lk][wn * (32 * WN) + j * 32 + li];
+          for (int j = 0; j < WN; ++j) b[nxt][j] = Bs[buf][kk + 2 + lk][wn * (32 * WN) + j * 32 + li];
+        }
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
       }
-#pragma unroll
-      for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
-    }
-    if (it + 1 < nit) store_tile(buf ^ 1);
+  };
+  // iteration it computes on LDS buffer it & 1, stores tile it+1 (stage (it+1) & 1, fetched two iterations ago) into the other
+  // buffer and refills that stage with tile it+3
+  for (int it = 0; it < nit; it += 2) {
+    compute(0);
+    if (it + 1 < nit) store_tile(st1, 1);
+    if (it + 3 < nit) load_tile(st1, it + 3);
     __syncthreads();
+    if (it + 1 < nit) {
+      compute(1);
+      if (it + 2 < nit) store_tile(st0, 0);
+      if (it + 4 < nit) load_tile(st0, it + 4);
+      __syncthreads();
+    }
   }
 
   // --- epilogue: C/D layout col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ---
