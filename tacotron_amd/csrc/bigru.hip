@@ -33,6 +33,13 @@ __device__ __forceinline__ float quad_sum(float v) {
 }
 
 constexpr int NTG = 512;
+// The four k-quarters of a quad read their ds_read_b128 slices of an LDS vector at the same time; unpadded, the quarter
+// bases are 128 B (32-float vectors) or 256 B (64-float) apart and fall on the same banks (PMC: LDS_BANK_CONFLICT on 12 % /
+// 25 % of the forward / backward wave cycles).  Each quarter therefore gets 4 floats of padding: base = q * (len + 4).
+__device__ __forceinline__ int pad32(int c) { return c + 4 * (c >> 5); }   // 32-float quarters (128-wide vectors)
+__device__ __forceinline__ int pad64(int c) { return c + 4 * (c >> 6); }   // 64-float quarters (256-wide vectors)
+constexpr int HP = H + 16;         // padded 128-vector
+constexpr int H2P = 2 * H + 16;    // padded 256-vector
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }   // v_pk_fma_f32
 __device__ __forceinline__ float hsum(f2 v) { return v.x + v.y; }      // 8 waves = 2 per SIMD: a lone wave per SIMD only issues ~1 instruction per 4 cycles
@@ -50,8 +57,8 @@ __global__ __launch_bounds__(NTG, 2) void bigru_fwd_kernel(const float* __restri
   (void)trace;
   const int b = blockIdx.x, d = blockIdx.y, t_ = threadIdx.x;
   const int cp = t_ >> 2, kq = t_ & 3, lane = t_ & 63, wv = t_ >> 6;
-  __shared__ __attribute__((aligned(16))) float hs[H];
-  __shared__ __attribute__((aligned(16))) float rhs[H];
+  __shared__ __attribute__((aligned(16))) float hs[HP];
+  __shared__ __attribute__((aligned(16))) float rhs[HP];
   __shared__ float us[H];
   __shared__ __attribute__((aligned(16))) float xgs[2][CH][3 * H];
 
@@ -67,7 +74,7 @@ __global__ __launch_bounds__(NTG, 2) void bigru_fwd_kernel(const float* __restri
       wcand[k] = f2{wc[(int64_t)(2 * k) * H], wc[(int64_t)(2 * k + 1) * H]};
     }
   }
-  if (t_ < H) hs[t_] = h0 ? h0[(int64_t)b * H + t_] : 0.f;   // initial_state_fw = initial_state_bw = s (ops.py:123-124)
+  if (t_ < H) hs[pad32(t_)] = h0 ? h0[(int64_t)b * H + t_] : 0.f;   // initial_state_fw = initial_state_bw = s (ops.py:123-124)
 
   const int64_t row0 = (int64_t)b * T;
   const int tstart = d == 0 ? 0 : T - 1, tstep = d == 0 ? 1 : -1;
@@ -93,16 +100,16 @@ __global__ __launch_bounds__(NTG, 2) void bigru_fwd_kernel(const float* __restri
     f2 a0 = {0.f, 0.f}, a1 = a0, b0 = a0, b1 = a0;
 #pragma unroll
     for (int k4 = 0; k4 < H / 16; ++k4) {
-      const float4 hv = reinterpret_cast<const float4*>(hs)[kq * (H / 16) + k4];
+      const float4 hv = reinterpret_cast<const float4*>(hs + kq * (H / 4 + 4))[k4];
       const f2 h01 = {hv.x, hv.y}, h23 = {hv.z, hv.w};
       a0 = pk_fma(h01, wr[2 * k4], a0); b0 = pk_fma(h01, wu[2 * k4], b0);
       a1 = pk_fma(h23, wr[2 * k4 + 1], a1); b1 = pk_fma(h23, wu[2 * k4 + 1], b1);
     }
     const float rg = sigmoid_fast(quad_sum(hsum(a0 + a1)) + xrow[cp]);
     const float ug = sigmoid_fast(quad_sum(hsum(b0 + b1)) + xrow[H + cp]);
-    const float hprev = hs[cp];
+    const float hprev = hs[pad32(cp)];
     if (kq == 0) {
-      rhs[cp] = rg * hprev;
+      rhs[pad32(cp)] = rg * hprev;
       us[cp] = ug;
     }
     lds_barrier();
@@ -110,7 +117,7 @@ __global__ __launch_bounds__(NTG, 2) void bigru_fwd_kernel(const float* __restri
     f2 p0 = {0.f, 0.f}, p1 = p0;
 #pragma unroll
     for (int k4 = 0; k4 < H / 16; ++k4) {
-      const float4 rv = reinterpret_cast<const float4*>(rhs)[kq * (H / 16) + k4];
+      const float4 rv = reinterpret_cast<const float4*>(rhs + kq * (H / 4 + 4))[k4];
       p0 = pk_fma(f2{rv.x, rv.y}, wcand[2 * k4], p0);
       p1 = pk_fma(f2{rv.z, rv.w}, wcand[2 * k4 + 1], p1);
     }
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(NTG, 2) void bigru_fwd_kernel(const float* __restri
     if (kq == 0) {
       const float cc = tanh_fast(cpre);
       const float hn = ug * hprev + (1.f - ug) * cc;
-      hs[cp] = hn;
+      hs[pad32(cp)] = hn;
       out[(row0 + t) * (2 * H) + d * H + cp] = hn;
       if (ruc) {
         float* rp = ruc + (row0 + t) * (6 * H) + d * 3 * H;
@@ -148,8 +155,8 @@ __global__ __launch_bounds__(NTG, 2) void bigru_bwd_kernel(const float* __restri
   const int cp = t_ >> 2, kq = t_ & 3, lane = t_ & 63, wv = t_ >> 6;
   // double buffered by step parity: the next step's writes never race with this step's reads, so a step needs only the two
   // barriers its own dependences require
-  __shared__ __attribute__((aligned(16))) float dcp_s2[2][H];
-  __shared__ __attribute__((aligned(16))) float dgp_s2[2][2 * H];
+  __shared__ __attribute__((aligned(16))) float dcp_s2[2][HP];
+  __shared__ __attribute__((aligned(16))) float dgp_s2[2][H2P];
   __shared__ __attribute__((aligned(16))) float in_s[2][CH][5 * H];   // [r | u | c | dout | h_prev]
 
   // wchT (128 [c], 128 [k]): d(rh)[cp] = sum_c dcp[c] * wchT[c][cp]      -> this lane: c in [32kq, 32kq+32)
@@ -210,8 +217,8 @@ __global__ __launch_bounds__(NTG, 2) void bigru_bwd_kernel(const float* __restri
     const float dcp = dc * (1.f - cc * cc);
     const float dup = du * u * (1.f - u);
     if (kq == 0) {
-      dcp_s[cp] = dcp;
-      dgp_s[H + cp] = dup;
+      dcp_s[pad32(cp)] = dcp;
+      dgp_s[pad64(H + cp)] = dup;
       float* xo = dxg + (row0 + t) * (6 * H) + d * 3 * H;
       xo[2 * H + cp] = dcp;
       xo[H + cp] = dup;
@@ -222,21 +229,21 @@ __global__ __launch_bounds__(NTG, 2) void bigru_bwd_kernel(const float* __restri
     f2 p0 = {0.f, 0.f}, p1 = p0;
 #pragma unroll
     for (int i4 = 0; i4 < H / 16; ++i4) {
-      const float4 v = reinterpret_cast<const float4*>(dcp_s)[kq * (H / 16) + i4];
+      const float4 v = reinterpret_cast<const float4*>(dcp_s + kq * (H / 4 + 4))[i4];
       p0 = pk_fma(f2{v.x, v.y}, wc_r[2 * i4], p0);
       p1 = pk_fma(f2{v.z, v.w}, wc_r[2 * i4 + 1], p1);
     }
     const float drh = quad_sum(hsum(p0 + p1));
     const float drp = drh * hp * r * (1.f - r);
     if (kq == 0) {
-      dgp_s[cp] = drp;
+      dgp_s[pad64(cp)] = drp;
       dxg[(row0 + t) * (6 * H) + d * 3 * H + cp] = drp;
     }
     lds_barrier();
     f2 q0 = {0.f, 0.f}, q1 = q0;
 #pragma unroll
     for (int i4 = 0; i4 < H / 8; ++i4) {
-      const float4 v = reinterpret_cast<const float4*>(dgp_s)[kq * (H / 8) + i4];
+      const float4 v = reinterpret_cast<const float4*>(dgp_s + kq * (H / 2 + 4))[i4];
       q0 = pk_fma(f2{v.x, v.y}, wg_r[2 * i4], q0);
       q1 = pk_fma(f2{v.z, v.w}, wg_r[2 * i4 + 1], q1);
     }
