@@ -59,7 +59,6 @@ __global__ __launch_bounds__(NTG, 2) void bigru_fwd_kernel(const float* __restri
   const int cp = t_ >> 2, kq = t_ & 3, lane = t_ & 63, wv = t_ >> 6;
   __shared__ __attribute__((aligned(16))) float hs[HP];
   __shared__ __attribute__((aligned(16))) float rhs[HP];
-  __shared__ float us[H];
   __shared__ __attribute__((aligned(16))) float xgs[2][CH][3 * H];
 
   // Wg_h[32kq + k][cp], Wg_h[..][128 + cp], Wc_h[32kq + k][cp], held as k-pairs so the dot products run on v_pk_fma_f32
@@ -110,7 +109,6 @@ __global__ __launch_bounds__(NTG, 2) void bigru_fwd_kernel(const float* __restri
     const float hprev = hs[pad32(cp)];
     if (kq == 0) {
       rhs[pad32(cp)] = rg * hprev;
-      us[cp] = ug;
     }
     lds_barrier();
     // ---- candidate ----
