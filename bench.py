@@ -107,8 +107,8 @@ def main():
     B, Tt, Td = args.batch, args.text_len, args.dec_steps
     batch = synthetic_batch(B, Tt, Td, c.r, c.vocab_size, seed=1234, rank=rank, num_speakers=args.speakers)
     reducer = GradReducer() if world > 1 else None
-    model = Tacotron(c, batch, train=True, seed=0, reducer=reducer)   # same init on every rank (seed 0)
-    model._seed += rank * 7919                                        # per-rank dropout / sampling streams
+    model = Tacotron(c, batch, train=True, seed=0, reducer=reducer)   # same init on every rank (seed 0); the mask
+    #                                                                   streams are offset by the reducer's rank (model.py)
 
     def barrier():
         if world > 1:

@@ -23,7 +23,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default)
 
-#define TACO_VERSION 100
+#define TACO_VERSION 110
 
 #define TACO_OK 0
 #define TACO_EINVAL (-1)   /* bad argument / unsupported shape   */
@@ -126,9 +126,38 @@ int taco_infer(const TacoShape* shape, const float* params, const int32_t* text,
                float* seq2seq_output, float* output, float* alignments, void* workspace, void* stream);
 
 /* add_train_op (tacotron.py:167-185): global-norm clip (cap_grads) then TF-form Adam, in place.
- *   step = global_step after this update (1-based).  scratch: >= 8 floats.  gnorm_out[1] receives ||g||. */
+ *   step = global_step after this update (1-based).  scratch: >= 256 floats.  gnorm_out[0] receives ||g||. */
 int taco_clip_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float cap,
                         int64_t step, float* scratch, float* gnorm_out, void* stream);
+
+/* Same, guarded: err_words (nullable) points at the two int32 decoder error words of the workspace (tensor "dec.err" of
+ * taco_workspace_table: [0] forward, [1] backward).  The persistent decoder kernels exchange data between workgroups with
+ * bounded spins; a time-out (workgroups not co-resident on a busy GPU) sets a word and the launch drains with garbage
+ * gradients.  When either word is non-zero the update is skipped and gnorm_out[0] = -1.  The words are STICKY: only
+ * taco_clear_error resets them (call it once on a fresh workspace, and after handling an error).
+ * scratch: >= 256 floats (per-block partial sums of squares, summed in a fixed order: the norm is reproducible). */
+int taco_clip_adam_step_guarded(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float cap,
+                                int64_t step, float* scratch, float* gnorm_out, const int32_t* err_words, void* stream);
+int taco_clear_error(const TacoShape* shape, int train, void* workspace, void* stream);
+
+/* ---- data-parallel overlap (no reference counterpart: train.py:24 is a single Session) ---------------- */
+/* The flat gradient buffer becomes final in three contiguous segments, in this order during taco_backward:
+ *   segment 2 = [bounds[2], bounds[3])  post-net CBHG + final dense   (before the decoder BPTT starts)
+ *   segment 1 = [bounds[1], bounds[2])  attention memory layer + decoder
+ *   segment 0 = [bounds[0], bounds[1])  embedding(s) + encoder       (end of taco_backward)
+ * taco_grad_segments fills bounds[4] (float offsets) and returns 3.  taco_wait_grad_segment makes `stream` wait (device
+ * side, hipStreamWaitEvent) until segment `seg` of the most recent taco_backward enqueued by the calling thread on the
+ * current device is final, so an all-reduce enqueued on `stream` afterwards overlaps the rest of the backward pass. */
+int taco_grad_segments(const TacoShape* shape, int64_t* bounds);
+int taco_wait_grad_segment(int seg, void* stream);
+
+/* ---- spectrogram boundary ---------------------------------------------------------------------------- */
+/* test.py:64 `out * stft_std + stft_mean` followed by audio.reshape_frames(forward=False) (audio.py:29-35), on the device.
+ *   output (B, Td, r*C) as produced by taco_infer (C = 1025 linear bins, or 80 for mel frames); stft_mean / stft_std (r*C)
+ *   spec  (B, F, C), nullable: chronological, de-normalised log-magnitude frames, F = (Td / 4) * 4 * r
+ *   mag_t (B, C, F), nullable: exp(spec) transposed -- the matrix audio.invert_spectrogram (audio.py:69-72) gives Griffin-Lim */
+int taco_denorm_unframe(const float* output, const float* stft_mean, const float* stft_std, float* spec, float* mag_t,
+                        int B, int Td, int r, int C, void* stream);
 
 /* Bernoulli(p_keep) bytes from a counter-based hash RNG (replaces TF's dropout / Bernoulli sampler state). */
 int taco_fill_bernoulli(uint8_t* out, int64_t n, float p_one, uint64_t seed, void* stream);

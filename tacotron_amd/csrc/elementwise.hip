@@ -258,10 +258,26 @@ __global__ void l1_kernel(const float* __restrict__ a, const float* __restrict__
     if (grad) grad[i] = g;
   }
   const float t = block_sum(acc, red);
-  if (threadIdx.x == 0) atomicAdd(loss_slot, t);
+  if (threadIdx.x == 0) loss_slot[blockIdx.x] = t;   // one partial per block; finish_loss adds them in block order
 }
 
-__global__ void finish_loss_kernel(float* loss) { loss[0] = loss[1] + loss[2]; }
+// loss[1], loss[2] = ordered sums of the two terms' block partials (kLossParts each, zero-padded by the l1 launches);
+// loss[0] = their sum (tacotron.py:160).  `out` (nullable) receives a copy of the three values.  One block, no atomics:
+// the loss is reproducible bit for bit.
+__global__ void finish_loss_kernel(float* __restrict__ loss, const float* __restrict__ parts, float* __restrict__ out) {
+  __shared__ float red[8];
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < kLossParts; i += blockDim.x) {
+    a += parts[i];
+    b += parts[kLossParts + i];
+  }
+  a = block_sum(a, red);
+  b = block_sum(b, red);
+  if (threadIdx.x == 0) {
+    loss[1] = a; loss[2] = b; loss[0] = a + b;
+    if (out) { out[0] = a + b; out[1] = a; out[2] = b; }
+  }
+}
 
 __global__ void transpose_batch_kernel(TransposeBatch b) {
   __shared__ float tile[32][33];
@@ -317,13 +333,23 @@ __global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __re
     acc += v * v;
   }
   const float t = block_sum(acc, red);
-  if (threadIdx.x == 0) atomicAdd(out, t);
+  if (threadIdx.x == 0) out[blockIdx.x] = t;   // one partial per block (kSumsqParts blocks): no atomics, no pre-zeroing
 }
 
+// Every block first adds the kSumsqParts partial sums of squares in the same fixed order (=> the same global norm in every
+// block and on every run), then updates its slice.  `err` (nullable): the decoder kernels' error words; when either is set
+// the gradients are garbage (a cluster exchange timed out), so the update is SKIPPED and gnorm_out reads -1.
 __global__ void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                  float* __restrict__ v, int64_t n, float lr_t, float cap, const float* __restrict__ sumsq,
-                                 float* __restrict__ gnorm_out) {
-  const float gn = sqrtf(sumsq[0]);
+                                 float* __restrict__ gnorm_out, const int32_t* __restrict__ err) {
+  __shared__ float red[8];
+  if (err && (err[0] | err[1])) {
+    if (gnorm_out && blockIdx.x == 0 && threadIdx.x == 0) gnorm_out[0] = -1.f;
+    return;
+  }
+  float part = 0.f;
+  for (int i = threadIdx.x; i < kSumsqParts; i += blockDim.x) part += sumsq[i];
+  const float gn = sqrtf(block_sum(part, red));
   const float scale = cap > 0.f ? cap / fmaxf(gn, cap) : 1.0f;
   if (gnorm_out && blockIdx.x == 0 && threadIdx.x == 0) gnorm_out[0] = gn;
   const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
@@ -334,6 +360,37 @@ __global__ void clip_adam_kernel(float* __restrict__ p, const float* __restrict_
     m[i] = mi;
     v[i] = vi;
     p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
+// Inverse r-frame layout + de-normalisation (audio.reshape_frames(forward=False), audio.py:29-35; test.py:64
+// `out * stft_std + stft_mean`).  out (B, Td, r*C): row 4c + j, column i*C + ch holds frame 4rc + 4i + j, feature ch.
+// spec (B, F, C) (nullable) = chronological log-magnitude frames, F = (Td / 4) * 4 * r (only whole chunks, like the
+// reference); mag_t (B, C, F) (nullable) = exp(spec) transposed = the (1 + n_fft/2, frames) magnitude matrix
+// audio.invert_spectrogram hands to Griffin-Lim.  32 x 32 tiles through LDS so both images are written coalesced.
+__global__ void denorm_unframe_kernel(const float* __restrict__ out, const float* __restrict__ mean,
+                                      const float* __restrict__ stdv, float* __restrict__ spec, float* __restrict__ mag_t,
+                                      int Td, int r, int C, int F) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, c0 = blockIdx.x * 32, f0 = blockIdx.y * 32;
+  const int RC = r * C;
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    const int f = f0 + j, ch = c0 + threadIdx.x;
+    float v = 0.f;
+    if (f < F && ch < C) {
+      const int chunk = f / (4 * r), rem = f - chunk * 4 * r;
+      const int i = rem >> 2, jj = rem & 3;
+      const int col = i * C + ch;
+      v = out[((int64_t)b * Td + chunk * 4 + jj) * RC + col] * stdv[col] + mean[col];
+      if (spec) spec[((int64_t)b * F + f) * C + ch] = v;
+    }
+    tile[j][threadIdx.x] = v;
+  }
+  if (!mag_t) return;
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    const int ch = c0 + j, f = f0 + threadIdx.x;
+    if (ch < C && f < F) mag_t[((int64_t)b * C + ch) * F + f] = expf(tile[threadIdx.x][j]);
   }
 }
 
@@ -429,15 +486,15 @@ int launch_add(const float* a, const float* b, float* y, int64_t n, hipStream_t 
   EW_LAUNCH(add_kernel, n, s, a, b, y, n);
   return TACO_OK;
 }
-int launch_l1(const float* a, const float* b, float* grad, int ldg, float* loss_slot, int64_t M, int N, hipStream_t s) {
+int launch_l1(const float* a, const float* b, float* grad, int ldg, float* loss_parts, int64_t M, int N, hipStream_t s) {
   TACO_REQUIRE(ldg >= N, "l1: ldg < N");
-  // <= 512 blocks: every block ends with an atomicAdd on the one loss word, and same-address atomics serialise
-  hipLaunchKernelGGL(l1_kernel, dim3(grid_for(M * ldg, kThreads, 512)), dim3(kThreads), 0, s, a, b, grad, ldg, loss_slot, M, N);
+  // exactly kLossParts blocks: block i leaves its partial in loss_parts[i] (blocks without work write 0)
+  hipLaunchKernelGGL(l1_kernel, dim3(kLossParts), dim3(kThreads), 0, s, a, b, grad, ldg, loss_parts, M, N);
   TACO_LAUNCH_CHECK("l1");
   return TACO_OK;
 }
-int launch_finish_loss(float* loss, hipStream_t s) {
-  hipLaunchKernelGGL(finish_loss_kernel, dim3(1), dim3(1), 0, s, loss);
+int launch_finish_loss(float* loss, const float* parts, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(finish_loss_kernel, dim3(1), dim3(kThreads), 0, s, loss, parts, out);
   TACO_LAUNCH_CHECK("finish_loss");
   return TACO_OK;
 }
@@ -452,19 +509,28 @@ int launch_transpose_batch(TransposeBatch& b, hipStream_t s) {
   TACO_LAUNCH_CHECK("transpose_batch");
   return TACO_OK;
 }
+int launch_denorm_unframe(const float* out, const float* mean, const float* stdv, float* spec, float* mag_t, int B, int Td,
+                          int r, int C, hipStream_t s) {
+  const int F = (Td / 4) * 4 * r;
+  TACO_REQUIRE(F > 0, "denorm_unframe: Td=%d holds no whole chunk of 4 steps", Td);
+  hipLaunchKernelGGL(denorm_unframe_kernel, dim3((C + 31) / 32, (F + 31) / 32, B), dim3(32, 8), 0, s, out, mean, stdv, spec,
+                     mag_t, Td, r, C, F);
+  TACO_LAUNCH_CHECK("denorm_unframe");
+  return TACO_OK;
+}
 int launch_sumsq(const float* x, int64_t n, float* out, hipStream_t s) {
   TACO_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "sumsq: x must be 16-byte aligned");
-  // one block per CU: the per-block atomicAdd on the single result word serialises (~15 ns each)
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4 + 1, kThreads, 256)), dim3(kThreads), 0, s, x, n, out);
+  // one block per CU, one partial each
+  hipLaunchKernelGGL(sumsq_kernel, dim3(kSumsqParts), dim3(kThreads), 0, s, x, n, out);
   TACO_LAUNCH_CHECK("sumsq");
   return TACO_OK;
 }
 int launch_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float cap, int64_t step,
-                     const float* sumsq, float* gnorm_out, hipStream_t s) {
+                     const float* sumsq, float* gnorm_out, const int32_t* err, hipStream_t s) {
   const double b1 = 0.9, b2 = 0.999;
   const double lr_t = (double)lr * sqrt(1.0 - pow(b2, (double)step)) / (1.0 - pow(b1, (double)step));
   hipLaunchKernelGGL(clip_adam_kernel, dim3(grid_for(n, kThreads, 2048)), dim3(kThreads), 0, s, p, g, m, v, n,
-                     (float)lr_t, cap, sumsq, gnorm_out);
+                     (float)lr_t, cap, sumsq, gnorm_out, err);
   TACO_LAUNCH_CHECK("clip_adam");
   return TACO_OK;
 }

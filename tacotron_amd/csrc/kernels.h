@@ -102,9 +102,12 @@ int launch_colsum_batched(const float* x, int ld, float* out, int B, int T, int 
 // values = enc * (t < len[b])
 int launch_mask_rows(const float* x, const int32_t* len, float* y, int B, int T, int C, hipStream_t s);
 int launch_add(const float* a, const float* b, float* y, int64_t n, hipStream_t s);  // y = a + b
-// L1 losses + sign gradients.  loss[1] += sum|a-b| (slot given).  grad (ldg >= N) = sign(a-b), pad columns zeroed.
-int launch_l1(const float* a, const float* b, float* grad, int ldg, float* loss_slot, int64_t M, int N, hipStream_t s);
-int launch_finish_loss(float* loss, hipStream_t s);  // loss[0] = loss[1] + loss[2]
+// L1 losses + sign gradients.  loss_parts[0..kLossParts) = per-block partial sums of |a-b| (overwritten; summed in block
+// order by launch_finish_loss: no atomics, reproducible).  grad (ldg >= N) = sign(a-b), pad columns zeroed.
+constexpr int kLossParts = 512;
+int launch_l1(const float* a, const float* b, float* grad, int ldg, float* loss_parts, int64_t M, int N, hipStream_t s);
+// parts (2 x kLossParts): loss[1] = sum parts[0..), loss[2] = sum parts[kLossParts..), loss[0] = loss[1] + loss[2]; out (nullable) = copy
+int launch_finish_loss(float* loss, const float* parts, float* out, hipStream_t s);
 // Batched form: up to kMaxTransposeBatch (in, out, taps, K, N) jobs in ONE launch.
 constexpr int kMaxTransposeBatch = 96;
 struct TransposeJob {
@@ -118,9 +121,14 @@ struct TransposeBatch {
   int n = 0;
 };
 int launch_transpose_batch(TransposeBatch& b, hipStream_t s);
-int launch_sumsq(const float* x, int64_t n, float* out, hipStream_t s);  // out[0] += sum x^2 (double-free, fp32 tree)
+// inverse r-frame layout + de-normalisation (+ optional exp / transpose for the vocoder); see the kernel
+int launch_denorm_unframe(const float* out, const float* mean, const float* stdv, float* spec, float* mag_t, int B, int Td,
+                          int r, int C, hipStream_t s);
+constexpr int kSumsqParts = 256;
+int launch_sumsq(const float* x, int64_t n, float* out, hipStream_t s);  // out[0..kSumsqParts) = per-block sums of x^2 (overwritten)
+// err (nullable): two int32 decoder error words; if either is non-zero the update is skipped (gnorm_out = -1)
 int launch_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float cap, int64_t step,
-                     const float* sumsq, float* gnorm_out, hipStream_t s);
+                     const float* sumsq, float* gnorm_out, const int32_t* err, hipStream_t s);
 int launch_bernoulli(uint8_t* out, int64_t n, float p_one, uint64_t seed, hipStream_t s);
 
 // ---------------------------------------------------------------- bigru.hip

@@ -229,7 +229,7 @@ void build_ws_layout(const TacoShape& s, bool train, const TransLayout& T, WsLay
     const int64_t e1 = M1 * (int64_t)P.enc.c1, e2 = M2 * (int64_t)P.post.c1;
     W.tapsplit = a.add("tapsplit", {3, e1 > e2 ? e1 : e2});
   }
-  W.loss = a.add("loss", {4});
+  W.loss = a.add("loss", {4 + 2 * kLossParts});   // [0..3] total / seq2seq / output; then the two terms' per-block partials
   if (train) {
     const int64_t Mx = M1 > M2 ? M1 : M2;
     W.ds2s = a.add("bwd.ds2s", {MD, R80});

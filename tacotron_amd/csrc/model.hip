@@ -221,6 +221,10 @@ struct SideStream {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool off = false;
+  // gradient-segment events of the most recent taco_backward issued by this thread on this device
+  // (taco_wait_grad_segment): [0] encoder, [1] decoder, [2] post-net segment of the flat gradient buffer is final
+  hipEvent_t ev_seg[3] = {nullptr, nullptr, nullptr};
+  bool seg_recorded = false;
 };
 SideStream& side_stream() {
   static thread_local SideStream ss[16];
@@ -237,6 +241,19 @@ SideStream& side_stream() {
     }
   }
   return x;
+}
+int record_segment(int seg, hipStream_t on) {
+  SideStream& x = side_stream();
+  if (!x.ev_seg[seg] && hipEventCreateWithFlags(&x.ev_seg[seg], hipEventDisableTiming) != hipSuccess) {
+    taco_set_error("taco_backward: cannot create the gradient-segment event");
+    return TACO_ELAUNCH;
+  }
+  if (hipEventRecord(x.ev_seg[seg], on) != hipSuccess) {
+    taco_set_error("taco_backward: hipEventRecord(segment %d) failed", seg);
+    return TACO_ELAUNCH;
+  }
+  if (seg == 0) x.seg_recorded = true;
+  return TACO_OK;
 }
 hipStream_t side_fork(hipStream_t s) {
   SideStream& x = side_stream();
@@ -322,6 +339,16 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
   const int M1 = B * Tt, M2 = B * Td * r;
   // decoder composites depend on the parameters only: side stream, concurrent with the encoder
   hipStream_t sd = side_fork(s);
+  {
+    // post/dense (256, 1025) kernel -> pitch 1028 so the W tile loads are 16-byte aligned float4 (pad columns are never
+    // stored); depends on the parameters only, so it rides on the side stream too
+    hipError_t e = hipMemcpy2DAsync(ws + W.wd_pad, 1028 * sizeof(float), P + PL.post_dense.w, kFft * sizeof(float),
+                                    kFft * sizeof(float), 2 * kCb, hipMemcpyDeviceToDevice, sd);
+    if (e != hipSuccess) {
+      taco_set_error("forward: memcpy2D: %s", hipGetErrorString(e));
+      return TACO_ELAUNCH;
+    }
+  }
   TACO_TRY(build_dec_composites(P, PL, W, ws, r, sd));
   if (train) {
     // everything the backward pass derives from the parameters alone (transposed / tap-flipped weight copies, transposed
@@ -367,13 +394,8 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
   da.xchg = ws + W.xchg; da.err = reinterpret_cast<int*>(ws + W.err);
   da.trace = getenv("TACO_DEC_TRACE") ? reinterpret_cast<long long*>(ws + W.err + 16) : nullptr;
   da.B = B; da.Tt = Tt; da.Td = Td; da.r = r; da.P = 1;
-  {
-    hipError_t e = hipMemsetAsync(ws + W.err, 0, 64 * sizeof(float), s);
-    if (e != hipSuccess) {
-      taco_set_error("forward: memset: %s", hipGetErrorString(e));
-      return TACO_ELAUNCH;
-    }
-  }
+  // (the error words are STICKY: only taco_clear_error() resets them, so a time-out in any step stays visible to the
+  //  guarded Adam update and to the host's next check, however rarely the host looks)
   {
     const int slot = prof_begin(0, s);
     TACO_TRY(launch_decoder_fwd(da, s));
@@ -383,25 +405,13 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
   if (train) {
     // seq2seq half of add_loss_op (tacotron.py:158) only needs the decoder output: side stream, beside the post-net
     sl = side_fork(s);
-    hipError_t e = hipMemsetAsync(ws + W.loss, 0, 4 * sizeof(float), sl);
-    if (e != hipSuccess) {
-      taco_set_error("forward: memset: %s", hipGetErrorString(e));
-      return TACO_ELAUNCH;
-    }
-    TACO_TRY(launch_l1(s2s, mel, ws + W.ds2s, R80, ws + W.loss + 1, (int64_t)B * Td, R80, sl));
+    TACO_TRY(launch_l1(s2s, mel, ws + W.ds2s, R80, ws + W.loss + 4, (int64_t)B * Td, R80, sl));
   }
   // post-net (tacotron.py:142-152): (B,Td,80r) reinterpreted as (B, Td*r, 80)
   CbhgBufs pb = cbhg_bufs(ws, W.post);
   pb.tapsplit = ws + W.tapsplit;
   TACO_TRY(cbhg_fwd(P, PL.post, s2s, B, Td * r, pb, train, s));
   {
-    // (256, 1025) kernel -> pitch 1028 so the W tile loads are 16-byte aligned float4 (pad columns are never stored)
-    hipError_t e = hipMemcpy2DAsync(ws + W.wd_pad, 1028 * sizeof(float), P + PL.post_dense.w, kFft * sizeof(float),
-                                    kFft * sizeof(float), 2 * kCb, hipMemcpyDeviceToDevice, s);
-    if (e != hipSuccess) {
-      taco_set_error("forward: memcpy2D: %s", hipGetErrorString(e));
-      return TACO_ELAUNCH;
-    }
     ConvGemmProblem p = dense_problem(pb.out, 2 * kCb, ws + W.wd_pad, 1028, P + PL.post_dense.b, output, kFft, M2, kFft,
                                       2 * kCb, TACO_ACT_NONE);
     p.Nld = 1028;
@@ -751,14 +761,8 @@ extern "C" int taco_forward(const TacoShape* shape, const float* params, const i
   const int64_t MD = (int64_t)shape->B * shape->Td, M2 = MD * shape->r;
   // (the seq2seq term and the zeroing of the loss slots were issued by forward_impl beside the post-net)
   (void)R80; (void)MD;
-  TACO_TRY(launch_l1(output, stft, ws + W.dout_pad, 1028, ws + W.loss + 2, M2, kFft, s));
-  TACO_TRY(launch_finish_loss(ws + W.loss, s));
-  hipError_t e = hipMemcpyAsync(loss, ws + W.loss, 3 * sizeof(float), hipMemcpyDeviceToDevice, s);
-  if (e != hipSuccess) {
-    taco_set_error("taco_forward: memcpy: %s", hipGetErrorString(e));
-    return TACO_ELAUNCH;
-  }
-  return TACO_OK;
+  TACO_TRY(launch_l1(output, stft, ws + W.dout_pad, 1028, ws + W.loss + 4 + kLossParts, M2, kFft, s));
+  return launch_finish_loss(ws + W.loss, ws + W.loss + 4, loss, s);
 }
 
 extern "C" int taco_infer(const TacoShape* shape, const float* params, const int32_t* text, const int32_t* text_length,
@@ -792,8 +796,8 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
   float* PT = ws + W.paramsT;
 
   hipError_t e = hipMemsetAsync(G, 0, (size_t)PL.total * sizeof(float), s);
-  if (e == hipSuccess) e = hipMemsetAsync(ws + W.dkeys, 0, (size_t)M1 * kAtt * sizeof(float), s);
-  if (e == hipSuccess) e = hipMemsetAsync(ws + W.dvalues, 0, (size_t)M1 * kAtt * sizeof(float), s);
+  if (e == hipSuccess)   // dkeys and dvalues are neighbours in the workspace: one fill
+    e = hipMemsetAsync(ws + W.dkeys, 0, (size_t)(W.dvalues + (int64_t)M1 * kAtt - W.dkeys) * sizeof(float), s);
   if (e != hipSuccess) {
     taco_set_error("taco_backward: memset: %s", hipGetErrorString(e));
     return TACO_ELAUNCH;
@@ -817,6 +821,10 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
   // d seq2seq_output = sign(s2s - mel) + post-net path
   float* dS2S = ws + W.ds2s_tot;
   TACO_TRY(launch_add(ws + W.ds2s, dPostIn, dS2S, (int64_t)MD * R80, s));
+  // gradient segment 2 (post-net CBHG + final dense) is final once the side stream's dense weight gradient has landed:
+  // data-parallel callers start its all-reduce here, under the decoder BPTT (taco_wait_grad_segment)
+  TACO_TRY(side_join(s, side));
+  TACO_TRY(record_segment(2, s));
 
   // ---- decoder BPTT ----
   {
@@ -926,6 +934,9 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
                             kPre1, TACO_ACT_NONE);
     b2.p[1].residual = G + PL.out_proj.b + (R80 - kMel); b2.p[1].ldr = R80;
     TACO_TRY(launch_conv_gemm_batch(b2, s));
+    // gradient segment 1 (memory layer + decoder) is final here: everything the main stream contributed (memory-layer
+    // kernel, attention_v from the BPTT kernel) was enqueued before this side stream forked
+    TACO_TRY(record_segment(1, s));
   }
   // ---- encoder CBHG ----
   float* dP2 = sc.gC;       // (M1,128)
@@ -950,6 +961,28 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
                                           TACO_ACT_NONE), s));
   TACO_TRY(launch_embedding_bwd(dEmb, text, G + PL.emb, M1, shape->V, s));
   TACO_TRY(side_join(s, side));
+  return record_segment(0, s);
+}
+
+extern "C" int taco_grad_segments(const TacoShape* shape, int64_t* bounds) {
+  TACO_TRY(validate_shape(shape));
+  TACO_REQUIRE(bounds != nullptr, "taco_grad_segments: null bounds");
+  const ParamLayout& PL = layouts_for(*shape).P;
+  bounds[0] = 0;
+  bounds[1] = PL.mem_w;            // [0, mem_w): embedding(s) + encoder pre_net + encoder CBHG
+  bounds[2] = PL.post.bank_w[0];   // [mem_w, post): attention memory layer + decoder
+  bounds[3] = PL.total;            // [post, total): post-net CBHG + final dense
+  return 3;
+}
+
+extern "C" int taco_wait_grad_segment(int seg, void* stream) {
+  TACO_REQUIRE(seg >= 0 && seg < 3, "taco_wait_grad_segment: segment %d out of range", seg);
+  SideStream& x = side_stream();
+  TACO_REQUIRE(x.seg_recorded && x.ev_seg[seg], "taco_wait_grad_segment: no taco_backward was issued by this thread on this device");
+  if (hipStreamWaitEvent(as_stream(stream), x.ev_seg[seg], 0) != hipSuccess) {
+    taco_set_error("taco_wait_grad_segment: hipStreamWaitEvent failed");
+    return TACO_ELAUNCH;
+  }
   return TACO_OK;
 }
 
@@ -1000,17 +1033,38 @@ extern "C" int taco_bigru_fwd(const float* x, const float* wg_fw, const float* b
   return launch_bigru_fwd(xg, w, nullptr, out, ruc, B, T, s);
 }
 
-extern "C" int taco_clip_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float cap,
-                                   int64_t step, float* scratch, float* gnorm_out, void* stream) {
+extern "C" int taco_clip_adam_step_guarded(float* params, const float* grads, float* m, float* v, int64_t n, float lr,
+                                           float cap, int64_t step, float* scratch, float* gnorm_out,
+                                           const int32_t* err_words, void* stream) {
   TACO_REQUIRE(params && grads && m && v && scratch && n > 0 && step >= 1, "clip_adam_step: bad arguments");
   hipStream_t s = as_stream(stream);
-  hipError_t e = hipMemsetAsync(scratch, 0, 8 * sizeof(float), s);
+  TACO_TRY(launch_sumsq(grads, n, scratch, s));
+  return launch_clip_adam(params, grads, m, v, n, lr, cap, step, scratch, gnorm_out, err_words, s);
+}
+
+extern "C" int taco_clip_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr, float cap,
+                                   int64_t step, float* scratch, float* gnorm_out, void* stream) {
+  return taco_clip_adam_step_guarded(params, grads, m, v, n, lr, cap, step, scratch, gnorm_out, nullptr, stream);
+}
+
+extern "C" int taco_clear_error(const TacoShape* shape, int train, void* workspace, void* stream) {
+  TACO_TRY(validate_shape(shape));
+  TACO_REQUIRE(workspace != nullptr, "taco_clear_error: null workspace");
+  const Layouts& L = layouts_for(*shape);
+  const WsLayout& W = train ? L.Wtrain : L.Winfer;
+  hipError_t e = hipMemsetAsync(static_cast<float*>(workspace) + W.err, 0, 512 * sizeof(float), as_stream(stream));
   if (e != hipSuccess) {
-    taco_set_error("clip_adam_step: memset: %s", hipGetErrorString(e));
+    taco_set_error("taco_clear_error: memset: %s", hipGetErrorString(e));
     return TACO_ELAUNCH;
   }
-  TACO_TRY(launch_sumsq(grads, n, scratch, s));
-  return launch_clip_adam(params, grads, m, v, n, lr, cap, step, scratch, gnorm_out, s);
+  return TACO_OK;
+}
+
+extern "C" int taco_denorm_unframe(const float* output, const float* stft_mean, const float* stft_std, float* spec,
+                                   float* mag_t, int B, int Td, int r, int C, void* stream) {
+  TACO_REQUIRE(output && stft_mean && stft_std && (spec || mag_t) && B > 0 && Td > 0 && r >= 1 && r <= 5 && C > 0,
+               "denorm_unframe: bad arguments");
+  return launch_denorm_unframe(output, stft_mean, stft_std, spec, mag_t, B, Td, r, C, as_stream(stream));
 }
 
 extern "C" int taco_fill_bernoulli(uint8_t* out, int64_t n, float p_one, uint64_t seed, void* stream) {

@@ -30,20 +30,58 @@ def init_from_env(backend=None):
 
 
 class GradReducer:
+    """SUM all-reduce of the flat gradient buffer, overlapped with the backward pass.
+
+    `taco_backward` finalises the buffer in three contiguous segments (post-net first, then decoder, then encoder;
+    `lib.grad_segments`) and records a HIP event per segment.  `reduce_after_backward` enqueues, on a communication
+    stream, a device-side wait for each event followed by that segment's bucketed all-reduce -- so the post-net
+    gradients (60 % of the bytes) travel over xGMI while the decoder BPTT and the encoder backward are still running,
+    and the host never blocks.  The loss triple and the decoder error words ride along, so every rank takes (or skips)
+    the same Adam update and replicas stay bit-identical."""
+
     def __init__(self, bucket_floats=2 * 1024 * 1024, group=None):
         self.bucket = int(bucket_floats)
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        on = dist.is_initialized()
+        self.world = dist.get_world_size(group) if on else 1
+        self.rank = dist.get_rank(group) if on else 0
+        self.comm = None
 
-    def all_reduce(self, grads: torch.Tensor, loss: torch.Tensor | None = None):
+    def _buckets(self, t, lo, hi):
+        for off in range(lo, hi, self.bucket):
+            yield t[off:min(hi, off + self.bucket)]
+
+    def all_reduce(self, grads: torch.Tensor, loss: torch.Tensor | None = None, extra: torch.Tensor | None = None):
+        """Plain form: everything after backward has finished (also what the CPU tests drive)."""
         if self.world == 1:
             return
-        works = []
-        n = grads.numel()
-        for off in range(0, n, self.bucket):
-            works.append(dist.all_reduce(grads[off:min(n, off + self.bucket)], op=dist.ReduceOp.SUM, group=self.group,
-                                         async_op=True))
-        if loss is not None:
-            works.append(dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                 for b in self._buckets(grads, 0, grads.numel())]
+        for t in (loss, extra):
+            if t is not None:
+                works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for w in works:
             w.wait()
+
+    def reduce_after_backward(self, model):
+        """Call right after `model.backward()` has been ENQUEUED (it need not have run yet)."""
+        if self.world == 1:
+            return
+        grads = model.grads
+        if not grads.is_cuda:
+            return self.all_reduce(grads, model._loss, model._err)
+        from . import lib
+        if self.comm is None:
+            self.comm = torch.cuda.Stream()
+        bounds = lib.grad_segments(model.shape)
+        works = []
+        with torch.cuda.stream(self.comm):
+            for seg in (2, 1, 0):                       # completion order inside taco_backward
+                lib.wait_grad_segment(seg, self.comm)   # device-side: the collectives below start when the segment is final
+                for b in self._buckets(grads, bounds[seg], bounds[seg + 1]):
+                    works.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            for t in (model._loss, model._err):
+                works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for w in works:
+            w.wait()                                    # the CURRENT stream waits for the collective (no host block with RCCL)
+        torch.cuda.current_stream().wait_stream(self.comm)

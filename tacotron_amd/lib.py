@@ -58,6 +58,11 @@ EXPORTS = {
     'taco_backward': (C.c_int, [_SH] + [_P] * 14),
     'taco_infer': (C.c_int, [_SH] + [_P] * 9),
     'taco_clip_adam_step': (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_int64, _P, _P, _P]),
+    'taco_clip_adam_step_guarded': (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_int64, _P, _P, _P, _P]),
+    'taco_clear_error': (C.c_int, [_SH, _I, _P, _P]),
+    'taco_grad_segments': (C.c_int, [_SH, C.POINTER(C.c_int64)]),
+    'taco_wait_grad_segment': (C.c_int, [_I, _P]),
+    'taco_denorm_unframe': (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'taco_fill_bernoulli': (C.c_int, [_P, C.c_int64, C.c_float, C.c_uint64, _P]),
     'taco_profile_enable': (C.c_int, [_I]),
     'taco_profile_read': (C.c_int, [_I, C.POINTER(C.c_float), _I]),
@@ -180,9 +185,45 @@ def infer(shape, params, text, text_length, s2s, out, align, workspace, speaker=
                            ptr(workspace), stream_ptr()), 'taco_infer')
 
 
-def clip_adam_step(params, grads, m, v, lr, cap, step, scratch, gnorm_out):
-    _check(_lib.taco_clip_adam_step(ptr(params), ptr(grads), ptr(m), ptr(v), params.numel(), float(lr), float(cap),
-                                    int(step), ptr(scratch), ptr(gnorm_out), stream_ptr()), 'taco_clip_adam_step')
+def clip_adam_step(params, grads, m, v, lr, cap, step, scratch, gnorm_out, err_words=None):
+    """err_words: int32 view of the workspace's `dec.err` tensor (first two words) or None (unguarded)."""
+    assert scratch.numel() >= 256, 'taco: clip_adam scratch must hold 256 floats'
+    _check(_lib.taco_clip_adam_step_guarded(ptr(params), ptr(grads), ptr(m), ptr(v), params.numel(), float(lr), float(cap),
+                                            int(step), ptr(scratch), ptr(gnorm_out), ptr(err_words), stream_ptr()),
+           'taco_clip_adam_step_guarded')
+
+
+def clear_error(shape, train, workspace):
+    _check(_lib.taco_clear_error(C.byref(shape), int(train), ptr(workspace), stream_ptr()), 'taco_clear_error')
+
+
+def grad_segments(shape):
+    """Float offsets [b0, b1, b2, b3] of the three gradient segments (encoder, decoder, post-net); they become final in
+    the order 2, 1, 0 during taco_backward."""
+    b = (C.c_int64 * 4)()
+    n = _lib.taco_grad_segments(C.byref(shape), b)
+    if n != 3:
+        raise TacoError('taco_grad_segments: ' + last_error())
+    return [int(x) for x in b]
+
+
+def wait_grad_segment(seg, stream):
+    """Device-side wait of `stream` (a torch.cuda.Stream) for segment `seg` of this thread's last taco_backward."""
+    _check(_lib.taco_wait_grad_segment(int(seg), C.c_void_p(stream.cuda_stream)), 'taco_wait_grad_segment')
+
+
+def denorm_unframe(output, stft_mean, stft_std, r, want_spec=True, want_mag_t=False):
+    """(B, Td, r*C) normalised r-frame layout -> chronological de-normalised (B, F, C) [and / or exp() transposed (B, C, F)]."""
+    B, Td, RC = output.shape
+    Cw = RC // r
+    F = (Td // 4) * 4 * r
+    spec = torch.empty(B, F, Cw, device=output.device) if want_spec else None
+    mag_t = torch.empty(B, Cw, F, device=output.device) if want_mag_t else None
+    _check(_lib.taco_denorm_unframe(ptr(output), ptr(stft_mean), ptr(stft_std), ptr(spec), ptr(mag_t), B, Td, r, Cw,
+                                    stream_ptr()), 'taco_denorm_unframe')
+    if want_spec and want_mag_t:
+        return spec, mag_t
+    return spec if want_spec else mag_t
 
 
 def fill_bernoulli(out, p_one, seed):

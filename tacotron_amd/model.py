@@ -39,13 +39,17 @@ class Tacotron(object):
         self._loss = torch.zeros(3, device=dev)
         self.workspace = torch.empty(lib.workspace_bytes(self.shape, train) // 4, dtype=torch.float32, device=dev)
         self.masks = None
-        self._err_off = None
+        # the decoder kernels' two error words (sticky: cleared here and by check(), never by the library)
+        eoff = [o for name, o, s, d in lib.workspace_table(self.shape, train) if name == 'dec.err'][0]
+        self._err = self.workspace[eoff:eoff + 2].view(torch.int32)
+        lib.clear_error(self.shape, train, self.workspace)
+        self.stft_mean = self.stft_std = None   # train.py:31-33: normalisation statistics travel with the checkpoint
         if train:
             n = params.numel
             self.grads = torch.zeros(n, device=dev)
             self.adam_m = torch.zeros(n, device=dev)
             self.adam_v = torch.zeros(n, device=dev)
-            self._scratch = torch.zeros(8, device=dev)
+            self._scratch = torch.zeros(256, device=dev)
             self._gnorm = torch.zeros(1, device=dev)
             # the five mask tensors are views of ONE byte buffer (16-byte aligned pieces), so that neighbours with the same
             # Bernoulli parameter are filled by a single launch (all five, with the reference's default rates)
@@ -59,12 +63,25 @@ class Tacotron(object):
                 self._mask_buf[k] = self._mask_flat[off:off + n].view(*s)
                 self._mask_span[k] = (off, sz)
                 off += sz
-            self._seed = seed * 1000003 + 17
+            # per-rank dropout / scheduled-sampling streams: replicas share the parameters, not the masks
+            rank = reducer.rank if reducer is not None else 0
+            self._seed = seed * 1000003 + 17 + rank * 7919
         self.set_inputs(inputs)
 
     # -- inputs -----------------------------------------------------------------------------------------
     def set_inputs(self, inputs):
         dev = self.device
+        sh = self.shape
+        want = {'text': (sh.B, sh.Tt), 'text_length': (sh.B,)}
+        if self.train:
+            want.update(mel=(sh.B, sh.Td, 80 * sh.r), stft=(sh.B, sh.Td, 1025 * sh.r))
+        if self.config.num_speakers > 1:
+            want['speaker'] = (sh.B,)
+        for k, shp in want.items():
+            if k not in inputs:
+                raise lib.TacoError('inputs[%r] is missing' % k)
+            if tuple(inputs[k].shape) != shp:   # the kernels index with self.shape: a differently shaped batch would read past the tensors
+                raise lib.TacoError('inputs[%r] has shape %s, this model was built for %s' % (k, tuple(inputs[k].shape), shp))
         self.inputs = {
             'text': inputs['text'].to(dev, torch.int32).contiguous(),
             'text_length': inputs['text_length'].to(dev, torch.int32).contiguous(),
@@ -116,30 +133,33 @@ class Tacotron(object):
                      self.masks, self.grads, self.workspace, self.speaker)
 
     def apply_gradients(self, lr):
+        """Guarded: if a decoder kernel flagged a timed-out exchange (on ANY rank -- the error words are all-reduced with
+        the gradients) the update is skipped on the device and `global_gradient_norm` reads -1; check() raises."""
         self.global_step += 1
         lib.clip_adam_step(self.params.flat, self.grads, self.adam_m, self.adam_v, lr, self.config.cap_grads,
-                           self.global_step, self._scratch, self._gnorm)
+                           self.global_step, self._scratch, self._gnorm, self._err)
 
     def step(self, lr=None, masks='draw'):
-        """One `sess.run(train_op)`: forward + backward (+ gradient all-reduce) + clip + Adam.  Everything is
-        enqueued on the current stream; nothing is copied to the host."""
+        """One `sess.run(train_op)`: forward + backward (+ gradient all-reduce, overlapped with the backward pass) +
+        clip + Adam.  Everything is enqueued on the current stream; nothing is copied to the host."""
         if masks == 'draw':
             masks = self.draw_masks()
         self.forward(masks)
         self.backward()
         if self.reducer is not None:
-            self.reducer.all_reduce(self.grads, self._loss)
+            self.reducer.reduce_after_backward(self)
         self.apply_gradients(self.lr if lr is None else lr)
 
     def check(self):
         """Raises TacoError if a decoder kernel reported a timed-out cluster exchange (the kernels never hang: every spin is
-        bounded and a time-out sets an error word in the workspace).  This is a host synchronisation -- the drivers call
-        it where they already synchronise (loss logging, after inference), not every step."""
-        if self._err_off is None:
-            self._err_off = [o for name, o, s, d in lib.workspace_table(self.shape, self.train) if name == 'dec.err'][0]
-        flags = self.workspace[self._err_off:self._err_off + 2].view(torch.int32).tolist()
+        bounded and a time-out sets a STICKY error word in the workspace, which also makes the Adam update skip itself).
+        This is a host synchronisation -- the drivers call it where they already synchronise (loss logging, after
+        inference).  The words are cleared here, after the error has been turned into an exception."""
+        flags = self._err.tolist()
         if flags[0] or flags[1]:
-            raise lib.TacoError('decoder cluster exchange timed out (forward=%d, backward=%d)' % (flags[0], flags[1]))
+            lib.clear_error(self.shape, self.train, self.workspace)
+            raise lib.TacoError('decoder cluster exchange timed out (forward=%d, backward=%d); parameter updates were '
+                                'skipped while the flag was set' % (flags[0], flags[1]))
 
     @property
     def loss(self):
@@ -159,16 +179,29 @@ class Tacotron(object):
 
     # -- checkpoint (train.py:47,85-90: weights + Adam slots + global_step) --------------------------------
     def state_dict(self):
+        """Weights + Adam slots + global_step + the spectrogram normalisation statistics (the reference keeps stft_mean /
+        stft_std as checkpointed variables, train.py:31-33, and test.py:27-28,64 de-normalises with them)."""
         d = {'params': self.params.flat.detach().cpu(), 'global_step': self.global_step,
-             'shape': (self.shape.r, self.shape.V)}
+             'shape': (self.shape.r, self.shape.V), 'num_speakers': max(1, self.shape.S), 'taco_version': lib.version()}
+        if self.stft_mean is not None:
+            d['stft_mean'] = torch.as_tensor(self.stft_mean, dtype=torch.float32).cpu()
+            d['stft_std'] = torch.as_tensor(self.stft_std, dtype=torch.float32).cpu()
         if self.train:
             d['adam_m'] = self.adam_m.cpu()
             d['adam_v'] = self.adam_v.cpu()
         return d
 
     def load_state_dict(self, d):
+        if tuple(d.get('shape', (self.shape.r, self.shape.V))) != (self.shape.r, self.shape.V) or \
+                int(d.get('num_speakers', max(1, self.shape.S))) != max(1, self.shape.S) or \
+                d['params'].numel() != self.params.numel:
+            raise lib.TacoError('checkpoint was written for (r, V)=%s, %s speaker(s), %d parameters; this model has (r, V)=%s, '
+                                '%d speaker(s), %d parameters' % (d.get('shape'), d.get('num_speakers', '?'), d['params'].numel(),
+                                                                  (self.shape.r, self.shape.V), max(1, self.shape.S), self.params.numel))
         self.params.flat.copy_(d['params'])
         self.global_step = int(d.get('global_step', 0))
+        if 'stft_mean' in d:
+            self.stft_mean, self.stft_std = d['stft_mean'], d['stft_std']
         if self.train and 'adam_m' in d:
             self.adam_m.copy_(d['adam_m'])
             self.adam_v.copy_(d['adam_v'])

@@ -16,8 +16,10 @@ from .dist import GradReducer, init_from_env
 from .model import Tacotron
 
 
-def load_corpus(data_path):
-    """data_input.load_meta + load_from_npy (data_input.py:43-85,110-113) when the npy files exist."""
+def load_corpus(data_path, seed=0):
+    """data_input.load_meta + load_from_npy (data_input.py:43-85,110-113) when the npy files exist.  The normalisation
+    statistics come from 100 utterances like the reference's (data_input.py:55-65) but from a SEEDED draw, so every rank
+    (and a restarted run) standardises the targets identically; they are returned for the checkpoint (train.py:31-33)."""
     meta_path = os.path.join(data_path, 'meta.pkl')
     if not os.path.exists(meta_path):
         return None
@@ -25,40 +27,65 @@ def load_corpus(data_path):
         meta = pkl.load(f)
     arr = {n: np.load(os.path.join(data_path, n + '.npy')) for n in ('texts', 'text_lens', 'stfts', 'mels')}
     stft, mel = arr['stfts'].astype(np.float32), arr['mels'].astype(np.float32)
-    idx = np.random.randint(len(stft), size=100)
+    idx = np.random.default_rng(seed).integers(len(stft), size=100)
     stft_mean, stft_std = stft[idx].mean((0, 1)), stft[idx].std((0, 1))
     mel_mean, mel_std = mel[idx].mean((0, 1)), mel[idx].std((0, 1))
-    return meta, {'text': arr['texts'].astype(np.int32), 'text_length': arr['text_lens'].astype(np.int32),
-                  'stft': (stft - stft_mean) / stft_std, 'mel': (mel - mel_mean) / mel_std}, stft_mean, stft_std
+    data = {'text': arr['texts'].astype(np.int32), 'text_length': arr['text_lens'].astype(np.int32),
+            'stft': (stft - stft_mean) / stft_std, 'mel': (mel - mel_mean) / mel_std}
+    spk_path = os.path.join(data_path, 'speakers.npy')   # data_input.py:76-83: present for multi-speaker corpora (VCTK)
+    if os.path.exists(spk_path):
+        data['speaker'] = np.load(spk_path).astype(np.int32)
+    return meta, data, stft_mean, stft_std
+
+
+def latest_checkpoint(ckpt_prefix):
+    """tf.train.latest_checkpoint (train.py:49-52) for files named '<prefix>-<step>': the highest STEP, not the
+    lexicographically last name ('tacotron-5000' sorts after 'tacotron-10000')."""
+    d, base = os.path.dirname(ckpt_prefix) or '.', os.path.basename(ckpt_prefix)
+    if not os.path.isdir(d):
+        return None
+    best, best_step = None, -1
+    for f in os.listdir(d):
+        head, sep, tail = f.rpartition('-')
+        if sep and head == base and tail.isdigit() and int(tail) > best_step:
+            best, best_step = os.path.join(d, f), int(tail)
+    return best
 
 
 def train(config, num_steps=1000000, log_every=50):
     rank, world, local = init_from_env()
     torch.cuda.set_device(local)
     corpus = load_corpus(config.data_path)
+    stft_mean = stft_std = None
     if corpus is not None:
         meta, data, stft_mean, stft_std = corpus
         config.r, config.vocab_size = meta['r'], len(meta['vocab'])
+        if 'speaker' in data:                       # train.py:29
+            config.num_speakers = int(data['speaker'].max()) + 1
         n = len(data['text'])
     else:
         if rank == 0:
             print('no corpus under %s -- synthetic Nancy-shaped batches' % config.data_path)
         data, n = None, 0
+    draw = np.random.default_rng(1000 + rank)       # per-rank minibatch stream
 
     def next_batch(step):
         if data is None:
             return synthetic_batch(config.batch_size, 200, config.max_decode_iter, config.r, config.vocab_size,
-                                   seed=1234 + step * 9973, rank=rank)
-        idx = np.random.randint(n, size=config.batch_size)
+                                   seed=1234 + step * 9973, rank=rank, num_speakers=config.num_speakers)
+        idx = draw.integers(n, size=config.batch_size)
         return {k: torch.from_numpy(v[idx]) for k, v in data.items()}
 
+    # same initial parameters on every rank (seed 0); the dropout / sampling streams are offset by the reducer's rank
     model = Tacotron(config, next_batch(0), train=True, seed=0, reducer=GradReducer() if world > 1 else None)
-    ckpt_dir = os.path.join('weights', config.save_path)
+    model.stft_mean, model.stft_std = stft_mean, stft_std
+    ckpt_prefix = os.path.join('weights', config.save_path)   # 'weights/nancy/tacotron' or 'weights/debug'
     if config.restore:
-        cands = sorted(f for f in os.listdir(os.path.dirname(ckpt_dir) or '.') if f.startswith('tacotron-')) \
-            if os.path.isdir(os.path.dirname(ckpt_dir)) else []
-        if cands:
-            model.load_state_dict(torch.load(os.path.join(os.path.dirname(ckpt_dir), cands[-1])))
+        path = latest_checkpoint(ckpt_prefix)
+        if path is not None:
+            model.load_state_dict(torch.load(path))
+            if rank == 0:
+                print('restored %s (global_step %d)' % (path, model.global_step))
     lr = config.init_lr
     for step in range(num_steps):
         model.set_inputs(next_batch(step))
@@ -66,7 +93,8 @@ def train(config, num_steps=1000000, log_every=50):
         gs = model.global_step
         if gs % log_every == 0 or gs % SAVE_EVERY == 0:
             loss = float(model.loss)                      # the only host sync, every log_every steps
-            model.check()                                 # decoder exchange time-outs surface here
+            model.check()                                 # decoder exchange time-outs surface here (sticky flag; the
+            #                                               guarded Adam update skipped itself in the meantime)
             if rank == 0:
                 print('step %d loss %.1f gnorm %.2f' % (gs, loss, float(model.global_gradient_norm)))
             if loss > 1e8 and gs > 500:                   # train.py:77-80
@@ -75,8 +103,8 @@ def train(config, num_steps=1000000, log_every=50):
         if gs % 1000 == 0:
             lr *= config.annealing_rate                   # train.py:82-83
         if gs % SAVE_EVERY == 0 and gs != 0 and rank == 0:
-            os.makedirs(os.path.dirname(ckpt_dir) or '.', exist_ok=True)
-            torch.save(model.state_dict(), '%s-%d' % (ckpt_dir, gs))
+            os.makedirs(os.path.dirname(ckpt_prefix) or '.', exist_ok=True)
+            torch.save(model.state_dict(), '%s-%d' % (ckpt_prefix, gs))
     return model
 
 

@@ -370,6 +370,151 @@ def test_full_size_properties(built_lib):
     assert err < 1e-5
 
 
+def _full_case(B, Tt, Td, r, V, seed_masks=0):
+    from tacotron_amd.data import synthetic_batch
+    batch = synthetic_batch(B, Tt, Td, r, V)
+    inp = {k: batch[k].numpy() for k in ('text', 'text_length', 'mel', 'stft')}
+    rng = np.random.default_rng(seed_masks)
+    masks = {'enc_keep1': rng.integers(0, 2, (B, Tt, 256)), 'enc_keep2': rng.integers(0, 2, (B, Tt, 128)),
+             'dec_keep1': rng.integers(0, 2, (B, Td, 256)), 'dec_keep2': rng.integers(0, 2, (B, Td, 128)),
+             'sample': rng.integers(0, 2, (Td, B))}
+    return inp, masks
+
+
+def _argmax_check(al_hip, al_ref, text_length, min_margin=1e-5):
+    """Attention argmax must be bit-exact wherever the oracle's top-1 / top-2 margin is >= min_margin (north_star)."""
+    srt = np.sort(al_ref, -1)
+    margin = srt[..., -1] - srt[..., -2]
+    ok = margin >= min_margin
+    same = al_hip.argmax(-1) == al_ref.argmax(-1)
+    print('  argmax compared on %d/%d (b,t); min margin overall %.2e, min compared %.2e; max alpha: median %.3f max %.3f; '
+          'mismatches among compared: %d, among all: %d' %
+          (ok.sum(), ok.size, margin.min(), margin[ok].min() if ok.any() else float('nan'),
+           float(np.median(srt[..., -1])), float(srt[..., -1].max()), int((~same & ok).sum()), int((~same).sum())))
+    assert np.array_equal(al_hip.argmax(-1)[ok], al_ref.argmax(-1)[ok]), 'attention argmax differs'
+    return int(ok.sum())
+
+
+def test_full_size_vs_oracle(built_lib):
+    """BASELINE configs[1] at FULL size (S1: B=32, Tt=200, Td=180, r=2) against the CPU restatement in fp64: outputs,
+    alignments, arg-max on all 5,760 (b,t) whose margin is >= 1e-5, loss, and EVERY parameter gradient (180 steps of BPTT).
+    Stated tolerances: outputs rel-L2 <= 1e-4 / max-abs <= 1e-3, alignments max-abs <= 1e-5, loss rel <= 1e-5,
+    gradients rel-L2 <= 1e-3 per tensor."""
+    B, Tt, Td, r, V = 32, 200, 180, 2, 60
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    inp, masks = _full_case(B, Tt, Td, r, V)
+    R = Runner(built_lib, B, Tt, Td, r, V)
+    R.pb.init_(seed=0)
+    p = R.pb.to_dict()
+    R.set(p, inp, masks)
+    R.forward()
+    R.backward()
+    lt, s2, o2, a2, ref = ot.loss_and_grads(p, f64(inp), r, Td, f64(masks))
+    r1, m1 = report('S1 seq2seq_output', R.s2s.cpu().numpy(), s2)
+    r2, m2 = report('S1 output', R.out.cpu().numpy(), o2)
+    r3, m3 = report('S1 alignments', R.al.cpu().numpy(), a2)
+    assert r1 < 1e-4 and m1 < 1e-3 and r2 < 1e-4 and m2 < 1e-3 and m3 < 1e-5
+    loss = R.loss.cpu().numpy()
+    print('  loss hip %.3f oracle %.3f' % (loss[0], lt))
+    assert abs(loss[0] - lt) <= 1e-5 * lt
+    n = _argmax_check(R.al.cpu().numpy(), a2, inp['text_length'])
+    assert n > 0.5 * B * Td
+    bad = check_grads(R, ref, tol=1e-3)
+    assert not bad, bad
+
+
+def test_peaked_attention_fixture(built_lib):
+    """Committed medium fixture (B=4, Tt=60, Td=40) whose attention is PEAKED (memory/query/v scaled so max alpha > 0.9 on
+    most steps): arg-max bit-exact on every recorded (b,t) with margin >= 1e-5, forward + backward + inference."""
+    g = np.load(os.path.join(GOLD, 'model_r2_peaked.npz'))
+    r, V, B, Tt, Td = int(g['r']), int(g['V']), int(g['B']), int(g['Tt']), int(g['Td'])
+    p = on.init_params(V, r, seed=int(g['seed']), perturb=float(g['perturb']))
+    for k, sc in zip(g['scaled_names'], g['scaled_by']):
+        p[str(k)] = p[str(k)] * float(sc)
+    flat = on.flatten_params(p, V, r, np.float64)
+    assert abs(float(np.abs(flat).sum()) - float(g['param_checksum'])) <= 1e-9 * float(g['param_checksum'])
+    inp = {'text': g['text'], 'text_length': g['text_length'], 'mel': g['mel'], 'stft': g['stft']}
+    masks = {k[5:]: g[k] for k in g.files if k.startswith('mask_')}
+    R = Runner(built_lib, B, Tt, Td, r, V)
+    R.set(p, inp, masks)
+    R.forward()
+    al = R.al.cpu().numpy()
+    r1, m1 = report('peaked seq2seq_output', R.s2s.cpu().numpy(), g['seq2seq_output'])
+    r2, m2 = report('peaked output', R.out.cpu().numpy(), g['output'])
+    r3, m3 = report('peaked alignments', al, g['alignments'])
+    assert r1 < 1e-5 and m1 < 5e-5 and r2 < 1e-5 and m2 < 5e-5 and m3 < 1e-4   # energies O(1e3): see oracle/make_golden.make_peaked
+    assert abs(R.loss[0].item() - float(g['loss'])) <= 1e-5 * float(g['loss'])
+    ok = g['argmax_margin'] >= 1e-5
+    assert ok.sum() >= 0.95 * ok.size and float((g['alignments'].max(-1) > 0.9).mean()) > 0.5
+    assert np.array_equal(al.argmax(-1)[ok], g['argmax'][ok]), 'attention argmax differs'
+    print('  peaked: argmax exact on %d/%d (b,t); max alpha > 0.9 on %.0f%% of steps; min compared margin %.2e' %
+          (ok.sum(), ok.size, 100 * float((g['alignments'].max(-1) > 0.9).mean()), g['argmax_margin'][ok].min()))
+    R.backward()
+    _, _, _, _, ref = ot.loss_and_grads(p, f64(inp), r, Td, f64(masks))
+    names = [str(n) for n in g['grad_names']]
+    for n, gn in zip(names, g['grad_norms']):
+        assert abs(np.linalg.norm(ref[n]) - gn) <= 1e-8 * max(1.0, gn)
+    bad = check_grads(R, ref)
+    assert not bad, bad
+    Ri = Runner(built_lib, B, Tt, Td, r, V, train=False)
+    Ri.set(p, {'text': inp['text'], 'text_length': inp['text_length']})
+    Ri.infer()
+    assert report('peaked infer seq2seq_output', Ri.s2s.cpu().numpy(), g['infer_seq2seq_output'])[0] < 1e-5
+    ali = Ri.al.cpu().numpy()
+    oki = g['infer_argmax_margin'] >= 1e-5
+    assert np.array_equal(ali.argmax(-1)[oki], g['infer_argmax'][oki])
+
+
+def test_s2_envelope(built_lib):
+    """BASELINE envelope S2 (B=32, Tt=200, Td=500 = 1000 mel frames, r=2).  Size-independent properties (finite, alignment
+    rows sum to 1 and vanish past text_length, loss == fp64 recomputation, bit-reproducible forward, causality: the first
+    180 steps equal the S1 run on the truncated inputs) AND a forward comparison with the fp64 CPU restatement."""
+    B, Tt, Td, r, V = 32, 200, 500, 2, 60
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    inp, masks = _full_case(B, Tt, Td, r, V)
+    R = Runner(built_lib, B, Tt, Td, r, V)
+    R.pb.init_(seed=0)
+    p = R.pb.to_dict()
+    R.set(p, inp, masks)
+    R.forward()
+    R.backward()
+    s2s, out, al = R.s2s, R.out, R.al
+    assert torch.isfinite(s2s).all() and torch.isfinite(out).all() and torch.isfinite(R.grads).all()
+    assert float((al.sum(-1) - 1).abs().max()) < 1e-5
+    for b, L in enumerate(inp['text_length']):
+        if L < Tt:
+            assert float(al[b, :, L:].abs().max()) == 0
+    l1 = (s2s.double() - R.mel.double()).abs().sum().item()
+    l2 = (out.double() - R.stft.double()).abs().sum().item()
+    loss = R.loss.cpu().numpy()
+    assert abs(loss[1] - l1) <= 2e-5 * l1 and abs(loss[2] - l2) <= 2e-5 * l2
+    s2s0, al0 = s2s.clone(), al.clone()
+    R.forward()
+    assert torch.equal(s2s0, R.s2s) and torch.equal(al0, R.al)
+    # causality: a Td=180 run on the first 180 steps' inputs/masks reproduces the prefix of the 500-step decode
+    Rs = Runner(built_lib, B, Tt, 180, r, V)
+    ms = {k: (v[:180] if k == 'sample' else (v[:, :180] if k.startswith('dec_') else v)) for k, v in masks.items()}
+    Rs.set(p, {'text': inp['text'], 'text_length': inp['text_length'], 'mel': inp['mel'][:, :180], 'stft': inp['stft'][:, :180]}, ms)
+    Rs.forward()
+    d1 = float((Rs.s2s - s2s0[:, :180]).abs().max())
+    d2 = float((Rs.al - al0[:, :180]).abs().max())
+    print('  S2 prefix vs S1 run: max|ds2s|=%.2e max|dalign|=%.2e (bitwise: %s)' % (d1, d2, d1 == 0 and d2 == 0))
+    assert d1 <= 1e-6 and d2 <= 1e-7
+    del Rs
+    # forward vs the CPU restatement (fp64, no autograd)
+    with torch.no_grad():
+        pt = ot.to_torch(p, torch.float64)
+        ti = {'text': torch.tensor(inp['text'], dtype=torch.int64), 'text_length': torch.tensor(inp['text_length'], dtype=torch.int64),
+              'mel': torch.tensor(inp['mel'], dtype=torch.float64), 'stft': torch.tensor(inp['stft'], dtype=torch.float64)}
+        tm = {k: torch.tensor(v, dtype=torch.float64) for k, v in masks.items()}
+        s2, o2, a2, _ = ot.forward(pt, ti, r, Td, True, tm)
+    r1, m1 = report('S2 seq2seq_output', s2s0.cpu().numpy(), s2.numpy())
+    r2, m2 = report('S2 output', R.out.cpu().numpy(), o2.numpy())
+    r3, m3 = report('S2 alignments', al0.cpu().numpy(), a2.numpy())
+    assert r1 < 1e-4 and m1 < 1e-3 and r2 < 1e-4 and m2 < 1e-3 and m3 < 1e-5
+    _argmax_check(al0.cpu().numpy(), a2.numpy(), inp['text_length'])
+
+
 def test_model_class_train_steps_reduce_loss(built_lib):
     """Host mirror of the reference object: Tacotron(config, inputs, train).step(lr) runs and learns."""
     from tacotron_amd.config import Config
@@ -397,6 +542,39 @@ def test_model_class_train_steps_reduce_loss(built_lib):
     m2 = Tacotron(c, batch, train=True, seed=2)
     m2.load_state_dict(sd)
     assert torch.equal(m2.params.flat, m.params.flat) and m2.global_step == 8
+
+
+def test_error_words_are_sticky_and_guard_the_update(built_lib):
+    """A decoder exchange time-out must not reach the parameters: with an error word set, clip+Adam skips itself on the
+    device (gnorm = -1), the flag survives further forward passes until check() raises and clears it."""
+    from tacotron_amd.config import Config
+    from tacotron_amd.data import synthetic_batch
+    from tacotron_amd.model import Tacotron
+    c = Config()
+    c.r, c.vocab_size = 2, 30
+    batch = synthetic_batch(4, 24, 10, 2, 30, seed=5, min_len=10)
+    m = Tacotron(c, batch, train=True, seed=1)
+    m.step(lr=1e-3)
+    torch.cuda.synchronize()
+    m.check()
+    assert float(m.global_gradient_norm) > 0
+    before = m.params.flat.clone()
+    m_before = m.adam_m.clone()
+    m._err[1] = 1                      # what decoder_bwd_kernel does on a timed-out exchange
+    m.step(lr=1e-3)
+    m.forward(m.draw_masks())          # a later forward must NOT erase the flag
+    torch.cuda.synchronize()
+    assert torch.equal(m.params.flat, before) and torch.equal(m.adam_m, m_before)
+    assert float(m.global_gradient_norm) == -1.0
+    with pytest.raises(built_lib.TacoError):
+        m.check()
+    m.check()                          # cleared by the raise above
+    m.step(lr=1e-3)
+    torch.cuda.synchronize()
+    assert not torch.equal(m.params.flat, before) and float(m.global_gradient_norm) > 0
+    # a batch of another shape is refused instead of being read out of bounds
+    with pytest.raises(built_lib.TacoError):
+        m.set_inputs(synthetic_batch(4, 25, 10, 2, 30, seed=5, min_len=10))
 
 
 def test_inference_is_graph_capturable(built_lib):

@@ -113,3 +113,18 @@ def test_text_frontend_matches_reference_vectors():
     # the vocabulary feeds load_prompts exactly as the reference's pickled ivocab does
     b = next(load_prompts(['Hello'], v.ivocab, batch_size=4))
     assert b['text'][0, :5].tolist() == ids[0][:5]
+
+
+def test_latest_checkpoint_is_numeric_and_prefix_aware(tmp_path):
+    """'tacotron-5000' sorts after 'tacotron-10000' lexicographically; restore must pick the highest STEP and
+    must find debug-mode checkpoints ('weights/debug-N') too (train.py:49-52 uses tf.train.latest_checkpoint)."""
+    from tacotron_amd.train import latest_checkpoint
+    d = tmp_path / 'weights' / 'nancy'
+    d.mkdir(parents=True)
+    for n in ('tacotron-5000', 'tacotron-10000', 'tacotron-95000', 'tacotron-100000', 'tacotron-old', 'other-999999'):
+        (d / n).write_bytes(b'x')
+    assert latest_checkpoint(str(d / 'tacotron')).endswith('tacotron-100000')
+    (tmp_path / 'weights' / 'debug-15000').write_bytes(b'x')
+    (tmp_path / 'weights' / 'debug-5000').write_bytes(b'x')
+    assert latest_checkpoint(str(tmp_path / 'weights' / 'debug')).endswith('debug-15000')
+    assert latest_checkpoint(str(tmp_path / 'nowhere' / 'tacotron')) is None

@@ -116,6 +116,26 @@ def test_golden_fixture_reproduced(name):
     assert len(g['assumptions']) == len(on.ASSUMPTIONS)
 
 
+def test_peaked_fixture_reproduced():
+    """tests/golden/model_r2_peaked.npz (peaked attention, stored as fp32) is what both restatements compute."""
+    g = np.load(os.path.join(GOLD, 'model_r2_peaked.npz'))
+    V, Td, r = int(g['V']), int(g['Td']), int(g['r'])
+    p = on.init_params(V, r, seed=int(g['seed']), perturb=float(g['perturb']))
+    for k, sc in zip(g['scaled_names'], g['scaled_by']):
+        p[str(k)] = p[str(k)] * float(sc)
+    assert abs(np.abs(on.flatten_params(p, V, r, np.float64)).sum() - float(g['param_checksum'])) < 1e-8
+    inp = {'text': g['text'], 'text_length': g['text_length'], 'mel': g['mel'].astype(np.float64),
+           'stft': g['stft'].astype(np.float64)}
+    masks = {k[5:]: g[k].astype(np.float64) for k in g.files if k.startswith('mask_')}
+    s2s, out, al, _ = on.forward(p, inp, r, Td, True, masks)
+    assert np.abs(s2s - g['seq2seq_output']).max() < 1e-5 and np.abs(out - g['output']).max() < 1e-5
+    assert np.abs(al - g['alignments']).max() < 1e-7
+    assert np.array_equal(al.argmax(-1), g['argmax'])
+    assert float((al.max(-1) > 0.9).mean()) > 0.5 and g['argmax_margin'].min() > 1e-3
+    lt, s2, o2, a2, _ = ot.loss_and_grads(p, inp, r, Td, masks)
+    assert np.abs(a2 - al).max() < 1e-10 and abs(lt - float(g['loss'])) < 1e-8 * lt
+
+
 def test_clip_adam_restatements_agree():
     rng = np.random.default_rng(0)
     p = {'a': rng.standard_normal((5, 3)), 'b': rng.standard_normal(7)}
