@@ -13,6 +13,9 @@ Extra objects on the JSON line:
   roofline     -- for the dominant kernel (persistent decoder fwd/bwd): algorithmic fp32 FLOPs per launch / average
                   launch duration measured with HIP events on the launch stream inside the timed region, against the
                   157.3 TFLOP/s fp32 (vector == f32-MFMA) peak.  See DESIGN.md for why that kernel is latency bound.
+  rooflines    -- the same per family: dominant kernel, MFMA GEMM family (events around every launch, separate untimed
+                  pass), whole step (SURVEY 8d FLOPs / ms_per_step), bi-GRU recurrences, inference B=1.
+  s2 / vctk    -- the S2 envelope (Td=500 = 1000 mel frames) and the 109-speaker configuration, same step, 1 GPU.
   cpu_baseline -- the CPU restatement (oracle/taco_torch.py, fp32, torch-CPU GEMMs; NOT TensorFlow -- TF 1.2 cannot
                   be installed) timed on this box's host cores on the same workload, rank 0, N=1 only.
 """
@@ -37,7 +40,7 @@ def decoder_flops(B, Tt, Td, r):
     return float(B) * Td * per_step
 
 
-def cpu_baseline(B, Tt, Td, r, V, steps=2):
+def cpu_baseline(B, Tt, Td, r, V, steps=5):
     """fp32 CPU restatement, forward + backward + clip + Adam, same shapes/seeds.  Test infrastructure used as a
     reported baseline only."""
     import numpy as np
@@ -78,6 +81,64 @@ def cpu_baseline(B, Tt, Td, r, V, steps=2):
                       'CPU restatement oracle/taco_torch.py (fp32), not TensorFlow' % (B, Tt, Td, r, steps, sec)}
 
 
+def model_flops(B, Tt, Td, r):
+    """algorithmic forward FLOPs (multiply-add = 2); a train step is 3x."""
+    enc = 7110656.0                       # per text position: pre_net, conv bank, projections, highways, bi-GRU, memory layer
+    dec = 3039232.0 + 1536.0 * Tt         # per decoder step and row (r = 2)
+    post = 3633664.0                      # per mel frame
+    return B * (Tt * enc + Td * dec + Td * r * post)
+
+
+def source_hash():
+    """sha1 over the kernel sources: ties a PMC summary under profiles/ to the build it was measured on."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, 'tacotron_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h')):
+            h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:12]
+
+
+def time_steps(model, steps, warmup, barrier, world):
+    from tacotron_amd import lib
+    for _ in range(warmup):
+        model.step()
+    torch.cuda.synchronize()
+    lib.profile_read(0), lib.profile_read(1)
+    lib.profile_enable(3)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        model.step()
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    lib.profile_enable(0)
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device='cuda')
+    if world > 1:
+        torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
+    fwd_ms, bwd_ms = lib.profile_read(0), lib.profile_read(1)
+    return float(elapsed.item()) / steps, fwd_ms, bwd_ms
+
+
+def family_profile(model, steps=3):
+    """Separate, untimed pass: every MFMA GEMM-family launch and every bi-GRU recurrence bracketed by HIP events on its
+    launch stream (taco_profile_enable bits 2, 3).  Returns per-step sums."""
+    from tacotron_amd import lib
+    lib.profile_read(2), lib.profile_read(3)
+    lib.profile_enable(0b1100)
+    for _ in range(steps):
+        model.step()
+    torch.cuda.synchronize()
+    lib.profile_enable(0)
+    gm, gf = lib.profile_read(2, with_flops=True)
+    rm, _ = lib.profile_read(3, with_flops=True)
+    return {'gemm_ms': sum(gm) / steps, 'gemm_flops': sum(gf) / steps, 'gemm_launches': len(gm) / steps,
+            'bigru_ms': sum(rm) / steps, 'bigru_launches': len(rm) / steps}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -88,6 +149,7 @@ def main():
     ap.add_argument('--dec-steps', type=int, default=180)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-inference', action='store_true', help='skip the inference timing (clean per-kernel profiles of the train step)')
+    ap.add_argument('--no-extras', action='store_true', help='skip the S2 (Td=500) and VCTK (109 speakers) legs and the family profile')
     ap.add_argument('--speakers', type=int, default=1, help='>1: VCTK-shaped multi-speaker model (BASELINE configs[4])')
     args = ap.parse_args()
 
@@ -105,36 +167,28 @@ def main():
     c = Config()
     c.r, c.vocab_size, c.num_speakers = 2, 60, args.speakers
     B, Tt, Td = args.batch, args.text_len, args.dec_steps
-    batch = synthetic_batch(B, Tt, Td, c.r, c.vocab_size, seed=1234, rank=rank, num_speakers=args.speakers)
     reducer = GradReducer() if world > 1 else None
-    model = Tacotron(c, batch, train=True, seed=0, reducer=reducer)   # same init on every rank (seed 0); the mask
-    #                                                                   streams are offset by the reducer's rank (model.py)
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
 
-    for _ in range(args.warmup):
-        model.step()
-    torch.cuda.synchronize()
-    lib.profile_read(0), lib.profile_read(1)
-    lib.profile_enable(True)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        model.step()
-    torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
-    lib.profile_enable(False)
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device='cuda')
-    if world > 1:
-        torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
-    sec_per_step = float(elapsed.item()) / args.steps
-    fwd_ms = lib.profile_read(0)
-    bwd_ms = lib.profile_read(1)
+    def make_model(Td_, speakers):
+        cc = Config()
+        cc.r, cc.vocab_size, cc.num_speakers = 2, 60, speakers
+        batch = synthetic_batch(B, Tt, Td_, cc.r, cc.vocab_size, seed=1234, rank=rank, num_speakers=speakers)
+        # same initial parameters on every rank (seed 0); the mask streams are offset by the reducer's rank (model.py)
+        return Tacotron(cc, batch, train=True, seed=0, reducer=reducer)
+
+    model = make_model(Td, args.speakers)
+    sec_per_step, fwd_ms, bwd_ms = time_steps(model, args.steps, args.warmup, barrier, world)
     loss = float(model.loss)
+    model.check()
+    fam = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        fam = family_profile(model)
+    del model
+    torch.cuda.empty_cache()
 
     # ---- inference (BASELINE configs[3]: prompt -> mel -> linear, Tt=140 as data_input.MAX_TEXT_LEN, always Td steps) ----
     infer = None
@@ -155,26 +209,79 @@ def main():
                 mi.run()
             torch.cuda.synchronize()
             ms = (time.perf_counter() - ti) / n_it * 1e3
-            infer['B%d' % Bi] = {'ms_per_batch': ms, 'mel_frames_per_s': Bi * Td * ci.r / (ms * 1e-3)}
+            mi.check()
+            infer['B%d' % Bi] = {'ms_per_batch': ms, 'mel_frames_per_s': Bi * Td * ci.r / (ms * 1e-3),
+                                 'decoder_cluster_width': lib.last_cluster(0), 'placement_census': mi.placement_census(),
+                                 'gflop': model_flops(Bi, 140, Td, ci.r) / 1e9,
+                                 'tflops': model_flops(Bi, 140, Td, ci.r) / (ms * 1e-3) / 1e12}
             del mi
         infer['shape'] = 'Tt=140, Td=%d steps (r=2 -> %d frames/utt), full forward incl. post-net + linear' % (Td, Td * 2)
+
+    # ---- the other measured configurations (rank 0 of a 1-GPU run only; the driver's scaling runs skip them) ----
+    s2 = vctk = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        def leg(Td_, speakers, steps=8, warmup=3):
+            m = make_model(Td_, speakers)
+            sec, f, b_ = time_steps(m, steps, warmup, barrier, 1)
+            m.check()
+            fa_, ba_ = sum(f) / max(1, len(f)), sum(b_) / max(1, len(b_))
+            del m
+            torch.cuda.empty_cache()
+            return {'ms_per_step': sec * 1e3, 'mel_frames_per_s': B * Td_ * 2 / sec, 'steps': steps, 'warmup': warmup,
+                    'decoder_fwd_ms': fa_, 'decoder_bwd_ms': ba_, 'us_per_decoder_step_fwd': fa_ * 1e3 / Td_,
+                    'us_per_decoder_step_bwd': ba_ * 1e3 / Td_, 'train_gflop_per_step': 3 * model_flops(B, Tt, Td_, 2) / 1e9}
+        if Td != 500:
+            s2 = leg(500, args.speakers)
+            s2['workload'] = 'S2 envelope: B=%d, Tt=%d, Td=500 (1000 mel frames/utt), r=2' % (B, Tt)
+        if args.speakers == 1:
+            vctk = leg(Td, 109)
+            vctk['workload'] = 'VCTK-shaped (BASELINE configs[4], 1 GPU): 109 speakers, B=%d, Tt=%d, Td=%d, r=2' % (B, Tt, Td)
 
     if rank == 0:
         frames = world * B * Td * c.r
         fa = sum(fwd_ms) / max(1, len(fwd_ms))
         ba = sum(bwd_ms) / max(1, len(bwd_ms))
         dom, dom_ms = ('decoder_bwd_kernel', ba) if ba >= fa else ('decoder_fwd_kernel', fa)
-        # algorithmic FLOPs of ONE launch: forward = SURVEY §8(d) decoder figure; the backward kernel does the
+        # algorithmic FLOPs of ONE launch: forward = SURVEY 8(d) decoder figure; the backward kernel does the
         # transposed mat-vecs + attention backward = the same count again (weight gradients are separate GEMMs).
         flops = decoder_flops(B, Tt, Td, c.r)
         achieved = flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        # HBM-side traffic per launch from the PMC passes of tools/profile_round.sh -- only if they were collected on THIS
+        # build of the kernels (source hash), else null
         traffic = None
         pmc = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(dom, {}).get('hbm_bytes_per_launch')
+                pj = json.load(open(pmc))
+                if pj.get('build') == source_hash():
+                    traffic = pj.get(dom, {}).get('hbm_bytes_per_launch')
             except Exception:
                 traffic = None
+        PEAK = 157.3
+        step_flops = 3 * model_flops(B, Tt, Td, c.r)
+        rooflines = [
+            {'what': dom, 'bound': 'latency', 'achieved': achieved, 'peak': PEAK, 'unit': 'TFLOP/s', 'frac': achieved / PEAK,
+             'avg_ms': dom_ms, 'us_per_decoder_step': dom_ms * 1e3 / Td, 'flops_per_launch': flops, 'traffic': traffic,
+             'note': 'persistent per-row recurrence: %d strictly sequential steps x 9-10 dependent exchange rounds, no MFMA, '
+                     'not HBM bound; the fp32 peak is quoted for scale only (DESIGN.md 5)' % Td},
+            {'what': 'whole train step', 'bound': 'mfma', 'achieved': step_flops / sec_per_step / 1e12, 'peak': PEAK,
+             'unit': 'TFLOP/s', 'frac': step_flops / sec_per_step / 1e12 / PEAK, 'flops_per_step': step_flops,
+             'ms_per_step': sec_per_step * 1e3},
+        ]
+        if fam and fam['gemm_ms'] > 0:
+            g = fam['gemm_flops'] / (fam['gemm_ms'] * 1e-3) / 1e12
+            rooflines.insert(1, {'what': 'MFMA GEMM family (conv_gemm + gemm_tn + fused highway launches)', 'bound': 'mfma',
+                                 'achieved': g, 'peak': PEAK, 'unit': 'TFLOP/s', 'frac': g / PEAK,
+                                 'ms_per_step_summed': fam['gemm_ms'], 'flops_per_step': fam['gemm_flops'],
+                                 'launches_per_step': fam['gemm_launches'],
+                                 'note': 'HIP events around every launch on its own stream; launches that overlap on the side '
+                                         'stream are each counted in full'})
+            rooflines.append({'what': 'bi-GRU recurrences (4 launches/step)', 'bound': 'latency',
+                              'ms_per_step_summed': fam['bigru_ms'], 'launches_per_step': fam['bigru_launches']})
+        if infer:
+            rooflines.append({'what': 'inference B=1 (whole forward)', 'bound': 'latency', 'achieved': infer['B1']['tflops'],
+                              'peak': PEAK, 'unit': 'TFLOP/s', 'frac': infer['B1']['tflops'] / PEAK,
+                              'ms': infer['B1']['ms_per_batch'], 'gflop': infer['B1']['gflop']})
         res = {
             'metric': 'mel-frames/sec (train step, batch=32 r=2)', 'value': frames / sec_per_step, 'unit': 'mel-frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': sec_per_step * 1e3,
@@ -183,15 +290,17 @@ def main():
                                    '(%d mel frames/utt), sched-sampling 0.5, dropout 0.5, V=60, speakers=%d, fwd+bwd+clip+Adam'
                                    % (B, c.r, Tt, Td, Td * c.r, args.speakers),
                        'global_batch': world * B, 'parallelism': 'dp%d' % world},
-            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': 157.3, 'unit': 'TFLOP/s',
-                         'frac': achieved / 157.3, 'traffic': traffic, 'kernel': dom, 'avg_ms': dom_ms,
-                         'launches_timed': len(bwd_ms if dom.startswith('decoder_bwd') else fwd_ms),
-                         'flops_per_launch': flops,
-                         'note': 'persistent per-row recurrence, fp32 FMA; latency/L2-stream bound (DESIGN.md)'},
+            # dominant kernel (largest share of the step); `rooflines` carries every family
+            'roofline': dict(rooflines[0], kernel=dom, launches_timed=len(bwd_ms if dom.startswith('decoder_bwd') else fwd_ms)),
+            'rooflines': rooflines,
             'kernels_ms': {'decoder_fwd_kernel': fa, 'decoder_bwd_kernel': ba,
                            'us_per_decoder_step_fwd': fa * 1e3 / Td, 'us_per_decoder_step_bwd': ba * 1e3 / Td},
-            'final_loss': loss,
+            'final_loss': loss, 'build': source_hash(),
         }
+        if s2:
+            res['s2'] = s2
+        if vctk:
+            res['vctk'] = vctk
         if infer:
             res['inference'] = infer
         if world == 1 and not args.no_cpu_baseline:

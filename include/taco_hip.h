@@ -163,12 +163,19 @@ int taco_denorm_unframe(const float* output, const float* stft_mean, const float
 int taco_fill_bernoulli(uint8_t* out, int64_t n, float p_one, uint64_t seed, void* stream);
 
 /* ---- measurement --------------------------------------------------------------------------------------------- */
-/* When enabled, every launch of the two persistent decoder kernels (the dominant kernels of a train step) is bracketed
- * by hipEventRecord on the launch stream (a ring of 1024 event pairs per kernel; no synchronisation).
- * taco_profile_read synchronises on the recorded events, writes up to `cap` elapsed times in milliseconds to the HOST
- * array `ms` (oldest first), clears the ring and returns the count.  which: 0 = decoder forward, 1 = decoder backward. */
-int taco_profile_enable(int on);
+/* Launch-level timing with hipEventRecord pairs on the launch stream (rings of 4096 event pairs per category; no
+ * synchronisation at record time).  Categories: 0 = persistent decoder forward kernel, 1 = decoder backward kernel,
+ * 2 = MFMA GEMM family (conv_gemm / gemm_tn / fused highway stack launches), 3 = bi-GRU recurrences.
+ * taco_profile_enable(mask): bit c switches category c on (mask 1 is read as "both decoder kernels", mask 0 = off).
+ * taco_profile_read2 synchronises on the recorded events, writes up to `cap` elapsed times (milliseconds) and the
+ * algorithmic FLOPs of each launch (2 M N K taps) to the HOST arrays, oldest first, clears the ring, returns the count.
+ * Launches that overlap on two streams are each timed by their own events (their times then sum to more than the wall). */
+int taco_profile_enable(int mask);
+/* Workgroups per batch row (cluster width) the most recent decoder forward (which = 0) / backward (1) launch of this process
+ * ran with: 8 in training, up to 16 at inference, fewer when B * width workgroups would not be co-resident. */
+int taco_debug_last_cluster(int which);
 int taco_profile_read(int which, float* ms, int cap);
+int taco_profile_read2(int which, float* ms, double* flops, int cap);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

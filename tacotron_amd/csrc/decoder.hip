@@ -434,7 +434,15 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
   for (int i = tid; i < KX + kDec; i += NT) S.u0[i] = 0.f;
   for (int i = tid; i < TtP; i += NT) { S.als[i] = 0.f; S.es[i] = 0.f; }
   if (tid < kMel) S.fr[tid] = a.mel ? a.mel[((int64_t)b * Td) * R80 + kMel * (r - 1) + tid] : 0.f;
-  if (tid == 0) *S.dead = 0;
+  if (tid == 0) {
+    *S.dead = 0;
+    // placement census (diagnostic, one atomic per workgroup per launch): histogram of (blockIdx - XCC id) mod 8 in the
+    // integer words 4..11 of the error region.  The cluster layout is FAST when every workgroup falls in one bin (peer p of
+    // every row on the same XCD => each XCD's L2 holds one weight slice); any other placement is still correct, only slower.
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    atomicAdd(a.err + 4 + ((blockIdx.x - (xcc & 7u)) & 7u), 1);
+  }
   for (int i = tid; i < kPre1; i += NT) S.bias[BO_P1 + i] = w.pre_b1[i];
   for (int i = tid; i < kPre1; i += NT) S.bias[BO_P1O + i] = cw.bp1o[i];
   for (int i = tid; i < kPre2; i += NT) S.bias[BO_P2 + i] = w.pre_b2[i];
@@ -1152,12 +1160,19 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
 
 // Largest cluster width in {32,...,2,1} whose B*P workgroups are all co-resident (the all-gather needs every peer running).
 // The mat-vecs are bound by the per-CU vector-memory path (64 B/clk), so small batches spread a row over more CUs.
+int g_last_cluster[2] = {0, 0};   // cluster width of the most recent forward / backward launch (taco_debug_last_cluster)
 template <class K>
 int pick_cluster(K kernel, size_t smem, int B, int want) {
   int dev = 0, cus = 0, per_cu = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return 1;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 1;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, NT, smem) != hipSuccess) return 1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, NT, smem);
+  if (e != hipSuccess || per_cu < 1) {
+    // a silent fall-back to one workgroup per row is 3x slower: say so
+    fprintf(stderr, "taco: decoder occupancy query failed (%s, %d blocks/CU, %zu B LDS): running ONE workgroup per row\n",
+            hipGetErrorString(e), per_cu, smem);
+    return 1;
+  }
   const int64_t cap = (int64_t)cus * per_cu;
   for (int p = 32; p >= 2; p >>= 1)
     if (p <= want && (int64_t)B * p <= cap) return p;
@@ -1175,6 +1190,8 @@ int env_cluster(int dflt) {
 }
 
 }  // namespace
+
+int decoder_last_cluster(int which) { return g_last_cluster[which & 1]; }
 
 int64_t decoder_xchg_bytes(int B, int Tt) {
   const int TtP = (Tt + 3) & ~3;
@@ -1198,6 +1215,7 @@ int launch_decoder_fwd(DecFwdArgs a, hipStream_t s) {
     }
   }
   a.P = pick_cluster(kern, smem, a.B, env_cluster(a.mel ? 8 : 16));
+  g_last_cluster[0] = a.P;
   if (a.P > 1) {
     hipError_t e = hipMemsetAsync(a.xchg, 0, (size_t)decoder_xchg_bytes(a.B, a.Tt), s);
     if (e != hipSuccess) {
@@ -1226,6 +1244,7 @@ int launch_decoder_bwd(DecBwdArgs a, hipStream_t s) {
     }
   }
   a.P = pick_cluster(kern, smem, a.B, env_cluster(8));
+  g_last_cluster[1] = a.P;
   if (a.P > 1) {
     hipError_t e = hipMemsetAsync(a.xchg, 0, (size_t)decoder_xchg_bytes(a.B, a.Tt), s);
     if (e != hipSuccess) {

@@ -490,12 +490,16 @@ int launch_conv_gemm_batch(ConvGemmBatch& batch, hipStream_t stream) {
     maxN = p.N > maxN ? p.N : maxN;
     work += (double)cdiv(p.M, 128) * cdiv(p.N, 128);
   }
+  double flops = 0;
+  for (int i = 0; i < batch.n; ++i) flops += 2.0 * batch.p[i].M * batch.p[i].N * batch.p[i].K * batch.p[i].taps;
+  const int pslot = taco_prof_begin(2, stream);
   // Big tiles only when they still fill the chip (256 CUs); otherwise 64x64 tiles for more workgroups.
   if (work >= 384) {
     dispatch_nn<2, 2>(flags, dim3(cdiv(maxM, 128), cdiv(maxN, 128), batch.n), stream, batch);
   } else {
     dispatch_nn<1, 1>(flags, dim3(cdiv(maxM, 64), cdiv(maxN, 64), batch.n), stream, batch);
   }
+  taco_prof_end(2, pslot, stream, flops);
   TACO_LAUNCH_CHECK("conv_gemm");
   return TACO_OK;
 }
@@ -580,10 +584,12 @@ int launch_gemm_tn(GemmTnArgs a, bool zero_first, hipStream_t stream) {
   }
   dim3 grid;
   const int bm = plan_gemm_tn(a, false, grid);
+  const int pslot = taco_prof_begin(2, stream);
   if (bm == 128)
     dispatch_tn<2, 2>(a.flags, grid, stream, a);
   else
     dispatch_tn<1, 1>(a.flags, grid, stream, a);
+  taco_prof_end(2, pslot, stream, 2.0 * a.M * a.N * a.K * a.taps * a.batch);
   TACO_LAUNCH_CHECK("gemm_tn");
   return TACO_OK;
 }
@@ -613,7 +619,12 @@ int launch_gemm_tn_batch(GemmTnBatch& b, hipStream_t stream) {
     blocks += (int)(grid.x * grid.y * grid.z);
   }
   if (grouped.n > 0) {
+    double flops = 0;
+    for (int i = 0; i < grouped.n; ++i)
+      flops += 2.0 * grouped.p[i].M * grouped.p[i].N * grouped.p[i].K * grouped.p[i].taps * grouped.p[i].batch;
+    const int pslot = taco_prof_begin(2, stream);
     hipLaunchKernelGGL(gemm_tn_batch_kernel, dim3(blocks), dim3(256), 0, stream, grouped);
+    taco_prof_end(2, pslot, stream, flops);
     TACO_LAUNCH_CHECK("gemm_tn_batch");
   }
   b.n = 0;

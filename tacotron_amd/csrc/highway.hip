@@ -232,14 +232,18 @@ int launch_highway_stack_bwd(const HighwayStackBwdArgs& a, hipStream_t s) {
   static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(highway_stack_bwd_kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHwBwdSmem) == hipSuccess;
   TACO_REQUIRE(ok, "highway_stack_bwd: cannot reserve %zu bytes of LDS", kHwBwdSmem);
+  const int pslot = taco_prof_begin(2, s);
   hipLaunchKernelGGL(highway_stack_bwd_kernel, dim3(cdiv(a.M, HB)), dim3(256), kHwBwdSmem, s, a);
+  taco_prof_end(2, pslot, s, 2.0 * a.M * HC * 2 * HC * a.nl);
   TACO_LAUNCH_CHECK("highway_stack_bwd");
   return TACO_OK;
 }
 
 int launch_highway_stack_fwd(const HighwayStackArgs& a, hipStream_t s) {
   TACO_REQUIRE(a.M > 0 && a.nl >= 1 && a.nl <= 4 && a.x, "highway_stack_fwd: bad arguments");
+  const int pslot = taco_prof_begin(2, s);
   hipLaunchKernelGGL(highway_stack_fwd_kernel, dim3(cdiv(a.M, HB)), dim3(256), 0, s, a);
+  taco_prof_end(2, pslot, s, 2.0 * a.M * HC * 2 * HC * a.nl);
   TACO_LAUNCH_CHECK("highway_stack_fwd");
   return TACO_OK;
 }

@@ -2,6 +2,12 @@
 #pragma once
 #include "common.h"
 
+// ---------------------------------------------------------------- profiling rings (model.hip)
+// category 0 / 1: decoder fwd / bwd kernel, 2: MFMA GEMM family, 3: bi-GRU recurrences.  begin returns a slot (or -1 when the
+// category is not being recorded); end stamps the stop event and the launch's algorithmic FLOPs.
+int taco_prof_begin(int which, hipStream_t s);
+void taco_prof_end(int which, int slot, hipStream_t s, double flops);
+
 // ---------------------------------------------------------------- gemm.hip
 constexpr int kMaxGemmBatch = 16;
 
@@ -227,6 +233,7 @@ struct DecFwdArgs {
   int P;                 // cluster width (workgroups per row); chosen by launch_decoder_fwd
 };
 int64_t decoder_xchg_bytes(int B, int Tt);
+int decoder_last_cluster(int which);   // cluster width (workgroups per row) of the last forward (0) / backward (1) launch
 int launch_decoder_fwd(DecFwdArgs a, hipStream_t s);
 
 struct DecBwdArgs {

@@ -37,35 +37,43 @@ const Layouts& layouts_for(const TacoShape& s) {
 }
 
 
-// ---- HIP-event profiling ring for the dominant kernels (taco_profile_enable / taco_profile_read) ----
+// ---- HIP-event profiling rings (taco_profile_enable / taco_profile_read[2]) ----
+// category: 0 decoder forward kernel, 1 decoder backward kernel, 2 MFMA GEMM family (conv_gemm, gemm_tn, highway stack),
+// 3 bi-GRU recurrences.  Every bracketed launch gets a hipEventRecord pair on ITS launch stream plus its algorithmic FLOPs.
 struct ProfRing {
-  static constexpr int kCap = 1024;
+  static constexpr int kCap = 4096;
   hipEvent_t start[kCap], stop[kCap];
-  bool created = false;
+  double flops[kCap];
+  int created = 0;   // events created so far (lazily, in steps: creating 2 x 4096 events up front costs milliseconds)
   int n = 0;
 };
-ProfRing g_prof[2];
-bool g_prof_on = false;
+ProfRing g_prof[4];
+int g_prof_mask = 0;   // bit c: category c is recorded
 
-int prof_begin(int which, hipStream_t s) {
-  if (!g_prof_on) return -1;
+}  // namespace
+
+int taco_prof_begin(int which, hipStream_t s) {
+  if (!(g_prof_mask & (1 << which))) return -1;
   ProfRing& r = g_prof[which];
-  if (!r.created) {
-    for (int i = 0; i < ProfRing::kCap; ++i) {
-      if (hipEventCreate(&r.start[i]) != hipSuccess || hipEventCreate(&r.stop[i]) != hipSuccess) return -1;
-    }
-    r.created = true;
-  }
   if (r.n >= ProfRing::kCap) return -1;
+  while (r.created <= r.n) {
+    if (hipEventCreate(&r.start[r.created]) != hipSuccess || hipEventCreate(&r.stop[r.created]) != hipSuccess) return -1;
+    ++r.created;
+  }
   (void)hipEventRecord(r.start[r.n], s);
   return r.n;
 }
-void prof_end(int which, int slot, hipStream_t s) {
+void taco_prof_end(int which, int slot, hipStream_t s, double flops) {
   if (slot < 0) return;
   ProfRing& r = g_prof[which];
   (void)hipEventRecord(r.stop[slot], s);
+  r.flops[slot] = flops;
   r.n = slot + 1;
 }
+
+namespace {
+inline int prof_begin(int which, hipStream_t s) { return taco_prof_begin(which, s); }
+inline void prof_end(int which, int slot, hipStream_t s) { taco_prof_end(which, slot, s, 0.0); }
 
 struct CbhgBufs {
   float *bank, *pool, *pj1pre, *pj1, *pj2pre, *res, *h[5], *hx[4], *th[4], *xg, *out, *ruc, *tapsplit = nullptr;
@@ -1072,13 +1080,16 @@ extern "C" int taco_fill_bernoulli(uint8_t* out, int64_t n, float p_one, uint64_
   return launch_bernoulli(out, n, p_one, seed, as_stream(stream));
 }
 
-extern "C" int taco_profile_enable(int on) {
-  g_prof_on = on != 0;
+extern "C" int taco_debug_last_cluster(int which) { return decoder_last_cluster(which); }
+
+extern "C" int taco_profile_enable(int mask) {
+  // historical callers pass 1 for "the two decoder kernels"
+  g_prof_mask = mask == 1 ? 3 : mask;
   return TACO_OK;
 }
 
-extern "C" int taco_profile_read(int which, float* ms, int cap) {
-  TACO_REQUIRE(which == 0 || which == 1, "profile_read: which must be 0 or 1");
+extern "C" int taco_profile_read2(int which, float* ms, double* flops, int cap) {
+  TACO_REQUIRE(which >= 0 && which < 4, "profile_read: category %d out of range", which);
   ProfRing& r = g_prof[which];
   int n = 0;
   for (int i = 0; i < r.n; ++i) {
@@ -1086,8 +1097,11 @@ extern "C" int taco_profile_read(int which, float* ms, int cap) {
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.start[i], r.stop[i]) != hipSuccess) break;
     if (ms && n < cap) ms[n] = t;
+    if (flops && n < cap) flops[n] = r.flops[i];
     ++n;
   }
   r.n = 0;
   return n;
 }
+
+extern "C" int taco_profile_read(int which, float* ms, int cap) { return taco_profile_read2(which, ms, nullptr, cap); }

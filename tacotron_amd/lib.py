@@ -65,7 +65,9 @@ EXPORTS = {
     'taco_denorm_unframe': (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'taco_fill_bernoulli': (C.c_int, [_P, C.c_int64, C.c_float, C.c_uint64, _P]),
     'taco_profile_enable': (C.c_int, [_I]),
+    'taco_debug_last_cluster': (C.c_int, [_I]),
     'taco_profile_read': (C.c_int, [_I, C.POINTER(C.c_float), _I]),
+    'taco_profile_read2': (C.c_int, [_I, C.POINTER(C.c_float), C.POINTER(C.c_double), _I]),
 }
 for _name, (_res, _args) in EXPORTS.items():
     _fn = getattr(_lib, _name)  # AttributeError here = the library does not export what include/taco_hip.h declares
@@ -231,14 +233,23 @@ def fill_bernoulli(out, p_one, seed):
            'taco_fill_bernoulli')
 
 
-def profile_enable(on: bool):
-    _check(_lib.taco_profile_enable(int(on)), 'taco_profile_enable')
+def last_cluster(which: int) -> int:
+    return _lib.taco_debug_last_cluster(int(which))
 
 
-def profile_read(which: int):
-    """Elapsed milliseconds of every recorded launch of decoder forward (0) / backward (1) since the last read."""
-    buf = (C.c_float * 1024)()
-    n = _lib.taco_profile_read(which, buf, 1024)
+def profile_enable(mask):
+    """mask: bit c = category c (0 decoder fwd, 1 decoder bwd, 2 GEMM family, 3 bi-GRU); True = both decoder kernels."""
+    _check(_lib.taco_profile_enable(3 if mask is True else int(mask)), 'taco_profile_enable')
+
+
+def profile_read(which: int, with_flops=False):
+    """Elapsed milliseconds (and algorithmic FLOPs) of every recorded launch of category `which` since the last read."""
+    cap = 4096
+    buf = (C.c_float * cap)()
+    fl = (C.c_double * cap)()
+    n = _lib.taco_profile_read2(which, buf, fl, cap)
     if n < 0:
         raise TacoError('taco_profile_read: ' + last_error())
-    return [buf[i] for i in range(min(n, 1024))]
+    n = min(n, cap)
+    ms = [buf[i] for i in range(n)]
+    return (ms, [fl[i] for i in range(n)]) if with_flops else ms

@@ -42,6 +42,7 @@ class Tacotron(object):
         # the decoder kernels' two error words (sticky: cleared here and by check(), never by the library)
         eoff = [o for name, o, s, d in lib.workspace_table(self.shape, train) if name == 'dec.err'][0]
         self._err = self.workspace[eoff:eoff + 2].view(torch.int32)
+        self._census = self.workspace[eoff + 4:eoff + 12].view(torch.int32)
         lib.clear_error(self.shape, train, self.workspace)
         self.stft_mean = self.stft_std = None   # train.py:31-33: normalisation statistics travel with the checkpoint
         if train:
@@ -160,6 +161,11 @@ class Tacotron(object):
             lib.clear_error(self.shape, self.train, self.workspace)
             raise lib.TacoError('decoder cluster exchange timed out (forward=%d, backward=%d); parameter updates were '
                                 'skipped while the flag was set' % (flags[0], flags[1]))
+
+    def placement_census(self):
+        """Diagnostic: histogram of (blockIdx - XCD id) mod 8 over the decoder-forward workgroups launched since the last
+        clear_error().  One non-zero bin = the fast placement (one weight slice per XCD L2); host synchronisation."""
+        return self._census.tolist()
 
     @property
     def loss(self):

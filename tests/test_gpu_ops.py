@@ -186,7 +186,7 @@ def test_clip_adam_step(built_lib, gscale):
     m = {'w': np.zeros(n)}
     v = {'w': np.zeros(n)}
     P, Mm, Vv = dev(p0), torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
-    scratch, gn_out = torch.zeros(8, device='cuda'), torch.zeros(1, device='cuda')
+    scratch, gn_out = torch.zeros(256, device='cuda'), torch.zeros(1, device='cuda')
     for step in (1, 2, 3):
         g = rng.standard_normal(n) * gscale
         gn = on.clip_adam_step(p, {'w': g}, m, v, step, 5e-4)
