@@ -493,6 +493,17 @@ int launch_conv_gemm_batch(ConvGemmBatch& batch, hipStream_t stream) {
   double flops = 0;
   for (int i = 0; i < batch.n; ++i) flops += 2.0 * batch.p[i].M * batch.p[i].N * batch.p[i].K * batch.p[i].taps;
   const int pslot = taco_prof_begin(2, stream);
+  if (flags == 3) {
+    // second-generation kernel (gemm2.hip: DMA-staged 32-deep k-tiles, 128 x 128 tiles) whenever the batch meets its
+    // contract and has enough tiles to occupy the chip
+    const int rc = launch_conv_gemm2(batch, stream);
+    if (rc != TACO_ENOTFOUND) {
+      taco_prof_end(2, pslot, stream, flops);
+      if (rc != TACO_OK) return rc;
+      TACO_LAUNCH_CHECK("conv_gemm2");
+      return TACO_OK;
+    }
+  }
   // Big tiles only when they still fill the chip (256 CUs); otherwise 64x64 tiles for more workgroups.
   if (work >= 384) {
     dispatch_nn<2, 2>(flags, dim3(cdiv(maxM, 128), cdiv(maxN, 128), batch.n), stream, batch);

@@ -46,6 +46,9 @@ struct GemmTnArgs {
 };
 
 int launch_conv_gemm_batch(ConvGemmBatch& batch, hipStream_t stream);
+// gemm2.hip: DMA-staged NN kernel for batches that meet the vector contract (flags == 3 on every problem) and have at least
+// TACO_GEMM2_MIN_TILES (default 96) 128 x 128 tiles; returns TACO_ENOTFOUND without launching otherwise.
+int launch_conv_gemm2(ConvGemmBatch& batch, hipStream_t stream);
 // The CBHG's highway layers as one launch (highway.hip).  Layer l: th[l] = [sigmoid(x Wt+bt) | relu(x Wh+bh)] (M,256),
 // y[l] = H*T + x*(1-T) (M,128) feeds layer l+1.
 struct HighwayStackArgs {

@@ -302,7 +302,7 @@ def test_long_text_and_cluster_widths(built_lib, cluster, monkeypatch):
     assert report('B=1 infer align', R1.al.cpu().numpy(), a1)[1] < 1e-6
 
 
-def test_medium_shape_forward_backward(built_lib):
+def test_medium_shape_forward_backward(built_lib, grad_tol=2e-4):
     """B=4, Tt=37, Td=12: multi-tile GEMMs, several attention rows per wave, sampling + dropout masks."""
     r, V, B, Tt, Td = 2, 40, 4, 37, 12
     p = on.init_params(V, r, seed=4, perturb=0.2)
@@ -316,7 +316,7 @@ def test_medium_shape_forward_backward(built_lib):
     assert report('out', R.out.cpu().numpy(), o2)[0] < 1e-5
     assert report('align', R.al.cpu().numpy(), a2)[1] < 1e-6
     assert abs(R.loss[0].item() - lt) <= 1e-5 * lt
-    bad = check_grads(R, ref)
+    bad = check_grads(R, ref, tol=grad_tol)
     assert not bad, bad
 
 
@@ -368,6 +368,20 @@ def test_full_size_properties(built_lib):
     err = (gsum - g_full).norm().item() / g_full.norm().item()
     print('  DP additivity rel err %.3e, |g|=%.4e' % (err, g_full.norm().item()))
     assert err < 1e-5
+
+
+@pytest.mark.parametrize('variant', ['32x2', '16x3'])
+def test_medium_shape_with_gemm2_forced(built_lib, variant, monkeypatch):
+    """The whole train step with EVERY eligible NN GEMM on the second-generation kernel (at the test sizes the dispatcher would
+    otherwise keep the 64x64 kernel): batched conv-bank launch, tap-split projections, atomic-accumulate bank backward."""
+    monkeypatch.setenv('TACO_GEMM2_MIN_TILES', '1')
+    monkeypatch.setenv('TACO_GEMM2_VARIANT', variant)
+    # Gradient tolerance = the stated 1e-3 (SURVEY 8c), not the 2e-4 the other tests happen to meet: with this kernel's k
+    # summation order ONE highway ReLU pre-activation of row 0 (|x| ~ 1e-7) lands on the other side of zero than in the fp64
+    # oracle, which moves the encoder pre_net / embedding gradients of rows 0-2 by 2.3e-4 (bisected with
+    # tools/v2_bisect.py / v2_flip.py: every launch alone is within 5e-7 of the other kernel; forward tensors within 1e-6).
+    test_medium_shape_forward_backward(built_lib, grad_tol=1e-3)
+    test_backward_without_masks_and_ragged_lengths(built_lib)
 
 
 def _full_case(B, Tt, Td, r, V, seed_masks=0):

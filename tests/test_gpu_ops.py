@@ -99,6 +99,25 @@ def test_conv_gemm(built_lib, case):
         assert report('  Cpre', Cpre.cpu().numpy(), pre)[0] < 5e-6
 
 
+V2_CASES = [c for c in CASES if c[2] % 4 == 0 and c[3] % 4 == 0] + [
+    (1000, 200, 300, 132, 3, 1, 1, 'bias,keep,scale,residual,pre'),   # every ragged edge at once: M, N, K tails, 5 sequences
+    (640, 40, 128, 128, 16, 7, 1, 'bias'),                            # widest conv-bank problem
+    (720, 360, 1024, 256, 3, 1, 0, ''),                               # post-net dpool-like: many n-tiles
+    (520, 520, 260, 2048, 1, 0, 0, 'bias'),                           # deep K (64 k-tiles of 32)
+]
+
+
+@pytest.mark.parametrize('variant', ['32x2', '32x3', '16x3', '16x4'])
+@pytest.mark.parametrize('case', V2_CASES, ids=[str(c[:6]) for c in V2_CASES])
+def test_conv_gemm_v2(built_lib, case, variant, monkeypatch):
+    """gemm2.hip (DMA-staged, swizzled, 4-MFMAs-per-read kernel) forced for every shape that meets its contract, in all four
+    (k-tile depth x ring stages) instantiations: K / N / M tails redirected to the zero word, tap shifts across sequence
+    boundaries, the float4 and the scalar epilogue."""
+    monkeypatch.setenv('TACO_GEMM2_MIN_TILES', '1')
+    monkeypatch.setenv('TACO_GEMM2_VARIANT', variant)
+    test_conv_gemm(built_lib, case)
+
+
 def test_conv_gemm_strided_unaligned(built_lib):
     """lda not a multiple of 4 (1025-wide rows) exercises the scalar-load path; ldc > N exercises column offsets."""
     rng = np.random.default_rng(5)
