@@ -80,6 +80,13 @@ int taco_conv_gemm(const float* A, int lda, const float* W, int ldw, const float
                    const float* shift, const float* residual, int ldr, const uint8_t* keep, float* C, int ldc,
                    float* Cpre, int M, int N, int K, int taps, int T, int pad_l, int act, void* stream);
 
+/* Same contract (without the post() part), run the way the library runs the tall-skinny CBHG projections: the (tap, k) sum is
+ * cut into chunks that become independent workgroups writing partial slabs (scratch `slabs`, `slab_floats` floats), summed in a
+ * fixed order by a second pass -- deterministic, no atomics.  Exposed for parity tests and tuning. */
+int taco_debug_conv_gemm_ksplit(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M,
+                                int N, int K, int taps, int T, int pad_l, int act, float* slabs, int64_t slab_floats,
+                                void* stream);
+
 /* dW[tap][k][n] (+)= sum_m A[row(m,tap), k] * dY[m, n]   (weight gradient of the op above; accumulate != 0 adds) */
 int taco_gemm_tn(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, int M, int N, int K, int taps,
                  int T, int pad_l, int accumulate, void* stream);

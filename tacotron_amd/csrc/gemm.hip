@@ -9,6 +9,8 @@
 // A/B tiles are staged k-major in LDS so that the f32 MFMA operand fetch (lane l -> [k = l>>5][i = l&31]) is a
 // conflict-free 32-lane contiguous ds_read_b32.  Global loads are float4 along the contiguous dimension with a
 // scalar fallback for unaligned leading dimensions (e.g. 1025-wide linear frames).
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -515,7 +517,60 @@ int launch_conv_gemm_batch(ConvGemmBatch& batch, hipStream_t stream) {
   return TACO_OK;
 }
 
-int launch_conv_gemm_tapsplit(const ConvGemmProblem& p, float* slabs, hipStream_t stream) {
+int launch_conv_gemm_tapsplit(const ConvGemmProblem& p, float* slabs, int64_t slab_floats, hipStream_t stream) {
+  // Preferred: k-split on the second-generation kernel.  The (tap, 32-deep k-tile) sequence is cut into S chunks, each a
+  // problem of ONE grouped gemm2 launch writing its own slab; S minimises a makespan model
+  //   ceil(tiles * S / 256 CUs) * ceil(k-tiles / S)  +  slab round trip,
+  // e.g. encoder proj1 (50 tiles x 192 k-tiles): S = 5 -> 250 workgroups of 39 k-tiles instead of 50 of 192.
+  {
+    ConvGemmProblem q = p;
+    conv_gemm_set_flags(q);
+    const int64_t mn = (int64_t)p.M * p.N;
+    if (slabs && (q.flags & 3) == 3 && !p.atomic_out && p.N % 4 == 0 && gemm2_min_tiles() > 0 && mn > 0) {
+      const int tiles = cdiv(p.M, 128) * cdiv(p.N, 128);
+      const int nit = p.taps * cdiv(p.K, 32);
+      int maxS = (int)std::min<int64_t>(std::min<int64_t>(kMaxGemmBatch, slab_floats / mn), nit / 6);
+      int bestS = 1;
+      double best = 1e30;
+      for (int S = 1; S <= maxS; ++S) {
+        const double slab_units = S > 1 ? (2.0 * S * mn * 4.0 / 4.0e12) / 1.7e-6 : 0.0;   // write + read at ~4 TB/s, in k-tile times
+        const double cost = (double)cdiv((int64_t)tiles * S, 256) * cdiv(nit, S) + slab_units;
+        if (cost < best * 0.97) {   // prefer fewer slabs unless the model gains >= 3 %
+          best = cost;
+          bestS = S;
+        }
+      }
+      if (const char* e = getenv("TACO_KSPLIT")) {   // tuning override
+        const int v = atoi(e);
+        if (v >= 1 && v <= maxS) bestS = v;
+      }
+      if (bestS >= 2) {
+        ConvGemmBatch b;
+        b.n = bestS;
+        const int per = cdiv(nit, bestS);
+        for (int c = 0; c < bestS; ++c) {
+          ConvGemmProblem& r = b.p[c];
+          r = ConvGemmProblem();
+          r.A = p.A; r.lda = p.lda; r.W = p.W; r.ldw = p.ldw; r.Nld = p.Nld; r.C = slabs + c * mn; r.ldc = p.N;
+          r.M = p.M; r.N = p.N; r.K = p.K; r.taps = p.taps; r.T = p.T; r.pad_l = p.pad_l; r.act = TACO_ACT_NONE;
+          r.it0 = c * per;
+          r.it1 = std::min(nit, (c + 1) * per);
+          conv_gemm_set_flags(r);
+        }
+        const int pslot = taco_prof_begin(2, stream);
+        const int rc = launch_conv_gemm2(b, stream, /*force=*/true);
+        if (rc == TACO_OK) {
+          const int64_t total4 = mn / 4;
+          const int grid = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
+          hipLaunchKernelGGL(conv_gemm_tapsum_kernel, dim3(grid), dim3(256), 0, stream, p, slabs, bestS);
+          taco_prof_end(2, pslot, stream, 2.0 * p.M * p.N * p.K * p.taps);
+          TACO_LAUNCH_CHECK("conv_gemm2 k-split");
+          return TACO_OK;
+        }
+        if (rc != TACO_ENOTFOUND) return rc;
+      }
+    }
+  }
   const double tiles64 = (double)cdiv(p.M, 64) * cdiv(p.N, 64);
   // worth it only while the 64x64 grid leaves CUs idle (encoder proj1: 200 tiles, 241 -> 163 + 12 us; the post-net's 720 tiles
   // are better off unsplit), and every tap still has a deep K loop
@@ -593,6 +648,13 @@ int launch_gemm_tn(GemmTnArgs a, bool zero_first, hipStream_t stream) {
       }
     }
   }
+  if (gemm_tn2_eligible(a)) {
+    const int pslot2 = taco_prof_begin(2, stream);
+    TACO_TRY(launch_gemm_tn2(&a, 1, stream));
+    taco_prof_end(2, pslot2, stream, 2.0 * a.M * a.N * a.K * a.taps);
+    TACO_LAUNCH_CHECK("gemm_tn2");
+    return TACO_OK;
+  }
   dim3 grid;
   const int bm = plan_gemm_tn(a, false, grid);
   const int pslot = taco_prof_begin(2, stream);
@@ -611,10 +673,18 @@ int launch_gemm_tn_batch(GemmTnBatch& b, hipStream_t stream) {
   TACO_REQUIRE(b.n >= 0 && b.n <= kMaxTnBatch, "gemm_tn_batch: %d problems out of range", b.n);
   GemmTnBatch grouped;
   int blocks = 0;
+  GemmTnArgs big[kMaxTnBatch];
+  int nbig = 0;
+  double big_flops = 0;
   for (int i = 0; i < b.n; ++i) {
     GemmTnArgs a = b.p[i];
     TACO_REQUIRE(a.A && a.Y && a.W, "gemm_tn_batch: null operand");
     TACO_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.taps > 0 && a.T > 0 && a.batch > 0 && a.M % a.T == 0, "gemm_tn_batch: bad dims");
+    if (gemm_tn2_eligible(a)) {   // second-generation kernel: all eligible problems of the group share ONE grid
+      big[nbig++] = a;
+      big_flops += 2.0 * a.M * a.N * a.K * a.taps;
+      continue;
+    }
     dim3 grid;
     GemmTnArgs probe = a;
     const int bm = plan_gemm_tn(probe, false, grid);
@@ -628,6 +698,12 @@ int launch_gemm_tn_batch(GemmTnBatch& b, hipStream_t stream) {
     grouped.gx[j] = (int)grid.x;
     grouped.gy[j] = (int)grid.y;
     blocks += (int)(grid.x * grid.y * grid.z);
+  }
+  if (nbig > 0) {
+    const int pslot = taco_prof_begin(2, stream);
+    TACO_TRY(launch_gemm_tn2(big, nbig, stream));
+    taco_prof_end(2, pslot, stream, big_flops);
+    TACO_LAUNCH_CHECK("gemm_tn2 batch");
   }
   if (grouped.n > 0) {
     double flops = 0;

@@ -17,6 +17,7 @@
 //   * the interleaved column map makes the epilogue a float4 store per (row, lane): 512 contiguous bytes per row.
 //   * grouped launch: every (problem, m-tile, n-tile) of a batch is one workgroup of ONE grid, longest problems first.
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 #include "kernels.h"
@@ -32,6 +33,47 @@ __device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
 template <int N>
 __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_lgkm() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+// LDS fragment read the compiler's waitcnt pass does not see (it would wait lgkmcnt(0) right in front of the first use, i.e.
+// expose the whole LDS latency every few MFMAs): the kernel counts its own lgkmcnt.  There is NO scalar-memory load inside
+// the k-loop (everything is hoisted into registers first), so lgkmcnt counts exactly these reads, in issue order.
+template <int OFF>
+__device__ __forceinline__ f32x4 dsr128(uint32_t addr) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+__device__ __forceinline__ uint32_t lds_off(const float* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
+}
+
+// Issue order of the fragment reads of one k-tile (S = 4 NP steps, step s = (p, c) = (s / 4, s % 4)):
+//   prologue  a(0) b(0) b(1);   after the MFMAs of step s:  b(s + 2)  [s + 2 < S],  then a(s / 4 + 1)  [s % 4 == 1, next p exists]
+// wait_count(s) = reads issued before step s's MFMAs that are YOUNGER than the youngest read step s needs.
+constexpr int rd_n(int u, int S, int NP) { return (u + 2 < S ? 1 : 0) + ((u % 4 == 1 && u / 4 + 1 < NP) ? 1 : 0); }
+constexpr int rd_before(int s, int S, int NP) {
+  int n = 3;
+  for (int u = 0; u < s; ++u) n += rd_n(u, S, NP);
+  return n;
+}
+constexpr int rd_ord_b(int j, int S, int NP) { return j == 0 ? 2 : (j == 1 ? 3 : rd_before(j - 2, S, NP) + 1); }
+constexpr int rd_ord_a(int p, int S, int NP) { return p == 0 ? 1 : rd_before(4 * p - 3, S, NP) + (4 * p - 1 < S ? 1 : 0) + 1; }
+constexpr int rd_wait(int s, int S, int NP) {
+  const int b = rd_ord_b(s, S, NP), a = rd_ord_a(s / 4, S, NP);
+  return rd_before(s, S, NP) - (a > b ? a : b);
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
 }
 
 constexpr int TM = 128, TN = 128;
@@ -83,8 +125,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
   const int b_r0 = wave * B_INSTR * 2 + (lane >> 5);
   const float* b_ptr = P.W + (int64_t)b_r0 * ldw + (b_ok ? b_c : 0);
 
-  const int ktiles = (K + BK - 1) / BK;
-  const int nit = P.taps * ktiles;
+  // k-tiles per tap, counted so that a tap always spans whole 32-deep units (a k-split chunk [it0, it1) is given in those
+  // units whatever BK is; with BK = 16 an odd tail tile is all-masked zeros)
+  const int ktiles = ((K + 31) / 32) * (32 / BK);
+  const int it_begin = P.it0 * (32 / BK), it_end = (P.it1 > 0 ? P.it1 * (32 / BK) : P.taps * ktiles);
+  const int nit = it_end - it_begin;
   const int pad_l = P.pad_l;
   // the zero word's address, kept in a VGPR pair (opaque to the optimiser: otherwise it is re-fetched from the GOT with an
   // s_load + s_waitcnt lgkmcnt(0) in front of every DMA instruction, and lgkmcnt also counts the LDS fragment reads)
@@ -92,27 +137,30 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
   asm volatile("" : "+v"(zero));
 
   // next tile to issue: (tap, k0) advance incrementally (no division on the loop path)
-  int n_tap = 0, n_k0 = 0;
-  auto issue = [&](int stage) {
+  int n_tap = it_begin / ktiles, n_k0 = (it_begin - n_tap * ktiles) * BK;
+  // one DMA instruction of the next tile (g < A_INSTR: A rows, else B rows) -- interleaved between the MFMA groups below
+  // (the lane select is written as mask arithmetic so that it stays ONE basic block: a branch around the address computation
+  //  would stop the scheduler from spreading these instructions over the MFMA shadows of the surrounding step)
+  auto pick = [&](const float* p, bool ok) {
+    const uint64_t m = ok ? ~0ull : 0ull;
+    return reinterpret_cast<const float*>((reinterpret_cast<uint64_t>(p) & m) | (reinterpret_cast<uint64_t>(zero) & ~m));
+  };
+  auto issue_piece = [&](int g, int stage) {
     const int sh = n_tap - pad_l;
     const int k0 = n_k0;
     float* As = smem + stage * STAGE;
-    float* Bs = As + A_FLOATS;
-#pragma unroll
-    for (int i = 0; i < A_INSTR; ++i) {
-      const bool ok = (unsigned)(a_t[i] + sh) < (unsigned)T && k0 + a_k[i] < K;
-      const float* src = ok ? a_ptr[i] + ((int64_t)sh * lda + k0) : zero;
-      glds16(src, As + (wave * A_INSTR + i) * A_RPI * BK);
-    }
-    const float* wt = b_ptr + ((int64_t)n_tap * K + k0) * ldw;
-#pragma unroll
-    for (int i = 0; i < B_INSTR; ++i) {
+    if (g < A_INSTR) {
+      const bool ok = (unsigned)(a_t[g] + sh) < (unsigned)T && k0 + a_k[g] < K;
+      glds16(pick(a_ptr[g] + ((int64_t)sh * lda + k0), ok), As + (wave * A_INSTR + g) * A_RPI * BK);
+    } else {
+      const int i = g - A_INSTR;
       const bool ok = b_ok && k0 + b_r0 + 2 * i < K;
-      const float* src = ok ? wt + (int64_t)(2 * i) * ldw : zero;
-      glds16(src, Bs + (wave * B_INSTR + i) * 2 * TN);
+      glds16(pick(b_ptr + (((int64_t)n_tap * K + k0 + 2 * i) * ldw), ok), As + A_FLOATS + (wave * B_INSTR + i) * 2 * TN);
     }
+  };
+  auto advance = [&]() {
     n_k0 += BK;
-    if (n_k0 >= K) {
+    if (n_k0 >= ktiles * BK) {
       n_k0 = 0;
       ++n_tap;
     }
@@ -127,50 +175,72 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
   const int li = lane & 31, kh = lane >> 5;
   const int arow = wave * 32 + li;
   const int aswz = (arow >> SWZ_SH) & (SLOTS - 1);
-
-  // 64 MFMAs per 32-deep tile; the LDS fragments are requested TWO (p, c) steps ahead of the MFMAs that consume them, so a
-  // read has four 64-cycle MFMAs to land and the wait in front of a step is a counted lgkmcnt, not lgkmcnt(0)
-  auto compute = [&](int stage) {
-    const float* As = smem + stage * STAGE + arow * BK;
-    const float* Bs = smem + stage * STAGE + A_FLOATS + 4 * li;
-    constexpr int NP = BK / 8;
-    f32x4 a4[2], b4[3];
-    auto lda4 = [&](int p) { return *reinterpret_cast<const f32x4*>(As + 4 * ((2 * p + kh) ^ aswz)); };
-    auto ldb4 = [&](int idx) { return *reinterpret_cast<const f32x4*>(Bs + (8 * (idx >> 2) + 4 * kh + (idx & 3)) * TN); };
-    a4[0] = lda4(0);
-    b4[0] = ldb4(0);
-    b4[1] = ldb4(1);
+  constexpr int NP = BK / 8, NSTEP = NP * 4;
+  // per-lane LDS byte offsets inside a stage: A slot of step p (swizzled), B row base
+  uint32_t a_off[NP];
 #pragma unroll
-    for (int idx = 0; idx < NP * 4; ++idx) {
-      const int p = idx >> 2, c = idx & 3;
-      // fragments of step idx + 2 (B) / of the next p (A, two steps before its first use) are requested now
-      if (idx + 2 < NP * 4) b4[(idx + 2) % 3] = ldb4(idx + 2);
-      if (c == 2 && p + 1 < NP) a4[(p + 1) & 1] = lda4(p + 1);
-      // (pinned: the machine scheduler otherwise sinks each read back in front of its first use and waits lgkmcnt(0) there)
+  for (int p = 0; p < NP; ++p) a_off[p] = (uint32_t)(arow * BK + 4 * ((2 * p + kh) ^ aswz)) * 4u;
+  const uint32_t b_off = (uint32_t)(A_FLOATS + 4 * kh * TN + 4 * li) * 4u;
+  const uint32_t lds0 = lds_off(smem);
+
+  // 4 NP steps of four MFMAs per tile.  Fragments are requested two steps (B) / three steps (A) ahead with counted
+  // lgkmcnt waits; one DMA instruction of the tile after next is issued in the shadow of each of the first NLD MFMA groups.
+  auto compute = [&](int stage, int fill_stage, auto fill_c) {
+    constexpr bool fill = decltype(fill_c)::value;
+    const uint32_t sb = lds0 + (uint32_t)stage * (STAGE * 4u);
+    const uint32_t bb = sb + b_off;
+    f32x4 a4[2], b4[3];
+    a4[0] = dsr128<0>(sb + a_off[0]);
+    b4[0] = dsr128<0>(bb);
+    b4[1] = dsr128<TN * 4>(bb);
+    static_for<0, NSTEP>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      constexpr int p = s >> 2, c = s & 3;
+      wait_lgkm<rd_wait(s, NSTEP, NP)>();
       __builtin_amdgcn_sched_barrier(0);
       const float av = a4[p & 1][c];
-      const f32x4 bv = b4[idx % 3];
+      const f32x4 bv = b4[s % 3];
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[0], acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[1], acc[1], 0, 0, 0);
       acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[2], acc[2], 0, 0, 0);
       acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[3], acc[3], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+      // (no pin between the MFMAs and what follows: the scheduler spreads the reads and the DMA set-up over the MFMA shadows;
+      //  the only fixed point is the wait + sched_barrier at the head of the next step -- guide rule 18)
+      if (s + 2 < NSTEP) b4[(s + 2) % 3] = dsr128<(8 * ((s + 2) >> 2) + ((s + 2) & 3)) * TN * 4>(bb);
+      if (c == 1 && p + 1 < NP) a4[(p + 1) & 1] = dsr128<0>(sb + a_off[p + 1]);
+      if (s < NLD && fill) issue_piece(s, fill_stage);
+    });
   };
 
   // ---- NS-stage ring: tile t lives in stage t % NS; tiles up to t + NS - 2 are in flight while t is computed ----
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s)
-    if (s < nit) issue(s);
-  for (int it = 0; it < nit; ++it) {
+    if (s < nit) {
+#pragma unroll
+      for (int g = 0; g < NLD; ++g) issue_piece(g, s);
+      advance();
+    }
+  // Every scalar the loop body reads is consumed once HERE, so the compiler waits for the kernarg loads in front of the loop
+  // instead of inserting `s_waitcnt lgkmcnt(0)` at their first use inside it (which would also drain the fragment reads);
+  // from here on lgkmcnt counts the LDS reads below and nothing else.
+  asm volatile("" ::"s"(T), "s"(K), "s"(lda), "s"(ldw), "s"(pad_l), "s"(nit), "s"(n_tap), "s"(n_k0), "s"(ktiles));
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  int it = 0;
+  for (; it + NS - 1 < nit; ++it) {   // steady state: tile it + NS - 1 refills the stage tile it - 1 just vacated
     // this wave's share of tile `it` has landed once at most the younger tiles' DMA instructions are outstanding
-    if (nit - 1 - it >= NS - 2) wait_vm<NLD*(NS - 2)>();
-    else wait_vm<0>();
+    wait_vm<NLD*(NS - 2)>();
     __builtin_amdgcn_s_barrier();   // every wave's share has landed AND every wave has finished reading tile it - 1
     asm volatile("" ::: "memory");
-    if (it + NS - 1 < nit) issue((it + NS - 1) % NS);   // refills the stage tile it - 1 just vacated
-    compute(it % NS);
+    compute(it % NS, (it + NS - 1) % NS, std::true_type{});
+    advance();
   }
+  for (; it < nit; ++it) {            // drain: nothing left to request
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    compute(it % NS, 0, std::false_type{});
+  }
+  wait_vm<0>();   // (nothing outstanding by construction; keeps the invariant explicit before the epilogue's ordinary loads)
 
   // ---- epilogue.  C/D layout of v_mfma_f32_32x32x2: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5);
   //      sub-tile j holds columns n0 + 4 li + j, so element e of the four accumulators is one float4 of row `row` ----
@@ -232,6 +302,174 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Weight-gradient GEMM, second generation:  dW[tap][k][n] += sum_m A[row(m, tap)][k] * dY[m][n]   (tacotron.py:172)
+//
+// Same machinery as conv_gemm2_kernel with the REDUCTION running over rows: a stage holds 32 rows of A (128 k-columns each)
+// and the same 32 rows of dY (128 n-columns), both as plain row images (512 B per row, DMA-written, no swizzle needed: every
+// fragment read is a run of consecutive 8-byte words).  Wave (wm, wn) owns the 64 x 64 block of the 128 x 128 output tile;
+// one ds_read_b64 per operand feeds four MFMAs: lane (i, kh) holds A[m = 2s + kh][64 wm + 2i + {0,1}] and
+// dY[m][64 wn + 2i + {0,1}], i.e. two interleaved 32-wide sub-tiles per operand.  The row range of a problem is split over
+// `splits` workgroups that combine with fp32 atomics (as gemm.hip does); bias gradients (column sums of dY) are taken from the
+// LDS image by the k-tile-0 / tap-0 workgroups.
+struct Tn2Args {
+  GemmTnArgs p[kMaxTnBatch];
+  int first[kMaxTnBatch], gx[kMaxTnBatch], gy[kMaxTnBatch];
+  int n;
+};
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ f32x2 dsr64(uint32_t addr) {
+  f32x2 v;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(Tn2Args G) {
+  constexpr int BR = 32;                      // rows (reduction depth) per stage
+  constexpr int OP_FLOATS = BR * 128, STAGE = 2 * OP_FLOATS;
+  constexpr int NLD = 8;                      // 4 + 4 DMA instructions per wave per stage (one instruction = 2 rows)
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 stages
+
+  int pi = 0;
+  for (int i = 1; i < G.n; ++i)
+    if ((int)blockIdx.x >= G.first[i]) pi = i;
+  const GemmTnArgs& P = G.p[pi];
+  int rel = blockIdx.x - G.first[pi];
+  const int gx = G.gx[pi], gy = G.gy[pi];
+  int bz = rel / (gx * gy);
+  rel -= bz * gx * gy;
+  const int by = rel / gx, bx = rel - by * gx;
+  const int split = bz % P.splits;
+  const int tap = bz / P.splits;
+  const int k0 = bx * 128, n0 = by * 128;
+  const int K = P.K, N = P.N, T = P.T, lda = P.lda, ldy = P.ldy;
+  const int sh = tap - P.pad_l;
+  const int m_begin = split * P.chunk;
+  const int m_end = min(P.M, m_begin + P.chunk);
+  const int nit = (m_end - m_begin + BR - 1) / BR;
+  if (nit <= 0) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, kh = lane >> 5;
+  const float* zero = g_zero4;
+  asm volatile("" : "+v"(zero));
+  auto pick = [&](const float* p, bool ok) {
+    const uint64_t m = ok ? ~0ull : 0ull;
+    return reinterpret_cast<const float*>((reinterpret_cast<uint64_t>(p) & m) | (reinterpret_cast<uint64_t>(zero) & ~m));
+  };
+
+  // DMA sources: this thread serves rows (wave * 4 + i) * 2 + kh of every stage, 16-byte slot li of both operands
+  const int ka = k0 + 4 * li, na = n0 + 4 * li;
+  const bool a_ok = ka < K, y_ok = na < P.Nld;
+  const float* a_col = P.A + (a_ok ? ka : 0);
+  const float* y_col = P.Y + (y_ok ? na : 0);
+  int n_m = m_begin;   // first row of the next stage to request
+  auto issue_piece = [&](int g, int stage) {
+    float* base = smem + stage * STAGE;
+    const int i = g & 3;
+    const int m = n_m + (wave * 4 + i) * 2 + kh;
+    if (g < 4) {
+      const int st = (int)((unsigned)m % (unsigned)T) + sh;
+      const bool ok = a_ok && m < m_end && (unsigned)st < (unsigned)T;
+      glds16(pick(a_col + (int64_t)(m + sh) * lda, ok), base + (wave * 4 + i) * 2 * 128);
+    } else {
+      const bool ok = y_ok && m < m_end;
+      glds16(pick(y_col + (int64_t)m * ldy, ok), base + OP_FLOATS + (wave * 4 + i) * 2 * 128);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][jn][e] = 0.f;
+
+  const uint32_t lds0 = lds_off(smem);
+  const uint32_t a_rd = (uint32_t)(kh * 128 + 64 * wm + 2 * li) * 4u;
+  const uint32_t b_rd = (uint32_t)(OP_FLOATS + kh * 128 + 64 * wn + 2 * li) * 4u;
+  const bool do_bias = P.dbias != nullptr && bx == 0 && tap == 0;
+  float bsum = 0.f;
+
+  auto compute = [&](int stage, int fill_stage, auto fill_c) {
+    constexpr bool fill = decltype(fill_c)::value;
+    const uint32_t sb = lds0 + (uint32_t)stage * (STAGE * 4u);
+    if (do_bias) {   // column sums of this stage's dY rows (masked rows are zeros); compiler-tracked reads, drained before the asm reads
+      if (tid < 128) {
+        const float* yc = smem + stage * STAGE + OP_FLOATS + tid;
+        float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < BR; r += 2) {
+          t0 += yc[r * 128];
+          t1 += yc[(r + 1) * 128];
+        }
+        bsum += t0 + t1;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const uint32_t ab = sb + a_rd, bb = sb + b_rd;
+    f32x2 a2[3], b2[3];
+    a2[0] = dsr64<0>(ab);
+    b2[0] = dsr64<0>(bb);
+    a2[1] = dsr64<1024>(ab);
+    b2[1] = dsr64<1024>(bb);
+    static_for<0, 16>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      wait_lgkm<(s < 15 ? 2 : 0)>();   // reads of steps s + 1 (and s + 2's are not issued yet) may still be in flight
+      __builtin_amdgcn_sched_barrier(0);
+      const f32x2 av = a2[s % 3], bv = b2[s % 3];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[0], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[1], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[0], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[1], acc[1][1], 0, 0, 0);
+      if (s + 2 < 16) {
+        a2[(s + 2) % 3] = dsr64<(s + 2) * 1024>(ab);
+        b2[(s + 2) % 3] = dsr64<(s + 2) * 1024>(bb);
+      }
+      if (s < NLD && fill) issue_piece(s, fill_stage);
+    });
+  };
+
+#pragma unroll
+  for (int g = 0; g < NLD; ++g) issue_piece(g, 0);
+  n_m += BR;
+  asm volatile("" ::"s"(T), "s"(K), "s"(lda), "s"(ldy), "s"(sh), "s"(m_end), "s"(nit), "s"(n_m));
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  int it = 0;
+  for (; it + 1 < nit; ++it) {
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    compute(it & 1, (it + 1) & 1, std::true_type{});
+    n_m += BR;
+  }
+  wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  compute(it & 1, 0, std::false_type{});
+
+  // ---- epilogue: sub-tile (j, jn) element e -> row k0 + 64 wm + 2 (row_e) + j, column n0 + 64 wn + 2 li + jn ----
+  float* W = P.W + (int64_t)tap * K * P.ldw;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int k = k0 + 64 * wm + 2 * ((e & 3) + 8 * (e >> 2) + 4 * kh) + j;
+      if (k >= K) continue;
+      const int n = n0 + 64 * wn + 2 * li;
+      float* w = W + (int64_t)k * P.ldw + n;
+      if (n < N) atomicAdd(w, acc[j][0][e]);
+      if (n + 1 < N) atomicAdd(w + 1, acc[j][1][e]);
+    }
+  }
+  if (do_bias && tid < 128 && n0 + tid < N) atomicAdd(P.dbias + n0 + tid, bsum);
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 struct Variant {
@@ -261,7 +499,7 @@ int launch_variant(const Gemm2Args& g, int tiles, hipStream_t s) {
 
 int gemm2_min_tiles() {
   const char* e = getenv("TACO_GEMM2_MIN_TILES");   // 0 disables the second-generation kernel
-  return e ? atoi(e) : 96;
+  return e ? atoi(e) : 160;
 }
 
 // Returns TACO_ENOTFOUND (nothing launched) when the batch does not meet the DMA contract or is too small to fill the chip
@@ -275,9 +513,9 @@ extern "C" __attribute__((visibility("default"))) int taco_debug_gemm2_window(in
   return n;   // eligible launches seen since the last call
 }
 
-int launch_conv_gemm2(ConvGemmBatch& batch, hipStream_t stream) {
-  const int min_tiles = gemm2_min_tiles();
-  if (min_tiles <= 0) return TACO_ENOTFOUND;
+int launch_conv_gemm2(ConvGemmBatch& batch, hipStream_t stream, bool force) {
+  const int min_tiles = force ? 1 : gemm2_min_tiles();
+  if (gemm2_min_tiles() <= 0) return TACO_ENOTFOUND;
   Gemm2Args g;
   int order[kMaxGemmBatch];
   int tiles = 0;
@@ -322,4 +560,53 @@ int launch_conv_gemm2(ConvGemmBatch& batch, hipStream_t stream) {
   if (v.bk == 16 && v.ns == 3) return launch_variant<16, 3>(g, tiles, stream);
   if (v.bk == 16 && v.ns == 4) return launch_variant<16, 4>(g, tiles, stream);
   return launch_variant<32, 2>(g, tiles, stream);
+}
+
+// Grouped weight-gradient launch on gemm_tn2_kernel.  `probs` must already carry flags / splits / chunk (plan below).
+// Returns the number of problems it took (they are removed from the caller's list by index order), or a negative error.
+static void plan_tn2(GemmTnArgs& a, int& gx, int& gy, int& blocks) {
+  gx = cdiv(a.K, 128);
+  gy = cdiv(a.N, 128);
+  const int64_t tiles = (int64_t)gx * gy * a.taps;
+  int splits = (int)((640 + tiles - 1) / tiles);   // ~2.5 workgroups per CU over the whole launch group
+  const int max_splits = cdiv(a.M, 256);           // at least 8 stages of 32 rows per workgroup
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int chunk = cdiv(a.M, splits);
+  chunk = cdiv(chunk, 32) * 32;
+  splits = cdiv(a.M, chunk);
+  a.splits = splits;
+  a.chunk = chunk;
+  blocks = (int)tiles * splits;
+}
+
+bool gemm_tn2_eligible(const GemmTnArgs& a) {
+  // OPT-IN (TACO_TN2=1): measured on MI355X this kernel is correct but SLOWER than gemm.hip's gemm_tn at every model shape
+  // (e.g. post proj1 dW 207 vs 199 us, dense dW 140 vs 71 us, bank dW 70 vs 43 us): the weight gradients are split-M launches
+  // whose workgroups run only 8-12 stages before a 128 x 128 atomic epilogue, and the interleaved column map of the b64
+  // fragment reads turns that epilogue into two half-used-cache-line atomics per row.  Kept for the tuning harness.
+  static const bool on = [] { const char* e = getenv("TACO_TN2"); return e && atoi(e) != 0; }();
+  if (!on || gemm2_min_tiles() <= 0) return false;
+  if (a.batch != 1 || a.K < 96 || a.N < 96 || a.M < 512) return false;
+  if (a.lda % 4 || a.ldy % 4 || a.K % 4 || !al16(a.A) || !al16(a.Y)) return false;
+  const int nld = a.Nld > 0 ? a.Nld : (a.N % 4 == 0 ? a.N : 0);
+  return nld > 0 && nld % 4 == 0 && nld <= a.ldy;
+}
+
+int launch_gemm_tn2(const GemmTnArgs* probs, int n, hipStream_t stream) {
+  TACO_REQUIRE(n >= 1 && n <= kMaxTnBatch, "gemm_tn2: %d problems out of range", n);
+  Tn2Args g;
+  g.n = n;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    GemmTnArgs a = probs[i];
+    if (a.Nld <= 0) a.Nld = a.N;
+    int nb = 0;
+    plan_tn2(a, g.gx[i], g.gy[i], nb);
+    g.p[i] = a;
+    g.first[i] = blocks;
+    blocks += nb;
+  }
+  hipLaunchKernelGGL(gemm_tn2_kernel, dim3(blocks), dim3(256), 2 * 2 * 32 * 128 * sizeof(float), stream, g);
+  return TACO_OK;
 }

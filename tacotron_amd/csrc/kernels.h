@@ -27,6 +27,7 @@ struct ConvGemmProblem {
   int Nld = 0;         // loadable W columns (>= N, multiple of 4, <= ldw) when the storage is padded; 0 = derive from N
   int atomic_out = 0;  // C += result with fp32 atomics (C pre-zeroed by the caller); several problems may share C
   float scale_mul = 1.f;   // scale[n] is multiplied by this (BN inference: scale = gamma, scale_mul = 1/sqrt(1+eps))
+  int it0 = 0, it1 = 0;    // gemm2.hip only: restrict the (tap, 32-deep k-tile) sequence to [it0, it1) (k-split chunk); it1 = 0: all
 };
 struct ConvGemmBatch {
   ConvGemmProblem p[kMaxGemmBatch];
@@ -48,7 +49,8 @@ struct GemmTnArgs {
 int launch_conv_gemm_batch(ConvGemmBatch& batch, hipStream_t stream);
 // gemm2.hip: DMA-staged NN kernel for batches that meet the vector contract (flags == 3 on every problem) and have at least
 // TACO_GEMM2_MIN_TILES (default 96) 128 x 128 tiles; returns TACO_ENOTFOUND without launching otherwise.
-int launch_conv_gemm2(ConvGemmBatch& batch, hipStream_t stream);
+int launch_conv_gemm2(ConvGemmBatch& batch, hipStream_t stream, bool force = false);
+int gemm2_min_tiles();   // TACO_GEMM2_MIN_TILES (0 disables gemm2.hip)
 // The CBHG's highway layers as one launch (highway.hip).  Layer l: th[l] = [sigmoid(x Wt+bt) | relu(x Wh+bh)] (M,256),
 // y[l] = H*T + x*(1-T) (M,128) feeds layer l+1.
 struct HighwayStackArgs {
@@ -74,7 +76,7 @@ int launch_conv_gemm(const ConvGemmProblem& p, hipStream_t stream);
 // problems into `slabs` (taps x M x N floats) plus ONE elementwise pass that adds the slabs in tap order and applies the
 // epilogue: taps x the workgroups, results independent of scheduling (no atomics).  Falls back to launch_conv_gemm when the
 // split does not pay.
-int launch_conv_gemm_tapsplit(const ConvGemmProblem& p, float* slabs, hipStream_t stream);
+int launch_conv_gemm_tapsplit(const ConvGemmProblem& p, float* slabs, int64_t slab_floats, hipStream_t stream);
 int launch_gemm_tn(GemmTnArgs a, bool zero_first, hipStream_t stream);
 constexpr int kMaxTnBatch = 26;
 struct GemmTnBatch {
@@ -85,6 +87,9 @@ struct GemmTnBatch {
 };
 // Launches every queued problem (accumulating into W) in as few grids as possible and empties the batch.
 int launch_gemm_tn_batch(GemmTnBatch& b, hipStream_t stream);
+// gemm2.hip: second-generation weight-gradient kernel (accumulating; 128 x 128 tiles, DMA-staged 32-row stages)
+bool gemm_tn2_eligible(const GemmTnArgs& a);
+int launch_gemm_tn2(const GemmTnArgs* probs, int n, hipStream_t stream);
 int launch_gemm_naive(const ConvGemmProblem& p, hipStream_t stream);
 
 // ---------------------------------------------------------------- elementwise.hip

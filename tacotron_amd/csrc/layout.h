@@ -86,7 +86,8 @@ struct WsLayout {
   int64_t dc_wx, dc_wg0, dc_bg0, dc_wo, dc_bo, dc_wp1o, dc_bp1o;
   CbhgWs post;
   int64_t wd_pad;
-  int64_t tapsplit;   // 3 x max(M1*128, M2*256) floats: per-tap partial sums of the proj1 convolutions (conv_gemm_tapsplit)
+  int64_t tapsplit;   // 4 x max(M1*128, M2*256) floats: per-chunk partial sums of the proj1 convolutions (conv_gemm_tapsplit)
+  int64_t tapsplit_floats = 0;
   int64_t loss;  // 4 floats
   // backward
   int64_t ds2s, dout_pad, paramsT, gstash, dkeys, dvalues, ds2s_tot;

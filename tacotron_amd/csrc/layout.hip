@@ -227,7 +227,8 @@ void build_ws_layout(const TacoShape& s, bool train, const TransLayout& T, WsLay
   W.wd_pad = a.add("post.wd_pad", {2 * kCb, 1028});   // post/dense kernel re-pitched to a 16-byte-aligned leading dimension
   {
     const int64_t e1 = M1 * (int64_t)P.enc.c1, e2 = M2 * (int64_t)P.post.c1;
-    W.tapsplit = a.add("tapsplit", {3, e1 > e2 ? e1 : e2});
+    W.tapsplit = a.add("tapsplit", {4, e1 > e2 ? e1 : e2});
+    W.tapsplit_floats = 4 * (e1 > e2 ? e1 : e2);
   }
   W.loss = a.add("loss", {4 + 2 * kLossParts});   // [0..3] total / seq2seq / output; then the two terms' per-block partials
   if (train) {

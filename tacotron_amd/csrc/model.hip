@@ -77,6 +77,7 @@ inline void prof_end(int which, int slot, hipStream_t s) { taco_prof_end(which, 
 
 struct CbhgBufs {
   float *bank, *pool, *pj1pre, *pj1, *pj2pre, *res, *h[5], *hx[4], *th[4], *xg, *out, *ruc, *tapsplit = nullptr;
+  int64_t tapsplit_floats = 0;
   float *sv[4], *rowb[4], *h0, *dh0, *dsmall, *dsmall2;   // speaker sites (null without speakers)
   const float* spk_e;   // (B,16) gathered speaker embeddings
   float* dspk_e;        // (B,16) their gradient (accumulated)
@@ -143,7 +144,7 @@ int cbhg_fwd(const float* P, const CbhgP& c, const float* x, int B, int T, const
     p.A = w.pool; p.lda = KC; p.W = P + c.p1_w; p.ldw = c.c1; p.bias = P + c.p1_b; p.scale = P + c.p1_g; p.scale_mul = bn_rs; p.shift = P + c.p1_be;
     p.C = w.pj1; p.Cpre = w.pj1pre; p.ldc = c.c1; p.M = M; p.N = c.c1; p.K = KC; p.taps = 3; p.T = T; p.pad_l = 1;
     p.act = TACO_ACT_RELU;
-    TACO_TRY(launch_conv_gemm_tapsplit(p, w.tapsplit, s));
+    TACO_TRY(launch_conv_gemm_tapsplit(p, w.tapsplit, w.tapsplit_floats, s));
   }
   {
     ConvGemmProblem p;
@@ -378,6 +379,7 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
   }
   CbhgBufs eb = cbhg_bufs(ws, W.enc);
   eb.tapsplit = ws + W.tapsplit;
+  eb.tapsplit_floats = W.tapsplit_floats;
   if (PL.enc.spk) {   // speaker embedding lookup (tacotron.py:117-124)
     TACO_REQUIRE(speaker != nullptr, "num_speakers=%d but no speaker ids were given", sh.S);
     TACO_TRY(launch_embedding(P + PL.spk_embed, speaker, ws + W.spk_e, B, sh.S, s, 16));
@@ -418,6 +420,7 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
   // post-net (tacotron.py:142-152): (B,Td,80r) reinterpreted as (B, Td*r, 80)
   CbhgBufs pb = cbhg_bufs(ws, W.post);
   pb.tapsplit = ws + W.tapsplit;
+  pb.tapsplit_floats = W.tapsplit_floats;
   TACO_TRY(cbhg_fwd(P, PL.post, s2s, B, Td * r, pb, train, s));
   {
     ConvGemmProblem p = dense_problem(pb.out, 2 * kCb, ws + W.wd_pad, 1028, P + PL.post_dense.b, output, kFft, M2, kFft,
@@ -1002,6 +1005,17 @@ extern "C" int taco_conv_gemm(const float* A, int lda, const float* W, int ldw, 
   p.ldr = ldr; p.keep = keep; p.C = C; p.ldc = ldc; p.Cpre = Cpre; p.M = M; p.N = N; p.K = K; p.taps = taps; p.T = T;
   p.pad_l = pad_l; p.act = act;
   return launch_conv_gemm(p, as_stream(stream));
+}
+
+// debug / tuning aid: the tap- / k-split form of taco_conv_gemm used for the tall-skinny CBHG projections (slabs: scratch)
+extern "C" int taco_debug_conv_gemm_ksplit(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc,
+                                           int M, int N, int K, int taps, int T, int pad_l, int act, float* slabs,
+                                           int64_t slab_floats, void* stream) {
+  TACO_REQUIRE(A && W && C && slabs && M > 0 && N > 0 && K > 0 && taps > 0 && T > 0, "conv_gemm_ksplit: bad arguments");
+  ConvGemmProblem p;
+  p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.bias = bias; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.taps = taps;
+  p.T = T; p.pad_l = pad_l; p.act = act;
+  return launch_conv_gemm_tapsplit(p, slabs, slab_floats, as_stream(stream));
 }
 
 extern "C" int taco_gemm_tn(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, int M, int N, int K,

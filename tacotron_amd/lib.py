@@ -51,6 +51,7 @@ EXPORTS = {
     'taco_workspace_bytes': (C.c_int64, [_SH, _I]),
     'taco_workspace_table': (C.c_int, [_SH, _I, C.POINTER(TacoTensorInfo), _I]),
     'taco_conv_gemm': (C.c_int, [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'taco_debug_conv_gemm_ksplit': (C.c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, C.c_int64, _P]),
     'taco_gemm_tn': (C.c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'taco_debug_gemm_naive': (C.c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'taco_bigru_fwd': (C.c_int, [_P] * 12 + [_I, _I, _P]),
@@ -143,6 +144,12 @@ def conv_gemm(A, W, C_out, M, N, K, taps=1, T=None, pad_l=0, act=0, bias=None, s
     _check(_lib.taco_conv_gemm(ptr(A), lda or K, ptr(W), ldw or N, ptr(bias), ptr(scale), ptr(shift), ptr(residual),
                                ldr or N, ptr(keep), ptr(C_out), ldc or N, ptr(Cpre), M, N, K, taps, T, pad_l, act,
                                stream_ptr()), 'taco_conv_gemm')
+
+
+def conv_gemm_ksplit(A, W, C_out, M, N, K, slabs, taps=1, T=None, pad_l=0, act=0, bias=None):
+    T = M if T is None else T
+    _check(_lib.taco_debug_conv_gemm_ksplit(ptr(A), K, ptr(W), N, ptr(bias), ptr(C_out), N, M, N, K, taps, T, pad_l, act,
+                                            ptr(slabs), slabs.numel(), stream_ptr()), 'taco_debug_conv_gemm_ksplit')
 
 
 def gemm_tn(A, dY, dW, M, N, K, taps=1, T=None, pad_l=0, accumulate=False, lda=None, ldy=None, ldw=None):

@@ -377,9 +377,9 @@ def test_medium_shape_with_gemm2_forced(built_lib, variant, monkeypatch):
     monkeypatch.setenv('TACO_GEMM2_MIN_TILES', '1')
     monkeypatch.setenv('TACO_GEMM2_VARIANT', variant)
     # Gradient tolerance = the stated 1e-3, not the 2e-4 the other tests happen to meet: with this kernel's k
-    # summation order ONE highway ReLU pre-activation of row 0 (|x| ~ 1e-7) lands on the other side of zero than in the fp64
-    # oracle, which moves the encoder pre_net / embedding gradients of rows 0-2 by 2.3e-4 (bisected with
-    # tools/v2_bisect.py / v2_flip.py: every launch alone is within 5e-7 of the other kernel; forward tensors within 1e-6).
+    # summation order the encoder pre_net / embedding gradients of rows 0-2 once moved by 2.3e-4 against the fp64 oracle
+    # although every launch alone was within 5e-7 of the other kernel and all forward tensors within 1e-6 (bisected with
+    # tools/v2_bisect.py / v2_flip.py) -- rounding-level sensitivity of the 12-step BPTT at this seed, not a kernel defect.
     test_medium_shape_forward_backward(built_lib, grad_tol=1e-3)
     test_backward_without_masks_and_ragged_lengths(built_lib)
 

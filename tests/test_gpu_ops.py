@@ -118,6 +118,27 @@ def test_conv_gemm_v2(built_lib, case, variant, monkeypatch):
     test_conv_gemm(built_lib, case)
 
 
+@pytest.mark.parametrize('case', [(1000, 200, 128, 2048, 3, 1, 1), (520, 130, 256, 1024, 3, 1, 0), (300, 300, 132, 516, 1, 0, 3)],
+                         ids=['enc-proj1-like', 'post-proj1-like', 'ragged'])
+def test_conv_gemm_ksplit(built_lib, case):
+    """Tall-skinny projections: (tap, k) chunks as independent workgroups of the gemm2 kernel + ordered slab sum; twice, to
+    pin run-to-run bit reproducibility (no atomics anywhere on this path)."""
+    M, T, N, K, taps, pad_l, act = case
+    rng = np.random.default_rng(7)
+    A = rng.standard_normal((M, K))
+    W = rng.standard_normal((taps, K, N)) / np.sqrt(K * taps)
+    bias = rng.standard_normal(N)
+    slabs = torch.empty(4 * M * N, device='cuda')
+    outs = []
+    for _ in range(2):
+        C = torch.full((M, N), float('nan'), device='cuda')
+        built_lib.conv_gemm_ksplit(dev(A), dev(W), C, M, N, K, slabs, taps=taps, T=T, pad_l=pad_l, act=act, bias=dev(bias))
+        outs.append(C.clone())
+    ref, _ = conv_ref(A, W, bias, T, pad_l, act)
+    assert report('conv_gemm_ksplit %s' % (case,), outs[0].cpu().numpy(), ref)[0] < 5e-6
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_conv_gemm_strided_unaligned(built_lib):
     """lda not a multiple of 4 (1025-wide rows) exercises the scalar-load path; ldc > N exercises column offsets."""
     rng = np.random.default_rng(5)
@@ -133,11 +154,15 @@ def test_conv_gemm_strided_unaligned(built_lib):
 
 
 TN_CASES = [(128, 128, 128, 128, 1, 0), (360, 36, 80, 128, 3, 1), (5760, 180, 256, 512, 1, 1), (400, 40, 128, 128, 1, -1),
-            (90, 9, 128, 128, 16, 7), (512, 512, 1025, 256, 1, 0), (77, 77, 20, 36, 1, 0)]
+            (90, 9, 128, 128, 16, 7), (512, 512, 1025, 256, 1, 0), (77, 77, 20, 36, 1, 0),
+            # second-generation kernel (gemm2.hip gemm_tn2: M >= 512, K, N >= 96, vector contract)
+            (1600, 200, 128, 128, 16, 7), (1200, 40, 132, 260, 3, 1), (1440, 360, 256, 1024, 3, 1), (2000, 2000, 100, 96, 1, 0),
+            (640, 20, 128, 128, 8, 4)]
 
 
 @pytest.mark.parametrize('case', TN_CASES, ids=[str(c) for c in TN_CASES])
 def test_gemm_tn(built_lib, case):
+    """(the opt-in gemm_tn2 kernel is read from TACO_TN2 once per process: run this file with TACO_TN2=1 to cover it)"""
     M, T, N, K, taps, pad_l = case
     rng = np.random.default_rng(hash(case) % 2**31)
     A = rng.standard_normal((M, K))

@@ -25,9 +25,10 @@ NN = [  # name, M, T, N, K, taps
     ('enc prenet', 6400, 6400, 256, 256, 1),
     ('square 4096', 4096, 4096, 4096, 4096, 1),
 ]
-VARS = [('old', {'TACO_GEMM2_MIN_TILES': '0'}), ('32x2', None), ('32x3', None), ('16x3', None), ('16x4', None)]
+VARS = [('old', {'TACO_GEMM2_MIN_TILES': '0'}), ('32x2', None), ('32x3', None), ('16x3', None), ('ksplit', None)]
 for name, M, T, N, K, taps in NN:
     A = torch.randn(M, K, device='cuda'); W = torch.randn(taps, K, N, device='cuda') * 0.05; C = torch.empty(M, N, device='cuda')
+    slabs = torch.empty(4 * max(6400 * 128, 11520 * 256), device='cuda')
     gf = 2.0 * M * N * K * taps / 1e9
     best = {v: 1e30 for v, _ in VARS}
     for rnd in range(3):
@@ -35,6 +36,23 @@ for name, M, T, N, K, taps in NN:
             if env: os.environ.update(env)
             else:
                 os.environ['TACO_GEMM2_MIN_TILES'] = '1'; os.environ['TACO_GEMM2_VARIANT'] = v
-            us = timeit(lambda: lib.conv_gemm(A, W, C, M, N, K, taps=taps, T=T, pad_l=(taps - 1) // 2, act=1))
+            if v == 'ksplit':
+                os.environ['TACO_GEMM2_VARIANT'] = '32x2'
+                us = timeit(lambda: lib.conv_gemm_ksplit(A, W, C, M, N, K, slabs, taps=taps, T=T, pad_l=(taps - 1) // 2, act=1))
+            else:
+                us = timeit(lambda: lib.conv_gemm(A, W, C, M, N, K, taps=taps, T=T, pad_l=(taps - 1) // 2, act=1))
             best[v] = min(best[v], us)
     print('NN %-18s M=%5d N=%4d K=%4d taps=%2d  ' % (name, M, N, K, taps) + '  '.join('%s %7.1f us %5.1f TF' % (v, best[v], gf / (best[v] * 1e-6) / 1e3) for v, _ in VARS), flush=True)
+
+TN = [('enc proj1 dW', 6400, 200, 128, 2048, 3), ('post proj1 dW', 11520, 360, 256, 1024, 3), ('dec gru gates dW', 5760, 180, 512, 256, 1),
+      ('bank k=16 dW', 6400, 200, 128, 128, 16), ('highway dW', 6400, 6400, 128, 128, 1), ('post dense dW(1024)', 11520, 11520, 1024, 256, 1)]
+for name, M, T, N, K, taps in TN:
+    A = torch.randn(M, K, device='cuda'); Y = torch.randn(M, N, device='cuda'); dW = torch.zeros(taps, K, N, device='cuda')
+    gf = 2.0 * M * N * K * taps / 1e9
+    best = {}
+    for rnd in range(3):
+        for v, mt in (('old', '0'), ('tn2', '160')):
+            os.environ['TACO_GEMM2_MIN_TILES'] = mt
+            us = timeit(lambda: lib.gemm_tn(A, Y, dW, M, N, K, taps=taps, T=T, pad_l=(taps - 1) // 2, accumulate=True))
+            best[v] = min(best.get(v, 1e30), us)
+    print('TN %-18s M=%5d N=%4d K=%4d taps=%2d  ' % (name, M, N, K, taps) + '  '.join('%s %7.1f us %5.1f TF' % (v, best[v], gf / (best[v] * 1e-6) / 1e3) for v in best), flush=True)
