@@ -44,6 +44,7 @@ struct Xchg {
   int* dead;        // LDS: set once this workgroup has given up polling
   long long* trace; // optional: 4 wall_clock64 stamps per phase (enabled for one workgroup at one step), else null
   int tslot;
+  int fake;         // TIMING PROBE ONLY (TACO_DEC_FAKEW=1): every weight row aliases row 0 (L1 hits), results are garbage
 };
 
 // stamp k (0 entry, 1 partials done, 2 own slice published, 3 gather done) of the current phase
@@ -57,6 +58,7 @@ __device__ __forceinline__ void xput(const Xchg& X, int idx, float v) {
 }
 __device__ __forceinline__ float xget(const Xchg& X, int idx) {
   if (*X.dead) return 0.f;
+  if (X.fake & 2) return 0.f;   // timing probe: no polling at all
   gu64* g = (gu64*)(X.base + idx);
   for (unsigned spin = 0;; ++spin) {
     const u64 x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -85,6 +87,7 @@ __device__ __forceinline__ void tmark(const Xchg& X, int id) {
 __device__ __forceinline__ void xget2(const Xchg& X, int idxA, bool needA, int idxB, bool needB, float& vA, float& vB) {
   vA = vB = 0.f;
   if (*X.dead) return;
+  if (X.fake & 2) return;
   gu64* gA = (gu64*)(X.base + idxA);
   gu64* gB = (gu64*)(X.base + idxB);
   for (unsigned spin = 0; needA || needB; ++spin) {
@@ -164,7 +167,7 @@ __device__ __forceinline__ void prefetch_w(Pref& pf, const float* __restrict__ W
 #pragma unroll
     for (int i = 0; i < kPF; ++i) {
       const bool ok = k0 + i < k1;
-      pf.w[i] = *reinterpret_cast<const float4*>(wp + (int64_t)(ok ? k0 + i : 0) * ldw);   // clamped address, value unused if !ok
+      pf.w[i] = *reinterpret_cast<const float4*>(wp + (int64_t)(ok && !(X.fake & 1) ? k0 + i : 0) * ldw);   // clamped address, value unused if !ok
     }
   }
 }
@@ -173,6 +176,7 @@ __device__ __forceinline__ void prefetch_w(Pref& pf, const float* __restrict__ W
 template <bool PF>
 __device__ __forceinline__ void phase_mv_impl(const float* __restrict__ W, int ldw, int K, int N, const float* x,
                                               float* part, const Xchg& X, const Pref& pf) {
+  if (X.fake & 1) ldw = 0;
   const int tid = opaque_tid();
   const Slice S = slice_of(X, N);
   const int n4 = S.n4, nloc = S.nloc;
@@ -419,6 +423,7 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
   X.epoch = 0;
   X.trace = nullptr;
   X.tslot = 0;
+  X.fake = a.fakew;
   const bool lead = X.peer == 0;
 
   int len = a.text_length[b];
@@ -825,6 +830,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
   X.epoch = 0;
   X.trace = nullptr;
   X.tslot = 0;
+  X.fake = a.fakew;
   const bool lead = X.peer == 0;
   float* const dov = S.vo;               // d cell_output (direct part)
   float* const dq = S.vo + R80;
@@ -1216,6 +1222,7 @@ int launch_decoder_fwd(DecFwdArgs a, hipStream_t s) {
   }
   a.P = pick_cluster(kern, smem, a.B, env_cluster(a.mel ? 8 : 16));
   g_last_cluster[0] = a.P;
+  a.fakew = (getenv("TACO_DEC_FAKEW") ? 1 : 0) | (getenv("TACO_DEC_FAKEX") ? 2 : 0);
   if (a.P > 1) {
     hipError_t e = hipMemsetAsync(a.xchg, 0, (size_t)decoder_xchg_bytes(a.B, a.Tt), s);
     if (e != hipSuccess) {
@@ -1245,6 +1252,7 @@ int launch_decoder_bwd(DecBwdArgs a, hipStream_t s) {
   }
   a.P = pick_cluster(kern, smem, a.B, env_cluster(8));
   g_last_cluster[1] = a.P;
+  a.fakew = (getenv("TACO_DEC_FAKEW") ? 1 : 0) | (getenv("TACO_DEC_FAKEX") ? 2 : 0);
   if (a.P > 1) {
     hipError_t e = hipMemsetAsync(a.xchg, 0, (size_t)decoder_xchg_bytes(a.B, a.Tt), s);
     if (e != hipSuccess) {

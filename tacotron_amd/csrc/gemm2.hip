@@ -554,7 +554,13 @@ int launch_conv_gemm2(ConvGemmBatch& batch, hipStream_t stream, bool force) {
     g.mt[i] = cdiv(p.M, TM);
     first += g.mt[i] * cdiv(p.N, TN);
   }
-  const Variant v = env_variant();
+  Variant v = env_variant();
+  if (!getenv("TACO_GEMM2_VARIANT")) {
+    // K = 80 (post-net conv bank: 80 mel channels) is 2.5 tiles of 32 -- the 16-deep instantiation wastes nothing there
+    bool k16 = true;
+    for (int i = 0; i < batch.n; ++i) k16 = k16 && batch.p[i].K % 32 != 0 && batch.p[i].K % 16 == 0;
+    if (k16) v = Variant{16, 3};
+  }
   if (v.bk == 32 && v.ns == 2) return launch_variant<32, 2>(g, tiles, stream);
   if (v.bk == 32 && v.ns == 3) return launch_variant<32, 3>(g, tiles, stream);
   if (v.bk == 16 && v.ns == 3) return launch_variant<16, 3>(g, tiles, stream);

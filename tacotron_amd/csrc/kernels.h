@@ -239,6 +239,7 @@ struct DecFwdArgs {
   long long* trace;      // optional (TACO_DEC_TRACE=1): per-phase wall_clock64 stamps of block 0 at step Td/2
   int B, Tt, Td, r;
   int P;                 // cluster width (workgroups per row); chosen by launch_decoder_fwd
+  int fakew = 0;         // timing probe (TACO_DEC_FAKEW): see Xchg::fake
 };
 int64_t decoder_xchg_bytes(int B, int Tt);
 int decoder_last_cluster(int which);   // cluster width (workgroups per row) of the last forward (0) / backward (1) launch
@@ -268,5 +269,6 @@ struct DecBwdArgs {
   long long* trace;      // optional per-phase stamps (see DecFwdArgs)
   int B, Tt, Td, r;
   int P;
+  int fakew = 0;
 };
 int launch_decoder_bwd(DecBwdArgs a, hipStream_t s);

@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libtaco_hip.so')
+LIB_PATH = os.environ.get('TACO_LIB') or os.path.join(_HERE, 'libtaco_hip.so')   # TACO_LIB: an alternative build (tuning A/B)
 
 
 class TacoError(RuntimeError):
