@@ -166,6 +166,17 @@ int taco_wait_grad_segment(int seg, void* stream);
 int taco_denorm_unframe(const float* output, const float* stft_mean, const float* stft_std, float* spec, float* mag_t,
                         int B, int Td, int r, int C, void* stream);
 
+/* ---- vocoder ---------------------------------------------------------------------------------------------- */
+/* audio.griffinlim (audio.py:77-97) with the reference's constants compiled in (n_fft 2048, win_length 1200, hop_length 300,
+ * periodic Hann, librosa center=True framing): n_iter rounds of istft -> stft keeping the given magnitudes, then a final istft.
+ *   mag_t  (B, 1025, F)  linear magnitudes (taco_denorm_unframe's mag_t)
+ *   phase0 (B, 1025, F)  initial phase angles in radians (the reference draws 2 pi U[0,1), audio.py:81; caller supplied here so
+ *                        that results are reproducible)
+ *   wave   (B, 300 (F - 1)) output samples
+ *   workspace: taco_griffinlim_workspace_bytes(B, F) bytes.  Hand-written 2048-point FFT, no vendor library. */
+int64_t taco_griffinlim_workspace_bytes(int B, int F);
+int taco_griffinlim(const float* mag_t, const float* phase0, float* wave, void* workspace, int B, int F, int n_iter, void* stream);
+
 /* Bernoulli(p_keep) bytes from a counter-based hash RNG (replaces TF's dropout / Bernoulli sampler state). */
 int taco_fill_bernoulli(uint8_t* out, int64_t n, float p_one, uint64_t seed, void* stream);
 

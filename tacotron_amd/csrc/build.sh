@@ -6,10 +6,10 @@ OUT=../libtaco_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -fPIC -fvisibility=hidden"
 mkdir -p ../../build/obj
 pids=()
-for f in gemm gemm2 elementwise bigru decoder highway layout model; do
+for f in gemm gemm2 vocoder elementwise bigru decoder highway layout model; do
   hipcc $FLAGS -c $f.hip -o ../../build/obj/$f.o &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT ../../build/obj/{gemm,gemm2,elementwise,bigru,decoder,highway,layout,model}.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT ../../build/obj/{gemm,gemm2,vocoder,elementwise,bigru,decoder,highway,layout,model}.o
 echo "built $(realpath $OUT)"

@@ -272,3 +272,8 @@ struct DecBwdArgs {
   int fakew = 0;
 };
 int launch_decoder_bwd(DecBwdArgs a, hipStream_t s);
+
+// ---------------------------------------------------------------- vocoder.hip
+// Griffin-Lim (audio.py:77-97).  mag_t / phase0 (B, 1025, F); wave (B, 300 (F - 1)); work: griffinlim_workspace_floats floats
+int64_t griffinlim_workspace_floats(int B, int F);
+int launch_griffinlim(const float* mag_t, const float* phase0, float* wave, float* work, int B, int F, int n_iter, hipStream_t s);

@@ -1089,6 +1089,16 @@ extern "C" int taco_denorm_unframe(const float* output, const float* stft_mean, 
   return launch_denorm_unframe(output, stft_mean, stft_std, spec, mag_t, B, Td, r, C, as_stream(stream));
 }
 
+extern "C" int64_t taco_griffinlim_workspace_bytes(int B, int F) {
+  if (B <= 0 || F < 2) return TACO_EINVAL;
+  return griffinlim_workspace_floats(B, F) * (int64_t)sizeof(float);
+}
+
+extern "C" int taco_griffinlim(const float* mag_t, const float* phase0, float* wave, void* workspace, int B, int F, int n_iter,
+                               void* stream) {
+  return launch_griffinlim(mag_t, phase0, wave, static_cast<float*>(workspace), B, F, n_iter, as_stream(stream));
+}
+
 extern "C" int taco_fill_bernoulli(uint8_t* out, int64_t n, float p_one, uint64_t seed, void* stream) {
   TACO_REQUIRE(out && n > 0, "fill_bernoulli: bad arguments");
   return launch_bernoulli(out, n, p_one, seed, as_stream(stream));

@@ -64,6 +64,8 @@ EXPORTS = {
     'taco_grad_segments': (C.c_int, [_SH, C.POINTER(C.c_int64)]),
     'taco_wait_grad_segment': (C.c_int, [_I, _P]),
     'taco_denorm_unframe': (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'taco_griffinlim_workspace_bytes': (C.c_int64, [_I, _I]),
+    'taco_griffinlim': (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
     'taco_fill_bernoulli': (C.c_int, [_P, C.c_int64, C.c_float, C.c_uint64, _P]),
     'taco_profile_enable': (C.c_int, [_I]),
     'taco_debug_last_cluster': (C.c_int, [_I]),
@@ -233,6 +235,20 @@ def denorm_unframe(output, stft_mean, stft_std, r, want_spec=True, want_mag_t=Fa
     if want_spec and want_mag_t:
         return spec, mag_t
     return spec if want_spec else mag_t
+
+
+def griffinlim(mag_t, phase0, n_iter=50):
+    """mag_t, phase0 (B, 1025, F) -> waveform (B, 300 (F - 1)); audio.griffinlim on the GPU."""
+    B, Cb, F = mag_t.shape
+    assert Cb == 1025 and phase0.shape == mag_t.shape
+    nbytes = _lib.taco_griffinlim_workspace_bytes(B, F)
+    if nbytes < 0:
+        raise TacoError('taco_griffinlim_workspace_bytes: bad shape')
+    work = torch.empty(nbytes // 4, device=mag_t.device)
+    wave = torch.empty(B, 300 * (F - 1), device=mag_t.device)
+    _check(_lib.taco_griffinlim(ptr(mag_t), ptr(phase0), ptr(wave), ptr(work), B, F, int(n_iter), stream_ptr()),
+           'taco_griffinlim')
+    return wave
 
 
 def fill_bernoulli(out, p_one, seed):

@@ -361,7 +361,11 @@ def test_full_size_properties(built_lib):
         Rh.set(p, {k: v[sl] for k, v in inp.items()}, mh)
         Rh.forward()
         Rh.backward()
-        assert torch.equal(Rh.s2s, s2s0[sl])       # rows are independent: bit-identical outputs
+        # rows are independent.  (Round 1 pinned this bitwise; since round 2 the GEMM dispatcher picks kernels and k-split
+        # factors by tile count, i.e. by batch size, so the summation order -- not the result -- may differ between B = 16 and 32.)
+        dh = float((Rh.s2s - s2s0[sl]).abs().max())
+        print('  rows of a B=16 run vs the same rows of the B=32 run: max|d s2s| = %.2e (bitwise: %s)' % (dh, dh == 0.0))
+        assert dh <= 2e-6 * float(s2s0.abs().max())
         halves.append(Rh.grads.clone())
         del Rh
     gsum = halves[0] + halves[1]

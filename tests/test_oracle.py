@@ -153,3 +153,32 @@ def test_clip_adam_restatements_agree():
     for k in p:
         assert np.abs(p[k] - pt[k].numpy()).max() < 1e-12
     assert gn > 5  # the clip branch was exercised
+
+
+def test_griffinlim_oracle_stft_istft_are_consistent():
+    """oracle/griffinlim_numpy.py (librosa's algorithm restated; librosa itself is absent): istft inverts stft, stft agrees with
+    scipy.signal.stft under matching conventions and with a hand-written DFT, Griffin-Lim reduces the spectral error."""
+    import scipy.signal
+    from oracle import griffinlim_numpy as gl
+    rng = np.random.default_rng(0)
+    y = rng.standard_normal(300 * 11)
+    S = gl.stft(y)
+    assert S.shape == (1025, 12)
+    back = gl.istft(S)
+    assert back.shape == y.shape and np.abs(back - y).max() < 1e-10          # exact inverse (window sum-of-squares normalisation)
+    # independent implementation: scipy's STFT with the same window image, hop, reflect ('even') boundary, no scaling
+    w = gl.pad_center(gl.hann_periodic())
+    _, _, Z = scipy.signal.stft(y, window=w, nperseg=2048, noverlap=2048 - 300, nfft=2048, boundary='even', padded=False,
+                                return_onesided=True, scaling='spectrum')
+    Z = Z * w.sum()                                                          # undo scipy's 'spectrum' scaling
+    assert Z.shape[1] >= 12 and np.abs(Z[:, :12] - S).max() < 1e-9 * np.abs(S).max()
+    # one bin by hand
+    yp = np.pad(y, 1024, mode='reflect')
+    k, t = 37, 5
+    n = np.arange(2048)
+    assert abs(np.sum(w * yp[t * 300:t * 300 + 2048] * np.exp(-2j * np.pi * k * n / 2048)) - S[k, t]) < 1e-9
+    mag = np.abs(S)
+    ph = 2 * np.pi * rng.random(mag.shape)
+    e0 = gl.spectral_convergence(gl.griffinlim(mag, ph, 0), mag)
+    e20 = gl.spectral_convergence(gl.griffinlim(mag, ph, 20), mag)
+    assert e20 < 0.6 * e0
