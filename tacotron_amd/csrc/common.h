@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/taco_hip.h"
 
@@ -101,3 +102,11 @@ __device__ __forceinline__ float apply_act(float x, int act) {
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// TACO_DETERMINISTIC=1: every reduction that is otherwise combined with fp32 atomics (split-M weight gradients, the K-way conv
+// bank input gradient, BN / bias column sums, the embedding scatter) runs in a fixed order instead -- slower, but two runs of
+// the same step give bit-identical gradients (needed to bisect a training divergence).  Read on every call.
+static inline bool taco_deterministic() {
+  const char* e = getenv("TACO_DETERMINISTIC");
+  return e && atoi(e) != 0;
+}

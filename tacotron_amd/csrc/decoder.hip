@@ -1160,7 +1160,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
   if (tid < un) {
     float dsum = 0.f;
     for (int g = 0; g < NSG; ++g) dsum += S.red[g * un + tid];
-    atomicAdd(&a.datt_v[ub + tid], dsum);
+    a.datt_v[(int64_t)b * kAtt + ub + tid] = dsum;   // per-row partial (each (row, unit) has one owner); rows are summed in order afterwards
   }
 }
 

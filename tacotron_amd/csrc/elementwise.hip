@@ -53,6 +53,21 @@ __global__ void embedding_bwd_kernel(const float* __restrict__ dout, const int32
   }
 }
 
+// deterministic variant: thread (vocabulary row v, column c) walks the rows in order and adds the matching ones
+__global__ void embedding_bwd_ordered_kernel(const float* __restrict__ dout, const int32_t* __restrict__ ids,
+                                             float* __restrict__ dtable, int64_t rows, int V, int width) {
+  const int v = blockIdx.x;
+  for (int c = threadIdx.x; c < width; c += blockDim.x) {
+    float acc = 0.f;
+    for (int64_t r = 0; r < rows; ++r) {
+      int id = ids[r];
+      id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+      if (id == v) acc += dout[r * width + c];
+    }
+    dtable[(int64_t)v * width + c] += acc;
+  }
+}
+
 __global__ void bn_maxpool_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                   const float* __restrict__ beta, float* __restrict__ y, int B, int T, int C) {
   const int C4 = C / 4;
@@ -426,6 +441,11 @@ int launch_embedding(const float* table, const int32_t* ids, float* out, int64_t
   return TACO_OK;
 }
 int launch_embedding_bwd(const float* dout, const int32_t* ids, float* dtable, int64_t rows, int V, hipStream_t s, int width) {
+  if (taco_deterministic()) {
+    hipLaunchKernelGGL(embedding_bwd_ordered_kernel, dim3(V), dim3(width < 256 ? 64 : 256), 0, s, dout, ids, dtable, rows, V, width);
+    TACO_LAUNCH_CHECK("embedding_bwd_ordered");
+    return TACO_OK;
+  }
   EW_LAUNCH(embedding_bwd_kernel, rows * width, s, dout, ids, dtable, rows, V, width);
   return TACO_OK;
 }
@@ -442,6 +462,7 @@ int launch_bn_maxpool(const float* x, const float* gamma, const float* beta, flo
 static inline void col_grid(int64_t M, int N, dim3& grid, int& rpb) {
   int chunks = (int)((M + 31) / 32);   // 8 rows per thread: enough blocks to cover 256 CUs even for 128-column tensors
   if (chunks > 2048) chunks = 2048;
+  if (taco_deterministic()) chunks = 1;   // one workgroup per column range sums all rows in a fixed order: a single atomicAdd each
   if (chunks < 1) chunks = 1;
   rpb = (int)((M + chunks - 1) / chunks);
   grid = dim3((N + 63) / 64, (unsigned)((M + rpb - 1) / rpb));

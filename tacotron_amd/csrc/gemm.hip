@@ -399,21 +399,21 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTnArgs& P, const int bx, 
     }
   }
   if (do_bias) {
-    // column sums of this block's Y rows: reduce the per-thread partials through LDS (As is free after the last barrier)
+    // column sums of this block's Y rows: per-thread partials -> LDS rows (As is free after the last barrier) -> summed in row
+    // order (no LDS atomics: the order of the adds is fixed)
     float* cs = &As[0][0][0];
-    for (int i = tid; i < BN; i += 256) cs[i] = 0.f;
-    __syncthreads();
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int i = 0; i < B_PER; ++i) {
-      atomicAdd(&cs[b_c4 * 4 + 0], bsum[i].x);
-      atomicAdd(&cs[b_c4 * 4 + 1], bsum[i].y);
-      atomicAdd(&cs[b_c4 * 4 + 2], bsum[i].z);
-      atomicAdd(&cs[b_c4 * 4 + 3], bsum[i].w);
-    }
+    for (int i = 0; i < B_PER; ++i) { t.x += bsum[i].x; t.y += bsum[i].y; t.z += bsum[i].z; t.w += bsum[i].w; }
+    __syncthreads();
+    *reinterpret_cast<float4*>(&cs[b_r * LDS_B + b_c4 * 4]) = t;   // B_RSTEP (8 or 16) rows of BN partial sums
     __syncthreads();
     float* db = P.dbias + (int64_t)bz * P.N;
-    for (int i = tid; i < BN; i += 256)
-      if (n0 + i < P.N) atomicAdd(&db[n0 + i], cs[i]);
+    for (int i = tid; i < BN; i += 256) {
+      float c = 0.f;
+      for (int r = 0; r < B_RSTEP; ++r) c += cs[r * LDS_B + i];
+      if (n0 + i < P.N) atomicAdd(&db[n0 + i], c);   // one contribution per launch in deterministic mode (splits == 1)
+    }
   }
 }
 
@@ -621,7 +621,7 @@ static int plan_gemm_tn(GemmTnArgs& a, bool force_small, dim3& grid) {
   const bool big = !force_small && (int64_t)cdiv(a.K, 128) * cdiv(a.N, 128) * a.taps * a.batch >= 128 && a.K >= 128 && a.N >= 128;
   const int bm = big ? 128 : 64;
   const int64_t tiles = (int64_t)cdiv(a.K, bm) * cdiv(a.N, bm) * a.taps * a.batch;
-  int splits = (int)((768 + tiles - 1) / tiles);
+  int splits = taco_deterministic() ? 1 : (int)((768 + tiles - 1) / tiles);   // deterministic: one workgroup owns the whole row range
   const int max_splits = cdiv(a.M, 64);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;

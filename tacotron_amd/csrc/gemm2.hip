@@ -592,7 +592,7 @@ bool gemm_tn2_eligible(const GemmTnArgs& a) {
   // whose workgroups run only 8-12 stages before a 128 x 128 atomic epilogue, and the interleaved column map of the b64
   // fragment reads turns that epilogue into two half-used-cache-line atomics per row.  Kept for the tuning harness.
   static const bool on = [] { const char* e = getenv("TACO_TN2"); return e && atoi(e) != 0; }();
-  if (!on || gemm2_min_tiles() <= 0) return false;
+  if (!on || gemm2_min_tiles() <= 0 || taco_deterministic()) return false;
   if (a.batch != 1 || a.K < 96 || a.N < 96 || a.M < 512) return false;
   if (a.lda % 4 || a.ldy % 4 || a.K % 4 || !al16(a.A) || !al16(a.Y)) return false;
   const int nld = a.Nld > 0 ? a.Nld : (a.N % 4 == 0 ? a.N : 0);

@@ -263,7 +263,7 @@ struct DecBwdArgs {
   const float* stash;    // (B,Td,kStRec)
   float* gstash;         // (B,Td,kGsRec)
   float* dkeys;          // (B,Tt,256) zero-initialised, accumulated
-  float* datt_v;         // (256) accumulated (atomics)
+  float* datt_v;         // (B,256) per-row partial gradients of attention_v (written, not accumulated)
   void* xchg;
   int* err;
   long long* trace;      // optional per-phase stamps (see DecFwdArgs)

@@ -92,6 +92,7 @@ struct WsLayout {
   // backward
   int64_t ds2s, dout_pad, paramsT, gstash, dkeys, dvalues, ds2s_tot;
   int64_t bc_fa, bc_wot, bc_g, bc_h1, bc_h2, bc_cq, bc_cp;   // decoder backward composites and small weight-gradient factors
+  int64_t dattv;      // (B,256) per-row attention_v gradient partials
   int64_t gA, gB, gC, gD, gE, gF, gG, scratch;
   int64_t total = 0;  // floats
   std::vector<TacoTensorInfo> rows;

@@ -714,7 +714,17 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
       }
     }
     TACO_TRY(bank_group.flush());
-    TACO_TRY(launch_conv_gemm_batch(batch, s));
+    if (taco_deterministic()) {
+      // fixed order: the K transposed convolutions run one after the other, each adding to dx_out through the residual input
+      for (int i = c.K - 1; i >= 0; --i) {   // batch.p[K - 1] is the k = 1 problem carrying the dres residual
+        ConvGemmProblem q = batch.p[i];
+        q.atomic_out = 0;
+        if (i != c.K - 1) { q.residual = dx_out; q.ldr = c.cin; }
+        TACO_TRY(launch_conv_gemm(q, s));
+      }
+    } else {
+      TACO_TRY(launch_conv_gemm_batch(batch, s));
+    }
   }
   return TACO_OK;
 }
@@ -861,13 +871,15 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     a.keys = ws + W.keys; a.values = ws + W.values; a.text_length = text_length;
     a.keep1 = dec_keep1; a.keep2 = dec_keep2; a.sample = sample;
     a.dout = dS2S; a.out = seq2seq_output; a.align = alignments; a.stash = st; a.gstash = gs;
-    a.dkeys = ws + W.dkeys; a.datt_v = G + PL.att_v;
+    a.dkeys = ws + W.dkeys; a.datt_v = ws + W.dattv;
     a.xchg = ws + W.xchg; a.err = reinterpret_cast<int*>(ws + W.err) + 1;
     a.trace = getenv("TACO_DEC_TRACE") ? reinterpret_cast<long long*>(ws + W.err + 16) + 128 : nullptr;
     a.B = B; a.Tt = Tt; a.Td = Td; a.r = r; a.P = 1;
     const int slot = prof_begin(1, s);
     TACO_TRY(launch_decoder_bwd(a, s));
     prof_end(1, slot, s);
+    // d attention_v = sum over batch rows of the kernel's per-row partials, in row order (no atomics)
+    TACO_TRY(launch_colsum_batched(ws + W.dattv, kAtt, G + PL.att_v, 1, B, kAtt, s));
   }
   // ---- attention memory: dvalues[b] = alignments[b]^T . dctx[b] ; keys = values . Wm ----
   {

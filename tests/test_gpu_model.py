@@ -535,6 +535,37 @@ def test_s2_envelope(built_lib):
     _argmax_check(al0.cpu().numpy(), a2.numpy(), inp['text_length'])
 
 
+@pytest.mark.parametrize('full', [False, True], ids=['medium', 'S1'])
+def test_deterministic_gradient_mode(built_lib, full, monkeypatch):
+    """TACO_DETERMINISTIC=1: no fp32 atomics decide the order of any gradient sum (split-M weight gradients, K-way conv-bank
+    input gradient, BN / bias column sums, embedding scatter, attention_v) -- two runs of the same step agree bit for bit, and
+    the gradients still match the default mode to rounding."""
+    if full:
+        B, Tt, Td, r, V = 32, 200, 180, 2, 60
+        inp, masks = _full_case(B, Tt, Td, r, V)
+    else:
+        r, V, B, Tt, Td = 2, 40, 4, 37, 12
+        inp, masks = small_case(r=r, V=V, B=B, Tt=Tt, Td=Td, seed=8)
+    R = Runner(built_lib, B, Tt, Td, r, V)
+    R.pb.init_(seed=3)
+    p = R.pb.to_dict()
+    R.set(p, inp, masks)
+    R.forward()
+    R.backward()
+    g_default = R.grads.clone()
+    monkeypatch.setenv('TACO_DETERMINISTIC', '1')
+    runs = []
+    for _ in range(2):
+        R.forward()
+        R.backward()
+        runs.append((R.grads.clone(), R.loss.clone(), R.s2s.clone()))
+    assert torch.equal(runs[0][0], runs[1][0]), 'gradients differ between two deterministic runs'
+    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+    d = float((runs[0][0] - g_default).norm() / g_default.norm())
+    print('  deterministic vs default gradients: rel-L2 %.2e' % d)
+    assert d < 1e-5
+
+
 def test_model_class_train_steps_reduce_loss(built_lib):
     """Host mirror of the reference object: Tacotron(config, inputs, train).step(lr) runs and learns."""
     from tacotron_amd.config import Config

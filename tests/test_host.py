@@ -128,3 +128,46 @@ def test_latest_checkpoint_is_numeric_and_prefix_aware(tmp_path):
     (tmp_path / 'weights' / 'debug-5000').write_bytes(b'x')
     assert latest_checkpoint(str(tmp_path / 'weights' / 'debug')).endswith('debug-15000')
     assert latest_checkpoint(str(tmp_path / 'nowhere' / 'tacotron')) is None
+
+
+@pytest.mark.parametrize('S', [1, 7])
+def test_tf_checkpoint_rename_table_round_trip(built_lib, S):
+    """the TF-1.2 scope -> taco_param_table rename map is code (tacotron_amd/tf_import.py).  A synthetic
+    "checkpoint" keyed by the TF names (plus Adam slots, BN moving statistics and bookkeeping variables, as a real one has)
+    imports to exactly the parameter buffer it was made from; name mismatches are reported, not guessed."""
+    from oracle import taco_numpy as on
+    from tacotron_amd.params import ParamBuffer
+    from tacotron_amd.tf_import import check_names, import_tf_variables, tf_name_map
+    V, r = 33, 2
+    shape = built_lib.make_shape(2, 8, 4, r, V, S)
+    p = on.init_params(V, r, seed=2, perturb=0.3, num_speakers=S)
+    table = tf_name_map(S)
+    assert set(table) == set(p) and len(set(table.values())) == len(table)          # total and injective
+    assert table['encoder/cbhg/bank_16/kernel'] == 'encoder/cbhg/conv1d_15/kernel'
+    assert table['post/cbhg/proj2/kernel'] == 'post-process/cbhg/conv1d_9/kernel'
+    assert table['post/cbhg/highway_0/adapt/kernel'] == 'post-process/cbhg/highway_0/dense/kernel'
+    assert table['post/cbhg/highway_0/H/kernel'] == 'post-process/cbhg/highway_0/dense_2/kernel'
+    assert table['encoder/cbhg/highway_2/H/kernel'] == ('encoder/cbhg/highway_2/dense_%d/kernel' % (3 if S > 1 else 1))
+    rng = np.random.default_rng(0)
+    ckpt = {}
+    for n, a in p.items():
+        ckpt[table[n] + ':0'] = a.astype(np.float32)
+        ckpt[table[n] + '/Adam'] = rng.standard_normal(a.shape).astype(np.float32)
+        ckpt[table[n] + '/Adam_1'] = rng.random(a.shape).astype(np.float32)
+    ckpt['encoder/cbhg/batch_normalization/moving_mean'] = np.zeros(2048, np.float32)
+    ckpt['global_step'] = np.int64(12345)
+    ckpt['beta1_power'] = np.float32(0.5)
+    ckpt['stft_mean'] = rng.standard_normal(1025 * r).astype(np.float32)
+    ckpt['stft_std'] = rng.random(1025 * r).astype(np.float32)
+    assert check_names(ckpt.keys(), shape) == ([], [])
+    sd = import_tf_variables(ckpt, shape)
+    want = ParamBuffer(shape).load_dict_(p).flat
+    assert torch.equal(sd['params'], want) and sd['global_step'] == 12345
+    assert sd['adam_m'].shape == want.shape and torch.equal(sd['stft_mean'], torch.from_numpy(ckpt['stft_mean']))
+    # a renamed / missing variable is reported by name
+    bad = dict(ckpt)
+    bad['decoder/attention_v_renamed'] = bad.pop(table['decoder/attention_v'] + ':0')
+    missing, extra = check_names(bad.keys(), shape)
+    assert missing == [table['decoder/attention_v']] and extra == ['decoder/attention_v_renamed']
+    with pytest.raises(KeyError):
+        import_tf_variables(bad, shape)
