@@ -1,10 +1,20 @@
-export TMPDIR=/tmp; R=$PWD
-python bench.py > gpurun_out/bench_v2.json 2> gpurun_out/bench_v2.err
+# Round profile on the GPU box: bench line, rocprofv3 kernel stats + one-step timeline, PMC passes (FETCH / WRITE / MFMA), probes.
+# usage: bash tools/profile_round.sh r02   -> files under gpurun_out/<tag>_*
+TAG=${1:-r02}; export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out
+H=$(python -c "import bench; print(bench.source_hash())")
+python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 cd /tmp
-timeout 280 rocprofv3 --kernel-trace --stats -d /tmp/p1 -o r -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > /tmp/b1.log 2>&1
-timeout 200 rocprofv3 --pmc FETCH_SIZE -d /tmp/p2 -o r -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-inference > /tmp/b2.log 2>&1
-timeout 200 rocprofv3 --pmc WRITE_SIZE -d /tmp/p3 -o r -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-inference > /tmp/b3.log 2>&1
+SHORT="--no-cpu-baseline --no-inference --no-extras"
+timeout 280 rocprofv3 --kernel-trace --stats -d /tmp/p1 -o r -- python $R/bench.py --steps 20 --warmup 5 $SHORT > /tmp/b1.log 2>&1
+timeout 200 rocprofv3 --pmc FETCH_SIZE -d /tmp/p2 -o r -- python $R/bench.py --steps 2 --warmup 1 $SHORT > /tmp/b2.log 2>&1
+timeout 200 rocprofv3 --pmc WRITE_SIZE -d /tmp/p3 -o r -- python $R/bench.py --steps 2 --warmup 1 $SHORT > /tmp/b3.log 2>&1
+timeout 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES -d /tmp/p4 -o r -- python $R/bench.py --steps 2 --warmup 1 $SHORT > /tmp/b4.log 2>&1
 cd $R
-python tools/rocpd_summary.py $(find /tmp/p1 -name "*.db" | head -1) > gpurun_out/kernel_stats_v2.txt 2>&1
-python tools/pmc_to_json.py $(find /tmp/p2 -name "*.db" | head -1) $(find /tmp/p3 -name "*.db" | head -1) gpurun_out/pmc_v2.json "round-1 v2: folded decoder rounds (9 fwd / 10 bwd), cross-round weight prefetch" > /dev/null 2> gpurun_out/pmc.err
-tail -c 600 gpurun_out/bench_v2.json
+python tools/rocpd_summary.py $(find /tmp/p1 -name "*.db" | head -1) > $O/${TAG}_kernel_stats.txt 2>&1
+python tools/rocpd_timeline.py $(find /tmp/p1 -name "*.db" | head -1) 12 > $O/${TAG}_step_timeline.txt 2>&1
+python tools/pmc_to_json.py $(find /tmp/p2 -name "*.db" | head -1) $(find /tmp/p3 -name "*.db" | head -1) $O/${TAG}_pmc.json $H "round $TAG" > /dev/null 2> $O/${TAG}_pmc.err
+python tools/pmc_mfma.py $(find /tmp/p4 -name "*.db" | head -1) $H > $O/${TAG}_pmc_mfma.txt 2>&1
+python tools/dec_probe.py > $O/${TAG}_dec_probes.txt 2>&1
+python tools/dec_trace.py >> $O/${TAG}_dec_probes.txt 2>&1
+python tools/family_trace.py > $O/${TAG}_family_trace.txt 2>&1
+tail -c 300 $O/${TAG}_bench.json; head -12 $O/${TAG}_pmc_mfma.txt
