@@ -248,6 +248,10 @@ void build_ws_layout(const TacoShape& s, bool train, const TransLayout& T, WsLay
     W.bc_cq = a.add("bwd.comp.cq", {kAtt});                         // sum_t dq_t
     W.bc_cp = a.add("bwd.comp.cp", {kPre1});                        // sum_t dp1s_t
     W.dattv = a.add("bwd.dattv_rows", {s.B, kAtt});                 // per-row d attention_v, summed in row order
+    W.post_dpj1 = a.add("bwd.post.dpj1", {M2, P.post.c1});
+    W.post_dz1 = a.add("bwd.post.dz1", {M2, P.post.c1});
+    W.post_dpool = a.add("bwd.post.dpool", {M2, P.post.K * kCb});
+    W.post_dx = a.add("bwd.post.dx", {M2, kMel});
     W.gA = a.add("bwd.gA", {Mx, 16 * kCb});
     W.gB = a.add("bwd.gB", {Mx, 16 * kCb});
     W.gC = a.add("bwd.gC", {Mx, 6 * kCb});
@@ -259,6 +263,7 @@ void build_ws_layout(const TacoShape& s, bool train, const TransLayout& T, WsLay
   } else {
     W.ds2s = W.dout_pad = W.paramsT = W.gstash = W.dkeys = W.dvalues = W.ds2s_tot = -1;
     W.bc_fa = W.bc_wot = W.bc_g = W.bc_h1 = W.bc_h2 = W.bc_cq = W.bc_cp = W.dattv = -1;
+    W.post_dpj1 = W.post_dz1 = W.post_dpool = W.post_dx = -1;
     W.gA = W.gB = W.gC = W.gD = W.gE = W.gF = W.gG = W.scratch = -1;
   }
   W.total = (a.off + 63) / 64 * 64;

@@ -7,6 +7,7 @@
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <vector>
 
 #include "common.h"
 #include "kernels.h"
@@ -234,6 +235,7 @@ struct SideStream {
   // (taco_wait_grad_segment): [0] encoder, [1] decoder, [2] post-net segment of the flat gradient buffer is final
   hipEvent_t ev_seg[3] = {nullptr, nullptr, nullptr};
   bool seg_recorded = false;
+  hipEvent_t ev_post = nullptr;   // deferred post-net weight gradients done (taco_backward)
 };
 SideStream& side_stream() {
   static thread_local SideStream ss[16];
@@ -435,6 +437,10 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
 // Weight-gradient GEMM.  Inside a TnGroup scope the call is queued and launched with its independent siblings in ONE grid
 // (launch_gemm_tn_batch); otherwise it is launched immediately.
 thread_local GemmTnBatch* g_tnq = nullptr;
+// Deferred sink: while set, weight-gradient problems are only COLLECTED (post-net CBHG backward); taco_backward launches them
+// later on the side stream, so that they run underneath the decoder BPTT kernel (which is latency bound and leaves the matrix
+// pipes and most issue slots of every CU idle; the GEMM workgroups co-reside with it -- tools/coresident_probe.py).
+thread_local std::vector<GemmTnArgs>* g_tn_defer = nullptr;
 struct TnGroup {
   GemmTnBatch batch;
   hipStream_t s;
@@ -450,6 +456,10 @@ int tn(const float* A, int lda, int K, const float* Y, int ldy, int N, float* W,
   a.Nld = Nld;
   a.A = A; a.lda = lda; a.Y = Y; a.ldy = ldy; a.W = W; a.ldw = ldw; a.M = M; a.N = N; a.K = K; a.taps = taps; a.T = T;
   a.pad_l = pad_l;
+  if (g_tn_defer) {
+    g_tn_defer->push_back(a);
+    return TACO_OK;
+  }
   if (g_tnq) {
     if (g_tnq->n == kMaxTnBatch) TACO_TRY(launch_gemm_tn_batch(*g_tnq, s));
     g_tnq->p[g_tnq->n++] = a;
@@ -549,6 +559,9 @@ int build_dec_composites_bwd(const float* P, const ParamLayout& PL, const WsLayo
 
 struct BwdScratch {
   float *gA, *gB, *gC, *gD, *gE, *gF, *gG;
+  // When the weight-gradient GEMMs are deferred their operands must outlive the rest of cbhg_bwd: these three buffers then
+  // replace the in-place reuse of gD / gC / gA (d pj1, d z1, d pool); null = reuse as before.
+  float *alt_dpj1 = nullptr, *alt_dz1 = nullptr, *alt_dpool = nullptr;
 };
 
 // CBHG backward.  dOut (M,256) -> dX (M,cin) written to `dx_out`; parameter gradients accumulated into G.
@@ -670,17 +683,17 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
   float* dz2 = sc.gG;    // (M,c2)
   TACO_TRY(launch_affine_act_bwd(w.pj2pre, P + c.p2_g, dres, dz2, G + c.p2_g, G + c.p2_be, M, c.c2, TACO_ACT_NONE, s));
   TACO_TRY(tn(w.pj1, c.c1, c.c1, dz2, c.c2, c.c2, G + c.p2_w, c.c2, M, T, 1, s, 3, G + c.p2_b));
-  float* dpj1 = sc.gD;   // (M,c1)
+  float* dpj1 = sc.alt_dpj1 ? sc.alt_dpj1 : sc.gD;   // (M,c1)
   {
     ConvGemmProblem p;
     p.A = dz2; p.lda = c.c2; p.W = PT + t.p2; p.ldw = c.c1; p.C = dpj1; p.ldc = c.c1; p.M = M; p.N = c.c1; p.K = c.c2;
     p.taps = 3; p.T = T; p.pad_l = 1; p.act = TACO_ACT_NONE;
     TACO_TRY(launch_conv_gemm(p, s));
   }
-  float* dz1 = sc.gC;    // (M,c1)  (dxg no longer needed)
+  float* dz1 = sc.alt_dz1 ? sc.alt_dz1 : sc.gC;    // (M,c1)  (dxg no longer needed unless its weight gradients are deferred)
   TACO_TRY(launch_affine_act_bwd(w.pj1pre, P + c.p1_g, dpj1, dz1, G + c.p1_g, G + c.p1_be, M, c.c1, TACO_ACT_RELU, s));
   TACO_TRY(tn(w.pool, KC, KC, dz1, c.c1, c.c1, G + c.p1_w, c.c1, M, T, 1, s, 3, G + c.p1_b));
-  float* dpool = sc.gA;  // (M,KC)
+  float* dpool = sc.alt_dpool ? sc.alt_dpool : sc.gA;  // (M,KC)
   {
     ConvGemmProblem p;
     p.A = dz1; p.lda = c.c1; p.W = PT + t.p1; p.ldw = KC; p.C = dpool; p.ldc = KC; p.M = M; p.N = KC; p.K = c.c1;
@@ -837,15 +850,51 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
   hipStream_t side = side_fork(s);
   TACO_TRY(tn(pb.out, 2 * kCb, 2 * kCb, dOutPad, 1028, kFft, G + PL.post_dense.w, kFft, M2, M2, 0, side, 1, G + PL.post_dense.b, 1028));
   // ---- post-net CBHG (input = seq2seq_output viewed as (B, Td*r, 80)) ----
+  // Only the activation-gradient chain is on the critical path to the decoder BPTT: the CBHG's ~27 weight-gradient GEMMs are
+  // collected here and launched on the side stream below, where they run underneath the (latency-bound) BPTT kernel.
+  // OPT-IN (TACO_DEFER_POST_TN=1).  Measured on MI355X (S1): step 15.68 -> 15.59 ms; the BPTT kernel itself stretches from
+  // 5.12 to 5.64 ms while it shares its CUs with 0.62 ms worth of GEMMs (tools/coresident_probe.py: both sides run ~1.5x
+  // slower while they overlap), so the net gain is 0.6 % -- not worth making the dominant kernel's timing depend on it.
+  const bool defer = side != s && getenv("TACO_DEFER_POST_TN") != nullptr;
+  std::vector<GemmTnArgs> post_tn;
+  BwdScratch scp = sc;
   float* dPostIn = sc.gC;   // (M2, 80)
-  TACO_TRY(cbhg_bwd(P, PT, G, PL.post, TL.post, seq2seq_output, dPostOut, B, F, pb, sc, dPostIn, s));
+  if (defer) {
+    scp.alt_dpj1 = ws + W.post_dpj1; scp.alt_dz1 = ws + W.post_dz1; scp.alt_dpool = ws + W.post_dpool;
+    dPostIn = ws + W.post_dx;
+    g_tn_defer = &post_tn;
+  }
+  const int rc_post = cbhg_bwd(P, PT, G, PL.post, TL.post, seq2seq_output, dPostOut, B, F, pb, scp, dPostIn, s);
+  g_tn_defer = nullptr;
+  TACO_TRY(rc_post);
   // d seq2seq_output = sign(s2s - mel) + post-net path
   float* dS2S = ws + W.ds2s_tot;
   TACO_TRY(launch_add(ws + W.ds2s, dPostIn, dS2S, (int64_t)MD * R80, s));
-  // gradient segment 2 (post-net CBHG + final dense) is final once the side stream's dense weight gradient has landed:
-  // data-parallel callers start its all-reduce here, under the decoder BPTT (taco_wait_grad_segment)
-  TACO_TRY(side_join(s, side));
-  TACO_TRY(record_segment(2, s));
+  SideStream& ssx = side_stream();
+  if (defer) {
+    // side: wait for the producers of the deferred operands (everything enqueued on `s` so far), then the grouped launches
+    if (hipEventRecord(ssx.ev_fork, s) != hipSuccess || hipStreamWaitEvent(side, ssx.ev_fork, 0) != hipSuccess) {
+      taco_set_error("taco_backward: event record/wait failed");
+      return TACO_ELAUNCH;
+    }
+    GemmTnBatch gb;
+    for (const GemmTnArgs& q : post_tn) {
+      if (gb.n == kMaxTnBatch) TACO_TRY(launch_gemm_tn_batch(gb, side));
+      gb.p[gb.n++] = q;
+    }
+    if (gb.n) TACO_TRY(launch_gemm_tn_batch(gb, side));
+    if (!ssx.ev_post && hipEventCreateWithFlags(&ssx.ev_post, hipEventDisableTiming) != hipSuccess) {
+      taco_set_error("taco_backward: cannot create an event");
+      return TACO_ELAUNCH;
+    }
+    (void)hipEventRecord(ssx.ev_post, side);
+    // gradient segment 2 (post-net CBHG + final dense) is final when the side stream gets here: data-parallel callers start
+    // its all-reduce at this point, under the decoder BPTT (taco_wait_grad_segment)
+    TACO_TRY(record_segment(2, side));
+  } else {
+    TACO_TRY(side_join(s, side));
+    TACO_TRY(record_segment(2, s));
+  }
 
   // ---- decoder BPTT ----
   {
@@ -880,6 +929,11 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     prof_end(1, slot, s);
     // d attention_v = sum over batch rows of the kernel's per-row partials, in row order (no atomics)
     TACO_TRY(launch_colsum_batched(ws + W.dattv, kAtt, G + PL.att_v, 1, B, kAtt, s));
+    // the scratch buffers the deferred post-net GEMMs read are reused from here on
+    if (defer && hipStreamWaitEvent(s, ssx.ev_post, 0) != hipSuccess) {
+      taco_set_error("taco_backward: event wait failed");
+      return TACO_ELAUNCH;
+    }
   }
   // ---- attention memory: dvalues[b] = alignments[b]^T . dctx[b] ; keys = values . Wm ----
   {
