@@ -591,7 +591,8 @@ bool gemm_tn2_eligible(const GemmTnArgs& a) {
   // (e.g. post proj1 dW 207 vs 199 us, dense dW 140 vs 71 us, bank dW 70 vs 43 us): the weight gradients are split-M launches
   // whose workgroups run only 8-12 stages before a 128 x 128 atomic epilogue, and the interleaved column map of the b64
   // fragment reads turns that epilogue into two half-used-cache-line atomics per row.  Kept for the tuning harness.
-  static const bool on = [] { const char* e = getenv("TACO_TN2"); return e && atoi(e) != 0; }();
+  const char* e2 = getenv("TACO_TN2");   // read on every call (the A/B harness toggles it inside one process)
+  const bool on = e2 && atoi(e2) != 0;
   if (!on || gemm2_min_tiles() <= 0 || taco_deterministic()) return false;
   if (a.batch != 1 || a.K < 96 || a.N < 96 || a.M < 512) return false;
   if (a.lda % 4 || a.ldy % 4 || a.K % 4 || !al16(a.A) || !al16(a.Y)) return false;

@@ -160,9 +160,11 @@ TN_CASES = [(128, 128, 128, 128, 1, 0), (360, 36, 80, 128, 3, 1), (5760, 180, 25
             (640, 20, 128, 128, 8, 4)]
 
 
+@pytest.mark.parametrize('tn2', ['0', '1'], ids=['gemm_tn', 'opt-in-tn2'])
 @pytest.mark.parametrize('case', TN_CASES, ids=[str(c) for c in TN_CASES])
-def test_gemm_tn(built_lib, case):
-    """(the opt-in gemm_tn2 kernel is read from TACO_TN2 once per process: run this file with TACO_TN2=1 to cover it)"""
+def test_gemm_tn(built_lib, case, tn2, monkeypatch):
+    """Weight-gradient GEMM; with TACO_TN2=1 the eligible shapes run on the opt-in second-generation kernel (gemm2.hip)."""
+    monkeypatch.setenv('TACO_TN2', tn2)
     M, T, N, K, taps, pad_l = case
     rng = np.random.default_rng(hash(case) % 2**31)
     A = rng.standard_normal((M, K))

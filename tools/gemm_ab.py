@@ -51,8 +51,9 @@ for name, M, T, N, K, taps in TN:
     gf = 2.0 * M * N * K * taps / 1e9
     best = {}
     for rnd in range(3):
-        for v, mt in (('old', '0'), ('tn2', '160')):
-            os.environ['TACO_GEMM2_MIN_TILES'] = mt
+        for v, on in (('old', '0'), ('tn2', '1')):
+            os.environ['TACO_GEMM2_MIN_TILES'] = '160'
+            os.environ['TACO_TN2'] = on
             us = timeit(lambda: lib.gemm_tn(A, Y, dW, M, N, K, taps=taps, T=T, pad_l=(taps - 1) // 2, accumulate=True))
             best[v] = min(best.get(v, 1e30), us)
     print('TN %-18s M=%5d N=%4d K=%4d taps=%2d  ' % (name, M, N, K, taps) + '  '.join('%s %7.1f us %5.1f TF' % (v, best[v], gf / (best[v] * 1e-6) / 1e3) for v in best), flush=True)
