@@ -41,30 +41,79 @@ __global__ void embedding_kernel(const float* __restrict__ table, const int32_t*
   }
 }
 
-__global__ void embedding_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ ids,
-                                     float* __restrict__ dtable, int64_t rows, int V, int width) {
-  const int64_t total = rows * width;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = i / width;
-    const int c = (int)(i % width);
-    int id = ids[row];
-    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
-    atomicAdd(&dtable[(int64_t)id * width + c], dout[i]);
-  }
-}
-
-// deterministic variant: thread (vocabulary row v, column c) walks the rows in order and adds the matching ones
-__global__ void embedding_bwd_ordered_kernel(const float* __restrict__ dout, const int32_t* __restrict__ ids,
-                                             float* __restrict__ dtable, int64_t rows, int V, int width) {
-  const int v = blockIdx.x;
-  for (int c = threadIdx.x; c < width; c += blockDim.x) {
-    float acc = 0.f;
-    for (int64_t r = 0; r < rows; ++r) {
-      int id = ids[r];
+// dtable[v] += sum of the dout rows whose id is v.  Workgroup (v, segment) handles the rows of its segment: its threads first
+// list the matching rows (each thread scans a contiguous run, a block-wide prefix sum keeps the list sorted), then four row
+// lanes x 64 column quads add the listed rows (lane l takes list entries l, l+4, ...; the lanes are summed in a fixed order).
+// One segment (deterministic mode): plain read-modify-write, reproducible.  Several: one atomicAdd per element and segment.
+// (Padded text makes id 0 by far the most frequent row -- a single workgroup walking all of its rows was 0.5 ms.)
+constexpr int kEmbSeg = 4096;   // rows listed per pass (LDS: 16 KB)
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ ids,
+                                                            float* __restrict__ dtable, int64_t rows, int V, int width,
+                                                            int64_t rows_per_seg) {
+  __shared__ int list[kEmbSeg];
+  __shared__ int cnt[256];
+  __shared__ float4 red[3][64];
+  const int v = blockIdx.x, tid = threadIdx.x, q0 = tid & 63, rl = tid >> 6;
+  const int W4 = width >> 2;
+  const int64_t seg0 = (int64_t)blockIdx.y * rows_per_seg;
+  const int64_t seg1 = min(rows, seg0 + rows_per_seg);
+  float4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // column quads q0, q0+64, ... (width <= 1024)
+  for (int64_t base = seg0; base < seg1; base += kEmbSeg) {
+    const int seg = (int)min((int64_t)kEmbSeg, seg1 - base);
+    const int per = (seg + 255) >> 8;
+    const int r0 = min(seg, tid * per), r1 = min(seg, r0 + per);
+    int c = 0;
+    for (int r = r0; r < r1; ++r) {
+      int id = ids[base + r];
       id = id < 0 ? 0 : (id >= V ? V - 1 : id);
-      if (id == v) acc += dout[r * width + c];
+      c += id == v;
     }
-    dtable[(int64_t)v * width + c] += acc;
+    cnt[tid] = c;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {   // inclusive scan
+      const int x = tid >= off ? cnt[tid - off] : 0;
+      __syncthreads();
+      cnt[tid] += x;
+      __syncthreads();
+    }
+    int o = cnt[tid] - c;
+    const int total = cnt[255];
+    for (int r = r0; r < r1; ++r) {
+      int id = ids[base + r];
+      id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+      if (id == v) list[o++] = r;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int j = rl; j < total; j += 4) {
+      const float4* src = reinterpret_cast<const float4*>(dout + (base + list[j]) * width);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (q0 + i * 64 < W4) {
+          const float4 d = src[q0 + i * 64];
+          acc[i].x += d.x; acc[i].y += d.y; acc[i].z += d.z; acc[i].w += d.w;
+        }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i * 64 >= W4) break;
+    if (rl > 0) red[rl - 1][q0] = acc[i];
+    __syncthreads();
+    if (rl == 0 && q0 + i * 64 < W4) {
+      float4 t = acc[i];
+      for (int l = 0; l < 3; ++l) { t.x += red[l][q0].x; t.y += red[l][q0].y; t.z += red[l][q0].z; t.w += red[l][q0].w; }
+      float* dst = dtable + (int64_t)v * width + (q0 + i * 64) * 4;
+      if (gridDim.y == 1) {
+        dst[0] += t.x; dst[1] += t.y; dst[2] += t.z; dst[3] += t.w;
+      } else {
+        atomicAdd(dst + 0, t.x); atomicAdd(dst + 1, t.y); atomicAdd(dst + 2, t.z); atomicAdd(dst + 3, t.w);
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -92,51 +141,74 @@ __global__ void bn_maxpool_kernel(const float* __restrict__ x, const float* __re
   }
 }
 
-// blockDim = (64 channels, 4 row lanes); grid = (C/64 ceil, row chunks)
+// blockDim = (64 channel quads, 4 row lanes); grid = (C/256 ceil, row chunks).  A row lane walks a CONTIGUOUS run of rows, so
+// the three pooled neighbours z[row-1], z[row], z[row+1] and dy[row-1] roll through registers: x and dy are read once.
 __global__ void bn_maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                       const float* __restrict__ beta, const float* __restrict__ dy,
                                       float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                       int B, int T, int C, int rows_per_block) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
+  const int C4 = C >> 2;
+  const int c4 = blockIdx.x * 64 + threadIdx.x;
   const int64_t M = (int64_t)B * T;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  const int seg = (rows_per_block + 3) >> 2;
+  const int64_t ra = r0 + (int64_t)threadIdx.y * seg;
+  const int64_t rb = ra + seg < r1 ? ra + seg : r1;
   const float rs = 1.0f / sqrtf(1.0f + kBnEps);
-  float ag = 0.f, ab = 0.f;
-  if (c < C) {
-    const float s = gamma[c] * rs, be = beta[c];
-    for (int64_t row = r0 + threadIdx.y; row < r1; row += 4) {
-      const int t = (int)(row % T);
-      const float xv = x[row * C + c];
-      const float z = xv * s + be;
-      float dz = 0.f;
-      if (t == T - 1) {
-        dz = dy[row * C + c];
-      } else {
-        const float zn = x[(row + 1) * C + c] * s + be;
-        if (z >= zn) dz = dy[row * C + c];
+  float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c4 < C4 && ra < rb) {
+    const float4 g4 = reinterpret_cast<const float4*>(gamma)[c4];
+    const float4 be4 = reinterpret_cast<const float4*>(beta)[c4];
+    const float sc[4] = {g4.x * rs, g4.y * rs, g4.z * rs, g4.w * rs};
+    const float be[4] = {be4.x, be4.y, be4.z, be4.w};
+    const float4* X = reinterpret_cast<const float4*>(x) + c4;
+    const float4* DY = reinterpret_cast<const float4*>(dy) + c4;
+    float4* DX = reinterpret_cast<float4*>(dx) + c4;
+    int t = (int)(ra % T);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 xp = t > 0 ? X[(ra - 1) * C4] : zero4, dyp = t > 0 ? DY[(ra - 1) * C4] : zero4;
+    float4 xc = X[ra * C4];
+    for (int64_t row = ra; row < rb; ++row) {
+      const bool last = t == T - 1, first = t == 0;
+      const float4 xn = last ? zero4 : X[(row + 1) * C4];
+      const float4 dyc = DY[row * C4];
+      const float xpv[4] = {xp.x, xp.y, xp.z, xp.w}, xcv[4] = {xc.x, xc.y, xc.z, xc.w}, xnv[4] = {xn.x, xn.y, xn.z, xn.w};
+      const float dpv[4] = {dyp.x, dyp.y, dyp.z, dyp.w}, dcv[4] = {dyc.x, dyc.y, dyc.z, dyc.w};
+      float o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float z = xcv[q] * sc[q] + be[q];
+        float dz = 0.f;
+        if (last || z >= xnv[q] * sc[q] + be[q]) dz = dcv[q];          // y[row] = max(z[row], z[row+1]) takes z[row] on ties
+        if (!first && z > xpv[q] * sc[q] + be[q]) dz += dpv[q];        // y[row-1] takes z[row] only when strictly larger
+        o[q] = dz * sc[q];
+        ag[q] += dz * xcv[q] * rs;
+        ab[q] += dz;
       }
-      if (t > 0) {
-        const float zp = x[(row - 1) * C + c] * s + be;
-        if (z > zp) dz += dy[(row - 1) * C + c];
-      }
-      dx[row * C + c] = dz * s;
-      ag += dz * xv * rs;
-      ab += dz;
+      DX[row * C4] = make_float4(o[0], o[1], o[2], o[3]);
+      xp = xc; xc = xn; dyp = dyc;
+      t = last ? 0 : t + 1;
+      if (last && row + 1 < rb) xc = X[(row + 1) * C4];   // next sequence starts: its first row was not fetched as a neighbour
     }
   }
-  __shared__ float red[2][4][64];
-  red[0][threadIdx.y][threadIdx.x] = ag;
-  red[1][threadIdx.y][threadIdx.x] = ab;
+  __shared__ float red[2][4][256];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    red[0][threadIdx.y][threadIdx.x * 4 + q] = ag[q];
+    red[1][threadIdx.y][threadIdx.x * 4 + q] = ab[q];
+  }
   __syncthreads();
-  if (threadIdx.y == 0 && c < C) {
-    float g = 0.f, b = 0.f;
+  const int tid = threadIdx.y * 64 + threadIdx.x;   // 256 threads <-> 256 channels of the block
+  const int c = blockIdx.x * 256 + tid;
+  if (c < C) {
+    float g = 0.f, b2 = 0.f;
     for (int i = 0; i < 4; ++i) {
-      g += red[0][i][threadIdx.x];
-      b += red[1][i][threadIdx.x];
+      g += red[0][i][tid];
+      b2 += red[1][i][tid];
     }
     atomicAdd(&dgamma[c], g);
-    atomicAdd(&dbeta[c], b);
+    atomicAdd(&dbeta[c], b2);
   }
 }
 
@@ -256,21 +328,29 @@ __global__ void add_kernel(const float* __restrict__ a, const float* __restrict_
     y[i] = a[i] + b[i];
 }
 
-__global__ void l1_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ grad, int ldg,
+__global__ __launch_bounds__(1024) void l1_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ grad, int ldg,
                           float* __restrict__ loss_slot, int64_t M, int N) {
-  __shared__ float red[8];
+  // one wave per row at a time: the row/column split of the padded gradient costs no division, and a wave's 64 lanes walk a
+  // row in coalesced 256-byte pieces (N = 1025 rows are not 16-byte aligned, so the accesses stay scalar)
+  __shared__ float red[16];
   float acc = 0.f;
-  const int64_t total = M * ldg;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t m = i / ldg;
-    const int n = (int)(i % ldg);
-    float g = 0.f;
-    if (n < N) {
-      const float d = a[m * N + n] - b[m * N + n];
-      acc += fabsf(d);
-      g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t m = wave0; m < M; m += nwaves) {
+    const float* ar = a + m * N;
+    const float* br = b + m * N;
+    float* gr = grad ? grad + m * ldg : nullptr;
+#pragma unroll 4
+    for (int n = lane; n < ldg; n += 64) {
+      float g = 0.f;
+      if (n < N) {
+        const float d = ar[n] - br[n];
+        acc += fabsf(d);
+        g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+      }
+      if (gr) gr[n] = g;
     }
-    if (grad) grad[i] = g;
   }
   const float t = block_sum(acc, red);
   if (threadIdx.x == 0) loss_slot[blockIdx.x] = t;   // one partial per block; finish_loss adds them in block order
@@ -441,12 +521,12 @@ int launch_embedding(const float* table, const int32_t* ids, float* out, int64_t
   return TACO_OK;
 }
 int launch_embedding_bwd(const float* dout, const int32_t* ids, float* dtable, int64_t rows, int V, hipStream_t s, int width) {
-  if (taco_deterministic()) {
-    hipLaunchKernelGGL(embedding_bwd_ordered_kernel, dim3(V), dim3(width < 256 ? 64 : 256), 0, s, dout, ids, dtable, rows, V, width);
-    TACO_LAUNCH_CHECK("embedding_bwd_ordered");
-    return TACO_OK;
-  }
-  EW_LAUNCH(embedding_bwd_kernel, rows * width, s, dout, ids, dtable, rows, V, width);
+  TACO_REQUIRE(width <= 1024 && width % 4 == 0, "embedding_bwd: width %d must be a multiple of 4, <= 1024", width);
+  int segs = taco_deterministic() ? 1 : (int)std::min<int64_t>(32, (rows + 255) / 256);
+  if (segs < 1) segs = 1;
+  const int64_t rps = (rows + segs - 1) / segs;
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(V, segs), dim3(256), 0, s, dout, ids, dtable, rows, V, width, rps);
+  TACO_LAUNCH_CHECK("embedding_bwd");
   return TACO_OK;
 }
 int launch_colsum_batched(const float* x, int ld, float* out, int B, int T, int N, hipStream_t s) {
@@ -471,7 +551,9 @@ int launch_bn_maxpool_bwd(const float* x, const float* gamma, const float* beta,
                           float* dgamma, float* dbeta, int B, int T, int C, hipStream_t s) {
   dim3 grid;
   int rpb;
+  TACO_REQUIRE(C % 4 == 0, "bn_maxpool_bwd: C %% 4 != 0");
   col_grid((int64_t)B * T, C, grid, rpb);
+  grid.x = (C / 4 + 63) / 64;
   hipLaunchKernelGGL(bn_maxpool_bwd_kernel, grid, dim3(64, 4), 0, s, x, gamma, beta, dy, dx, dgamma, dbeta, B, T, C, rpb);
   TACO_LAUNCH_CHECK("bn_maxpool_bwd");
   return TACO_OK;
@@ -510,7 +592,8 @@ int launch_add(const float* a, const float* b, float* y, int64_t n, hipStream_t 
 int launch_l1(const float* a, const float* b, float* grad, int ldg, float* loss_parts, int64_t M, int N, hipStream_t s) {
   TACO_REQUIRE(ldg >= N, "l1: ldg < N");
   // exactly kLossParts blocks: block i leaves its partial in loss_parts[i] (blocks without work write 0)
-  hipLaunchKernelGGL(l1_kernel, dim3(kLossParts), dim3(kThreads), 0, s, a, b, grad, ldg, loss_parts, M, N);
+  hipLaunchKernelGGL(l1_kernel, dim3(kLossParts), dim3(1024), 0, s,   // 16 waves per workgroup: the kernel is latency bound, the partial count is fixed
+                     a, b, grad, ldg, loss_parts, M, N);
   TACO_LAUNCH_CHECK("l1");
   return TACO_OK;
 }

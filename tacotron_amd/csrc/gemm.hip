@@ -612,8 +612,21 @@ static void dispatch_tn(int flags, dim3 grid, hipStream_t s, const GemmTnArgs& a
   }
 }
 
+// Workgroups a weight-gradient launch aims for (TACO_TN_BLOCKS overrides; swept on S1: 384 / 768 / 1536 / 3072 -> family 5.17 / 4.67 / 4.49 / 4.45 ms per step).
+static int tn_block_target() {
+  static const int v = [] {
+    const char* e = getenv("TACO_TN_BLOCKS");
+    const int x = e ? atoi(e) : 0;
+    return x > 0 ? x : 3072;
+  }();
+  return v;
+}
+
 // Validates one problem, derives its vector flags and split plan.  Returns the tile size used (64 or 128).
-static int plan_gemm_tn(GemmTnArgs& a, bool force_small, dim3& grid) {
+// `group_tiles`: output tiles of the whole grouped launch this problem is part of (0: on its own): the row range is split so
+// that the GROUP reaches the workgroup target, not every member by itself (a group of eight one-tile problems used to be cut
+// into 64-row chunks: 4096 atomics per 4 k-steps).
+static int plan_gemm_tn(GemmTnArgs& a, bool force_small, dim3& grid, int64_t group_tiles = 0) {
   a.flags = 0;
   if (a.Nld <= 0) a.Nld = (a.N % 4 == 0) ? a.N : 0;
   if (a.lda % 4 == 0 && aligned16(a.A) && a.strideA % 4 == 0 && a.K % 4 == 0) a.flags |= 1;
@@ -621,7 +634,8 @@ static int plan_gemm_tn(GemmTnArgs& a, bool force_small, dim3& grid) {
   const bool big = !force_small && (int64_t)cdiv(a.K, 128) * cdiv(a.N, 128) * a.taps * a.batch >= 128 && a.K >= 128 && a.N >= 128;
   const int bm = big ? 128 : 64;
   const int64_t tiles = (int64_t)cdiv(a.K, bm) * cdiv(a.N, bm) * a.taps * a.batch;
-  int splits = taco_deterministic() ? 1 : (int)((768 + tiles - 1) / tiles);   // deterministic: one workgroup owns the whole row range
+  const int64_t fill = group_tiles > tiles ? group_tiles : tiles;
+  int splits = taco_deterministic() ? 1 : (int)((tn_block_target() + fill - 1) / fill);   // deterministic: one workgroup owns the whole row range
   const int max_splits = cdiv(a.M, 64);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -676,6 +690,14 @@ int launch_gemm_tn_batch(GemmTnBatch& b, hipStream_t stream) {
   GemmTnArgs big[kMaxTnBatch];
   int nbig = 0;
   double big_flops = 0;
+  int64_t group_tiles = 0;
+  for (int i = 0; i < b.n; ++i) {
+    dim3 grid;
+    GemmTnArgs probe = b.p[i];
+    if (probe.A && probe.M > 0 && probe.N > 0 && probe.K > 0 && probe.taps > 0 && probe.batch > 0 && !gemm_tn2_eligible(probe) &&
+        plan_gemm_tn(probe, false, grid) == 64 && probe.flags == 3)
+      group_tiles += (int64_t)grid.x * grid.y * probe.taps * probe.batch;
+  }
   for (int i = 0; i < b.n; ++i) {
     GemmTnArgs a = b.p[i];
     TACO_REQUIRE(a.A && a.Y && a.W, "gemm_tn_batch: null operand");
@@ -687,7 +709,7 @@ int launch_gemm_tn_batch(GemmTnBatch& b, hipStream_t stream) {
     }
     dim3 grid;
     GemmTnArgs probe = a;
-    const int bm = plan_gemm_tn(probe, false, grid);
+    const int bm = plan_gemm_tn(probe, false, grid, group_tiles);
     if (bm == 128 || probe.flags != 3) {
       TACO_TRY(launch_gemm_tn(a, false, stream));
       continue;

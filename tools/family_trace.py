@@ -10,6 +10,11 @@ c = Config(); c.r, c.vocab_size = 2, 60
 m = Tacotron(c, synthetic_batch(32, 200, 180, 2, 60), train=True, seed=0)
 for _ in range(3): m.step()
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10): m.step()
+e1.record(); torch.cuda.synchronize()
+print('step %.3f ms' % (e0.elapsed_time(e1) / 10))
 lib.profile_read(2); lib.profile_read(3)
 lib.profile_enable(0b1100)
 N = 4
