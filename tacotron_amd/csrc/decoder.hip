@@ -172,16 +172,17 @@ __device__ __forceinline__ void prefetch_w(Pref& pf, const float* __restrict__ W
   }
 }
 
-// part: a kPartRegion-float LDS region private to this mat-vec until its phase_fin has run
+// Mat-vec of one (W, x) segment accumulated into `acc` (the thread's four columns over its k-chunk of THIS segment); several
+// segments with different matrices may feed one output vector (round G0: shared weights for [p2 ; out ; h1], the row's own
+// VW for the alignments).  mv_store then reduces over the k-groups of the wave and leaves the per-wave partials in `part`.
 template <bool PF>
-__device__ __forceinline__ void phase_mv_impl(const float* __restrict__ W, int ldw, int K, int N, const float* x,
-                                              float* part, const Xchg& X, const Pref& pf) {
+__device__ __forceinline__ float4 mv_accum(const float* __restrict__ W, int ldw, int K, int N, const float* x, const Xchg& X,
+                                           const Pref& pf, float4 acc) {
   if (X.fake & 1) ldw = 0;
   const int tid = opaque_tid();
   const Slice S = slice_of(X, N);
-  const int n4 = S.n4, nloc = S.nloc;
+  const int n4 = S.n4;
   const int kg = tid >> S.lg4, c4 = tid & (n4 - 1);
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   {
     const int Kc = (((K + (1 << S.lgKG) - 1) >> S.lgKG) + 3) & ~3;
     const int k0 = kg * Kc;
@@ -223,6 +224,14 @@ __device__ __forceinline__ void phase_mv_impl(const float* __restrict__ W, int l
       acc.x = fmaf(xs, w0.x, acc.x); acc.y = fmaf(xs, w0.y, acc.y); acc.z = fmaf(xs, w0.z, acc.z); acc.w = fmaf(xs, w0.w, acc.w);
     }
   }
+  return acc;
+}
+// part: a kPartRegion-float LDS region private to this mat-vec until its phase_fin has run
+__device__ __forceinline__ void mv_store(int N, const Xchg& X, float4 acc, float* part) {
+  const int tid = opaque_tid();
+  const Slice S = slice_of(X, N);
+  const int n4 = S.n4, nloc = S.nloc;
+  const int kg = tid >> S.lg4, c4 = tid & (n4 - 1);
   if (S.shfl) {
     for (int off = n4; off < 64; off <<= 1) {
       acc.x += __shfl_xor(acc.x, off, 64);
@@ -234,6 +243,11 @@ __device__ __forceinline__ void phase_mv_impl(const float* __restrict__ W, int l
   } else {
     *reinterpret_cast<float4*>(part + kg * nloc + c4 * 4) = acc;
   }
+}
+template <bool PF>
+__device__ __forceinline__ void phase_mv_impl(const float* __restrict__ W, int ldw, int K, int N, const float* x,
+                                              float* part, const Xchg& X, const Pref& pf) {
+  mv_store(N, X, mv_accum<PF>(W, ldw, K, N, x, X, pf, make_float4(0.f, 0.f, 0.f, 0.f)), part);
 }
 
 // after a workgroup barrier: reduce the partial rows, run the owner epilogue, update local state, publish the slice
@@ -343,19 +357,21 @@ constexpr int XB_FA = 0 /* NO <= 1024 */, XB_DP2 = 1024, XB_P2 = 1152, XB_DQP = 
               XB_G = 2432 /* +l*1024 */, XB_DAL = 7200;
 constexpr int kXchgFixed = 7200;
 
-// Forward step, 9 exchange rounds (DecComposite folds the purely linear links of the reference's cell, tacotron.py:54-60,73-76):
-//   G0   x = [p2 ; out' ; ctx'] Wx + bi   and   gates_1 = sigmoid([p2 ; out' ; ctx' ; h1] Wg0' + bg0')     (' = previous step)
+// Forward step, 8 exchange rounds (DecComposite folds the purely linear links of the reference's cell, tacotron.py:54-60,73-76):
+//   G0   x = [p2 ; out'] Wx_po + al' VWx + bi   and   gates_1 = sigmoid([p2 ; out' ; h1] Wg0' + al' VWg + bg0')   (' = previous step)
 //   C0   candidate_1 / h1            G1 C1 G2 C2  likewise for GRU 2, 3 (plain weights)
 //   OUT  [q | cell_output] = (x + h3) [Wo Wq | Wo] + ...    and   pre_net layer 1 of step t+1
 //   E    energies (all-gather) + softmax   and   pre_net layer 2 of step t+1
-//   CTX  context = alignments . values
 // The AttentionWrapper's attention vector [cell_output ; context] Wa is never formed: it only feeds the next step's input
-// projection, and Wa Wi_a is part of Wx.
+// projection, and Wa Wi_a is part of Wx.  Neither is the context: context = alignments . values is linear in the alignments and
+// only ever enters the next step through Wx_c (and Wx_c Wg0_x), so the host forms VWx = values Wx_c and VWg = values Wx_c Wg0_x
+// once per call ((B,Tt,256) and (B,Tt,512), model.hip) and round G0 takes the ALIGNMENTS as an input segment -- which every
+// peer already holds after the softmax.  That removes the context mat-vec and its all-gather round from every step.
 struct DecSmem {
   float* part;   // kPartFloats
   float* fr;     // 80   pre-net input frame
   float* p1;     // 256
-  float* u0;     // 128+80r+256+256  [p2 ; cell_output ; context ; h1]: input of round G0
+  float* u0;     // 128+80r+256  [p2 ; cell_output ; h1]: shared-weight input segment of round G0
   float* xs;     // 256  in-proj output (residual)
   float* cat;    // 3*512 [layer input ; h_l] (l = 1, 2; slot 0 unused)
   float* catc;   // 512  [layer input ; r*h_l]
@@ -407,7 +423,7 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
   const int b = blockIdx.x >> (31 - __builtin_clz(P));
   const int B = a.B, Tt = a.Tt, Td = a.Td, r = a.r;
   const int R80 = kMel * r;
-  const int KX = kPre2 + R80 + kAtt;   // rows of Wx;  u0 = [p2 (0) ; out (128) ; ctx (128+R80) ; h1 (KX)]
+  const int KA = kPre2 + R80;          // u0 = [p2 (0) ; out (128) ; h1 (KA)]; rows [0,KA) of Wx, rows [0,KA+256) of Wg0'  
   const int NO = a.c.NO;
   const int TtP = (Tt + 3) & ~3;
   DecSmem S = carve(smem, TtP);
@@ -429,14 +445,14 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
   int len = a.text_length[b];
   len = len < 1 ? 1 : (len > Tt ? Tt : len);
   const float* keys = a.keys + (int64_t)b * Tt * kAtt;
-  const float* values = a.values + (int64_t)b * Tt * kAtt;
+  const float* vwx = a.vwx + (int64_t)b * Tt * kDec;        // this row's values . Wx_c        (Tt, 256)
+  const float* vwg = a.vwg + (int64_t)b * Tt * 2 * kDec;    // this row's values . Wx_c Wg0_x  (Tt, 512)
   float* const u_out = S.u0 + kPre2;
-  float* const u_ctx = S.u0 + kPre2 + R80;
-  float* const h1 = S.u0 + KX;
+  float* const h1 = S.u0 + KA;
 
   // zero state (AttentionWrapper.zero_state, tacotron.py:94): h = 0, attention = 0 (<=> previous output and context 0)
   for (int i = tid; i < 3 * 512; i += NT) S.cat[i] = 0.f;
-  for (int i = tid; i < KX + kDec; i += NT) S.u0[i] = 0.f;
+  for (int i = tid; i < KA + kDec; i += NT) S.u0[i] = 0.f;
   for (int i = tid; i < TtP; i += NT) { S.als[i] = 0.f; S.es[i] = 0.f; }
   if (tid < kMel) S.fr[tid] = a.mel ? a.mel[((int64_t)b * Td) * R80 + kMel * (r - 1) + tid] : 0.f;
   if (tid == 0) {
@@ -491,7 +507,7 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
   auto p1_put = [&](int n, float v) { S.p1[n] = v; };
   auto p2_put = [&](int n, float v) { S.u0[n] = v; };
   Pref pf;   // next round's first weight rows, fetched during the current round's all-gather
-  const NextMv nx_x{cw.wx, kDec, KX, kDec}, nx_o{cw.wo, NO, kDec, NO};
+  const NextMv nx_x{cw.wx, kDec, KA, kDec}, nx_o{cw.wo, NO, kDec, NO};
   {
     const int64_t bt0 = (int64_t)b * Td;
     X.epoch = 0x7fffffffu;   // prologue tag, distinct from every step tag
@@ -531,7 +547,8 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
     park_next(t + 2);
 
     // ---- round G0: InputProjectionWrapper x = [pre_net ; attention] Wi + bi (tacotron.py:56-59) with the attention layer
-    //      folded in, and GRU-1's gates straight from x's inputs ----
+    //      and the context folded in (alignments of step t-1 against this row's VWx / VWg), and GRU-1's gates straight from
+    //      x's inputs ----
     {
       auto x_epi = [&](int n, float y) {
         y += S.bias[BO_IN + n];
@@ -557,8 +574,15 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
         else S.us[n - kDec] = v;              // u
       };
       tstamp(X, 0);
-      phase_mv(cw.wx, kDec, KX, kDec, S.u0, S.part, X, pf);
-      phase_mv(cw.wg0, 2 * kDec, KX + kDec, 2 * kDec, S.u0, S.part + kPartRegion, X);
+      {
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 ax = mv_accum<true>(cw.wx, kDec, KA, kDec, S.u0, X, pf, z4);
+        if (t > 0) ax = mv_accum<false>(vwx, kDec, len, kDec, S.als, X, pf, ax);
+        mv_store(kDec, X, ax, S.part);
+        float4 ag = mv_accum<false>(cw.wg0, 2 * kDec, KA + kDec, 2 * kDec, S.u0, X, pf, z4);
+        if (t > 0) ag = mv_accum<false>(vwg, 2 * kDec, len, 2 * kDec, S.als, X, pf, ag);
+        mv_store(2 * kDec, X, ag, S.part + kPartRegion);
+      }
       tstamp(X, 1);
       lds_barrier();
       phase_fin(kDec, S.part, X, XF_X, x_epi, x_put);
@@ -652,7 +676,6 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
       if (has_next) phase_fin(kPre1, S.part + kPartRegion, X, XF_P1, p1_epi(bt + 1, p1b), p1_put);
       tstamp(X, 2);
       if (has_next) prefetch_w(pf, w.pre_w2, kPre2, kPre1, kPre2, X);
-      else prefetch_w(pf, values, kAtt, len, kAtt, X);
       phase_gather2(NO, XF_O, o_put, has_next ? kPre1 : 0, XF_P1, p1_put, X);
       tstamp(X, 3);
       X.tslot++;
@@ -685,7 +708,7 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
         phase_mv(w.pre_w2, kPre2, kPre1, kPre2, S.p1, S.part, X, pf);
         lds_barrier();
         phase_fin(kPre2, S.part, X, XF_P2, p2_epi(bt + 1), p2_put);
-        prefetch_w(pf, values, kAtt, len, kAtt, X);
+        prefetch_w(pf, nx_x.W, nx_x.ldw, nx_x.K, nx_x.N, X);
       }
       tstamp(X, 2);
       tmark(X, 1);
@@ -722,31 +745,22 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
       }
     }
     tmark(X, 4);
-    lds_barrier();
+    lds_barrier();   // the alignments are the last product of a step: they are an input segment of the next step's round G0
     tmark(X, 5);
-    // ---- round CTX: context = alignments . values ----
-    tstamp(X, 1);   // (slot of the ctx phase, stamp 1 is overwritten; the softmax end shows as stamp 0 of ctx)
-    phase(values, kAtt, len, kAtt, S.als, S.part, X, XF_CTX,
-          [&](int n, float y) {
-            if (st) st[kStCtx + n] = y;
-            return y;
-          },
-          [&](int n, float v) { u_ctx[n] = v; }, pf, has_next ? nx_x : NextMv());
-    lds_barrier();
   }
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------------------
-// Backward step, 10 exchange rounds, mirroring the folded forward step:
-//   FAN   [d ctx_t | d out_t] += dx_{t+1} [Wx_c^T | Wx_o^T]   and   d p2_{t+1} = dx_{t+1} Wi_p^T  (pre_net of step t+1, one step late)
-//   DAL   d alignments (all-gather)   and   d p1_{t+1} = d p2pre_{t+1} W2^T
-//   DQ    softmax / energy backward (unit split), dq all-gather
+// Backward step, 9 exchange rounds, mirroring the folded forward step:
+//   FAN   d out_t += dx_{t+1} Wx_o^T ,  d alignments_t[s] = VWx[s] . dx_{t+1}  (memory rows dealt to peers)   and
+//         d p2_{t+1} = dx_{t+1} Wi_p^T  (pre_net of step t+1, one step late)
+//   DQ    softmax / energy backward (unit split), dq all-gather   and   d p1_{t+1} = d p2pre_{t+1} W2^T
 //   OUT   d(x + h3) = [d out ; dq ; d p1pre_{t+1} (if step t+1 was fed out_t)] [Wo^T ; (Wo Wq)^T ; (Wo_f W1)^T]
 //   C2 G2 C1 G1 C0 G0   GRU layers top down; G0 leaves dx_t
-// The gradients the folded links skip (d attention, total d cell_output) are only needed for WEIGHT gradients and are
-// recovered there from small products (model.hip).
+// The gradients the folded links skip (d attention, d context, total d cell_output) are only needed for WEIGHT / memory
+// gradients and are recovered there from small products (model.hip).
 struct DecBwdSmem {
   float* part;    // kPartFloats
   float* dh;      // 3*256 carried dL/dh_l
@@ -839,15 +853,15 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
   int len = a.text_length[b];
   len = len < 1 ? 1 : (len > Tt ? Tt : len);
   const float* keys = a.keys + (int64_t)b * Tt * kAtt;
-  const float* values = a.values + (int64_t)b * Tt * kAtt;
+  const float* vwx = a.vwx + (int64_t)b * Tt * kDec;   // this row's values . Wx_c
   float* dkeys = a.dkeys + (int64_t)b * Tt * kAtt;
 
   for (int i = tid; i < 768; i += NT) S.dh[i] = 0.f;
   if (tid < 256) S.dx[tid] = 0.f;
   for (int i = tid; i < TtP; i += NT) { S.als[i] = 0.f; S.des[i] = 0.f; }
   if (tid == 0) *S.dead = 0;
-  // Register-resident attention memory.  d alignments (3a) is split by memory ROW: this wave's rows of `values` (as in the
-  // forward kernel).  The energy backward (3c) is split by attention UNIT: this peer owns units [ub, ub+un) of all rows, so
+  // Register-resident attention memory.  d alignments is split by memory ROW: this wave's rows of VWx (dealt as the
+  // forward kernel deals the keys).  The energy backward (3c) is split by attention UNIT: this peer owns units [ub, ub+un) of all rows, so
   // dq needs no cross-peer partial sums; thread (ul = tid % un, sg = tid / un) walks rows s = sg, sg+NSG, ... and keeps
   // keys[s][u] and the dkeys[s][u] accumulators of its first kKR rows in registers for the whole launch.
   const int s_first = X.peer + P * wave, s_stride = P * (NT / 64);
@@ -855,7 +869,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
 #pragma unroll
   for (int i = 0; i < kAR; ++i) {
     const int s = s_first + i * s_stride;
-    vres[i] = s < len ? reinterpret_cast<const float4*>(values + (int64_t)s * kAtt)[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    vres[i] = s < len ? reinterpret_cast<const float4*>(vwx + (int64_t)s * kDec)[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const Slice US = slice_of(X, kAtt);
   const int ub = US.nbeg, un = US.nloc;
@@ -928,26 +942,42 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
       if (tid < Tt) pre_al = a.align[(bt - 1) * Tt + tid];
     }
     lds_barrier();
-    // 1. round FAN: dx_{t+1} through [Wx_c^T | Wx_o^T | 0] (a.fa, (256, NO)) -> [d ctx_t | d cell_output_t (added to the direct
-    //    part)], and through Wi_p^T (wT.in_w columns [0,128)) -> d p2_{t+1}
+    // 1. round FAN: dx_{t+1} through [Wx_o^T | 0] (a.fa, (256, NO)) -> d cell_output_t (added to the direct part), through
+    //    Wi_p^T (wT.in_w columns [0,128)) -> d p2_{t+1}, and against this wave's rows of VWx -> d alignments_t (the context of
+    //    step t only ever fed x_{t+1}, so d alignments = VWx . dx_{t+1}: no d context, no round of its own)
     {
       auto fa_epi = [&](int n, float y) {
-        if (n < kAtt) {
-          gs[kGsCtx + n] = y;
-          return y;
-        }
-        if (n < kAtt + R80) {
-          const float g = dov[n - kAtt] + y;
-          gs[kGsO + n - kAtt] = g;
+        if (n < R80) {
+          const float g = dov[n] + y;
+          gs[kGsO + n] = g;
           return g;
         }
         return 0.f;
       };
       auto fa_put = [&](int n, float v) {
-        if (n < kAtt) S.dctx[n] = v;
-        else if (n < kAtt + R80) dov[n - kAtt] = v;
+        if (n < R80) dov[n] = v;
       };
       tstamp(X, 0);
+      tmark(X, 10);
+      {
+        const float4 c4 = reinterpret_cast<const float4*>(S.dx)[lane];
+        auto dal = [&](int s, float4 x4) {
+          float dd = x4.x * c4.x + x4.y * c4.y + x4.z * c4.z + x4.w * c4.w;
+          dd = wave_sum(dd);
+          if (lane == 0) {
+            S.des[s] = dd;
+            if (P > 1) xput(X, XB_DAL + s, dd);
+          }
+        };
+#pragma unroll
+        for (int i = 0; i < kAR; ++i) {
+          const int s = s_first + i * s_stride;
+          if (s < len) dal(s, vres[i]);
+        }
+        for (int s = s_first + kAR * s_stride; s < len; s += s_stride)
+          dal(s, reinterpret_cast<const float4*>(vwx + (int64_t)s * kDec)[lane]);
+      }
+      tmark(X, 11);
       phase_mv(a.fa, NO, kDec, NO, S.dx, S.part, X, pf);
       if (pend) phase_mv(w.in_w, kPre2 + kAtt, kDec, kPre2, S.dx, S.part + kPartRegion, X);
       tstamp(X, 1);
@@ -956,56 +986,40 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
       if (pend) phase_fin(kPre2, S.part + kPartRegion, X, XB_DP2, dp2_epi, dp2_put);
       tstamp(X, 2);
       if (pend) prefetch_w(pf, nx_p2T.W, nx_p2T.ldw, nx_p2T.K, nx_p2T.N, X);
-      phase_gather2(NO, XB_FA, fa_put, pend ? kPre2 : 0, XB_DP2, dp2_put, X);
-      tstamp(X, 3);
-      X.tslot++;
-    }
-    lds_barrier();
-    // 2. round DAL: d alignments[s] = values[s] . dctx (memory rows dealt round-robin to peers);  same round: deferred
-    //    pre-net layer 2 of step t+1: d p1 = d p2pre . W2^T (wT.pre_w2 is (128, 256))
-    {
-      tmark(X, 10);
-      const float4 c4 = reinterpret_cast<const float4*>(S.dctx)[lane];
-      auto dal = [&](int s, float4 x4) {
-        float dd = x4.x * c4.x + x4.y * c4.y + x4.z * c4.z + x4.w * c4.w;
-        dd = wave_sum(dd);
-        if (lane == 0) {
-          S.des[s] = dd;
-          if (P > 1) xput(X, XB_DAL + s, dd);
+      if (P > 1) {
+        // slot A: this thread's granule of [d out | d p2] (d p2 rides behind d out when both fit NT threads);  slot B: its
+        // d alignments granule.  Both are polled concurrently.
+        const Slice SF = slice_of(X, NO), SP = slice_of(X, kPre2);
+        const bool p2_in_a = pend && NO + kPre2 <= NT;
+        int idxA = XB_FA + tid;
+        bool needA = tid < NO && !(tid >= SF.nbeg && tid < SF.nbeg + SF.nloc);
+        if (p2_in_a && tid >= NO) {
+          const int n = tid - NO;
+          idxA = XB_DP2 + n;
+          needA = n < kPre2 && !(n >= SP.nbeg && n < SP.nbeg + SP.nloc);
         }
-      };
-#pragma unroll
-      for (int i = 0; i < kAR; ++i) {
-        const int s = s_first + i * s_stride;
-        if (s < len) dal(s, vres[i]);
-      }
-      for (int s = s_first + kAR * s_stride; s < len; s += s_stride)
-        dal(s, reinterpret_cast<const float4*>(values + (int64_t)s * kAtt)[lane]);
-      if (pend) {
-        phase_mv(w.pre_w2, kPre1, kPre2, kPre1, S.dp2, S.part, X, pf);
-        lds_barrier();
-        phase_fin(kPre1, S.part, X, XB_P2, p2T_epi, p2T_put);
-      }
-      tmark(X, 11);
-      if (P > 1) {   // the other peers' rows and their slices of d p1, polled concurrently
-        const Slice SB = slice_of(X, kPre1);
-        const bool needA = tid < len && (tid & (P - 1)) != X.peer;
-        const bool needB = pend && tid < kPre1 && !(tid >= SB.nbeg && tid < SB.nbeg + SB.nloc);
+        const bool needB = tid < len && (tid & (P - 1)) != X.peer;
         float vA, vB;
-        xget2(X, XB_DAL + tid, needA, XB_P2 + tid, needB, vA, vB);
-        if (needA) S.des[tid] = vA;
-        if (needB) p2T_put(tid, vB);
+        xget2(X, idxA, needA, XB_DAL + tid, needB, vA, vB);
+        if (needA) {
+          if (tid < NO) fa_put(tid, vA);
+          else dp2_put(tid - NO, vA);
+        }
+        if (needB) S.des[tid] = vB;
+        for (int n = tid + NT; n < NO; n += NT)
+          if (!(n >= SF.nbeg && n < SF.nbeg + SF.nloc)) fa_put(n, xget(X, XB_FA + n));
+        if (pend && !p2_in_a && tid < kPre2 && !(tid >= SP.nbeg && tid < SP.nbeg + SP.nloc)) dp2_put(tid, xget(X, XB_DP2 + tid));
         for (int s = tid + NT; s < len; s += NT)
           if ((s & (P - 1)) != X.peer) S.des[s] = xget(X, XB_DAL + s);
       }
+      tstamp(X, 3);
       tmark(X, 12);
+      X.tslot++;
     }
     lds_barrier();
     tmark(X, 13);
-    // d p1pre of step t+1 reaches this step's cell_output only if that step was fed by it (sampled rows); record it (or 0)
-    // for the output projection's weight gradient
+    // d p1pre of step t+1 reaches this step's cell_output only if that step was fed by it (sampled rows)
     const bool use_p1 = pend && next_from_out;
-    if (lead && tid < kPre1) gs[kGsP1S + tid] = use_p1 ? dp1[tid] : 0.f;
     // 3b. softmax backward: de = al * (dal - sum al*dal)   (every wave computes the dot redundantly)
     {
       float dot = 0.f;
@@ -1044,6 +1058,8 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
         }
         S.red[sg * un + ul] = dqa;
       }
+      // same round: deferred pre-net layer 2 of step t+1: d p1 = d p2pre . W2^T (wT.pre_w2 is (128, 256))
+      if (pend) phase_mv(w.pre_w2, kPre1, kPre2, kPre1, S.dp2, S.part, X, pf);
       tmark(X, 15);
     }
     lds_barrier();
@@ -1058,12 +1074,23 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
         gs[kGsQ + n] = dsum;
         if (P > 1) xput(X, XB_DQP + n, dsum);
       }
+      if (pend) phase_fin(kPre1, S.part, X, XB_P2, p2T_epi, p2T_put);
       prefetch_w(pf, a.wot, kDec, R80 + kAtt + (use_p1 ? kPre1 : 0), kDec, X);
-      phase_gather(kAtt, X, XB_DQP, dq_put);
+      if (P > 1) {   // dq slices and the other peers' slices of d p1, polled concurrently
+        const Slice SB = slice_of(X, kPre1);
+        const bool needA = tid < kAtt && !(tid >= ub && tid < ub + un);
+        const bool needB = pend && tid < kPre1 && !(tid >= SB.nbeg && tid < SB.nbeg + SB.nloc);
+        float vA, vB;
+        xget2(X, XB_DQP + tid, needA, XB_P2 + tid, needB, vA, vB);
+        if (needA) dq_put(tid, vA);
+        if (needB) p2T_put(tid, vB);
+      }
     }
     tmark(X, 17);
     lds_barrier();
     tmark(X, 18);
+    // record d p1pre_{t+1} (or 0) for the output projection's weight gradient
+    if (lead && tid < kPre1) gs[kGsP1S + tid] = use_p1 ? dp1[tid] : 0.f;
     // 4. round OUT: dy = [d cell_output ; dq ; d p1pre_{t+1}] . [Wo^T ; (Wo Wq)^T ; (Wo_f W1)^T]   (a.wot, (80r+512, 256))
     phase(a.wot, kDec, R80 + kAtt + (use_p1 ? kPre1 : 0), kDec, S.vo, S.part, X, XB_OUT, [&](int n, float y) { return y; },
           [&](int n, float v) {

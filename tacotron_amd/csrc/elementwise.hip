@@ -323,6 +323,27 @@ __global__ void mask_rows_kernel(const float* __restrict__ x, const int32_t* __r
   }
 }
 
+// out[b,s,:] = x[b,s,:] - mean over s' < len[b] of x[b,s',:]   (rows s >= len[b]: 0).  One thread per column walks the rows in
+// order (reproducible).  Used for the attention memory of the decoder backward: d alignments only matter up to a per-step
+// constant (the softmax backward removes the alignment-weighted mean), and removing the rows' common component BEFORE the
+// fold with Wx_c keeps the per-row rounding errors relative to what the softmax backward actually sees.
+__global__ void center_rows_kernel(const float* __restrict__ x, const int32_t* __restrict__ len, float* __restrict__ out,
+                                   int T, int C) {
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  int n = len[b];
+  n = n < 1 ? 1 : (n > T ? T : n);
+  const float* xb = x + (int64_t)b * T * C + c;
+  float* ob = out + (int64_t)b * T * C + c;
+  float acc = 0.f;
+#pragma unroll 8
+  for (int s = 0; s < n; ++s) acc += xb[(int64_t)s * C];
+  const float mean = acc / (float)n;
+#pragma unroll 8
+  for (int s = 0; s < T; ++s) ob[(int64_t)s * C] = s < n ? xb[(int64_t)s * C] - mean : 0.f;
+}
+
 __global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     y[i] = a[i] + b[i];
@@ -527,6 +548,11 @@ int launch_embedding_bwd(const float* dout, const int32_t* ids, float* dtable, i
   const int64_t rps = (rows + segs - 1) / segs;
   hipLaunchKernelGGL(embedding_bwd_kernel, dim3(V, segs), dim3(256), 0, s, dout, ids, dtable, rows, V, width, rps);
   TACO_LAUNCH_CHECK("embedding_bwd");
+  return TACO_OK;
+}
+int launch_center_rows(const float* x, const int32_t* len, float* out, int B, int T, int C, hipStream_t s) {
+  hipLaunchKernelGGL(center_rows_kernel, dim3((C + 255) / 256, B), dim3(256), 0, s, x, len, out, T, C);
+  TACO_LAUNCH_CHECK("center_rows");
   return TACO_OK;
 }
 int launch_colsum_batched(const float* x, int ld, float* out, int B, int T, int N, hipStream_t s) {

@@ -94,6 +94,7 @@ int launch_gemm_naive(const ConvGemmProblem& p, hipStream_t stream);
 
 // ---------------------------------------------------------------- elementwise.hip
 int launch_embedding(const float* table, const int32_t* ids, float* out, int64_t rows, int V, hipStream_t s, int width = kEmbed);
+int launch_center_rows(const float* x, const int32_t* len, float* out, int B, int T, int C, hipStream_t s);
 int launch_embedding_bwd(const float* dout, const int32_t* ids, float* dtable, int64_t rows, int V, hipStream_t s, int width = kEmbed);
 // y = maxpool2_same(x*scale+shift) along T; x,y (B*T, C)
 int launch_bn_maxpool(const float* x, const float* gamma, const float* beta, float* y, int B, int T, int C, hipStream_t s);
@@ -174,10 +175,16 @@ inline int dec_out_cols(int r) {
   while (n < kAtt + kMel * r) n *= 2;
   return n;
 }
+// Columns of the backward FAN round's [d cell_output | pad] product (same power-of-two rule).
+inline int dec_fan_cols(int r) {
+  int n = 128;
+  while (n < kMel * r) n *= 2;
+  return n;
+}
 // Composite forward weights (workspace; products of consecutive linear maps, see model.hip build_dec_composites)
 struct DecComposite {
-  const float* wx;     // (128+80r+256, 256)   x = [p2 ; out ; ctx] wx + in_b
-  const float* wg0;    // (128+80r+256+256, 512)  gates_0 pre-activation = [p2 ; out ; ctx ; h0] wg0 + bg0
+  const float* wx;     // (128+80r+256, 256)   x = [p2 ; out ; ctx] wx + in_b   (the kernel uses rows [0, 128+80r); the ctx rows feed VWx)
+  const float* wg0;    // (128+80r+256+256, 512)  gates_0 pre-activation = [p2 ; out ; h0 ; ctx] wg0 + bg0   (ctx rows feed VWg)
   const float* bg0;    // (512)
   const float* wo;     // (256, NO)  [q | out | 0] = (x + h3) wo + bo
   const float* bo;     // (NO)
@@ -225,6 +232,8 @@ struct DecFwdArgs {
   DecComposite c;
   const float* keys;     // (B,Tt,256)
   const float* values;   // (B,Tt,256)
+  const float* vwx;      // (B,Tt,256)  values . Wx_c        (context folded into the input projection, see decoder.hip)
+  const float* vwg;      // (B,Tt,512)  values . Wx_c Wg0_x  (... and into GRU-1's gates)
   const int32_t* text_length;
   const float* mel;      // (B,Td,80r) or null (inference)
   const uint8_t* keep1;  // (B,Td,256) or null
@@ -247,12 +256,12 @@ int launch_decoder_fwd(DecFwdArgs a, hipStream_t s);
 
 struct DecBwdArgs {
   DecWeights wT;         // every matrix TRANSPOSED (out,in); biases unused
-  const float* fa;       // (256, NO)  [Wx_c^T | Wx_o^T | 0]: dx_{t+1} -> [d context | d cell_output]
+  const float* fa;       // (256, NO)  [Wx_o^T | 0]: dx_{t+1} -> d cell_output_t   (NO = dec_fan_cols(r))
   const float* wot;      // (80r+512, 256)  [Wo^T ; (Wo Wq)^T ; (Wo[:, last frame] W1)^T]
   int NO;
   const float* att_v;    // (256)
   const float* keys;
-  const float* values;
+  const float* vwx;      // (B,Tt,256)  values . Wx_c:  d alignments_t[s] = vwx[s] . dx_{t+1}
   const int32_t* text_length;
   const uint8_t* keep1;
   const uint8_t* keep2;

@@ -209,6 +209,10 @@ void build_ws_layout(const TacoShape& s, bool train, const TransLayout& T, WsLay
   ws_cbhg(a, "enc.", P.enc, M1, s.B, train, W.enc);
   W.values = a.add("dec.values", {M1, kAtt});
   W.keys = a.add("dec.keys", {M1, kAtt});
+  W.vwx = a.add("dec.vwx", {M1, kDec});        // values . Wx_c: the context's path into the input projection, per memory row
+  W.vwg = a.add("dec.vwg", {M1, 2 * kDec});    // values . Wx_c Wg0_x: ... and into GRU-1's gates
+  W.vcen = train ? a.add("dec.vcen", {M1, kAtt}) : -1;    // values minus their per-sequence mean row
+  W.vwxc = train ? a.add("dec.vwxc", {M1, kDec}) : -1;    // vcen . Wx_c: what the backward kernel scores d alignments against
   W.stash = train ? a.add("dec.stash", {MD, kStRec}) : -1;
   W.prein = train ? a.add("dec.prein", {MD, kMel}) : -1;
   W.xchg = a.add("dec.xchg", {decoder_xchg_bytes(s.B, s.Tt) / 4});
@@ -216,7 +220,7 @@ void build_ws_layout(const TacoShape& s, bool train, const TransLayout& T, WsLay
   {
     const int KX = kPre2 + R80 + kAtt, NO = dec_out_cols(s.r);
     W.dc_wx = a.add("dec.comp.wx", {KX, kDec});                 // [Wi_p ; Wa Wi_a]: x = [p2 ; out ; ctx] Wx + bi
-    W.dc_wg0 = a.add("dec.comp.wg0", {KX + kDec, 2 * kDec});    // [Wx Wg0_x ; Wg0_h]
+    W.dc_wg0 = a.add("dec.comp.wg0", {KX + kDec, 2 * kDec});    // [Wx_po Wg0_x ; Wg0_h ; Wx_c Wg0_x]  (rows: p2, out | h1 | ctx)
     W.dc_bg0 = a.add("dec.comp.bg0", {2 * kDec});               // bg0 + bi Wg0_x
     W.dc_wo = a.add("dec.comp.wo", {kDec, NO});                 // [Wo Wq | Wo | 0]
     W.dc_bo = a.add("dec.comp.bo", {NO});                       // [bo Wq | bo | 0]
@@ -238,9 +242,10 @@ void build_ws_layout(const TacoShape& s, bool train, const TransLayout& T, WsLay
     W.paramsT = a.add("bwd.paramsT", {T.total});
     W.gstash = a.add("bwd.gstash", {MD, kGsRec});
     W.dkeys = a.add("bwd.dkeys", {M1, kAtt});
-    W.dvalues = a.add("bwd.dvalues", {M1, kAtt});
+    W.dvalues = a.add("bwd.dvalues", {M1, kAtt});                    // E[b] = sum_t al_{t-1}^T dx_t  (d values = E Wx_c^T)
     W.ds2s_tot = a.add("bwd.ds2s_tot", {MD, R80});
-    W.bc_fa = a.add("bwd.comp.fa", {kDec, dec_out_cols(s.r)});      // [Wx_c^T | Wx_o^T | 0]
+    W.bc_fa = a.add("bwd.comp.fa", {kDec, dec_fan_cols(s.r)});      // [Wx_o^T | 0]
+    W.bc_wxct = a.add("bwd.comp.wxct", {kDec, kAtt});               // Wx_c^T
     W.bc_wot = a.add("bwd.comp.wot", {R80 + 2 * kAtt, kDec});       // [Wo^T ; (Wo Wq)^T ; (Wo_f W1)^T]
     W.bc_g = a.add("bwd.comp.g", {R80 + kAtt, kDec});               // sum_t [out_t ; ctx_t]^T dx_{t+1}
     W.bc_h1 = a.add("bwd.comp.h1", {kDec, kAtt});                   // sum_t (x + h3)_t^T dq_t
@@ -262,6 +267,7 @@ void build_ws_layout(const TacoShape& s, bool train, const TransLayout& T, WsLay
     W.scratch = a.add("bwd.scratch", {64});
   } else {
     W.ds2s = W.dout_pad = W.paramsT = W.gstash = W.dkeys = W.dvalues = W.ds2s_tot = -1;
+    W.bc_wxct = -1;
     W.bc_fa = W.bc_wot = W.bc_g = W.bc_h1 = W.bc_h2 = W.bc_cq = W.bc_cp = W.dattv = -1;
     W.post_dpj1 = W.post_dz1 = W.post_dpool = W.post_dx = -1;
     W.gA = W.gB = W.gC = W.gD = W.gE = W.gF = W.gG = W.scratch = -1;

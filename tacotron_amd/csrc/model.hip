@@ -304,7 +304,8 @@ int build_dec_composites(const float* P, const ParamLayout& PL, const WsLayout& 
   };
   const auto D2D = hipMemcpyDeviceToDevice;
   TACO_TRY(chk(hipMemcpyAsync(wx, Wi, sizeof(float) * kPre2 * kDec, D2D, s)));
-  TACO_TRY(chk(hipMemcpyAsync(wg0 + (int64_t)KX * 2 * kDec, Wg0 + (int64_t)kDec * 2 * kDec, sizeof(float) * kDec * 2 * kDec, D2D, s)));
+  const int KA = kPre2 + R80;   // wg0 rows: [0,KA) p2 and out, [KA,KA+256) h1 (= Wg0_h), [KA+256,KA+512) ctx (only used to form VWg)
+  TACO_TRY(chk(hipMemcpyAsync(wg0 + (int64_t)KA * 2 * kDec, Wg0 + (int64_t)kDec * 2 * kDec, sizeof(float) * kDec * 2 * kDec, D2D, s)));
   TACO_TRY(chk(hipMemsetAsync(wo, 0, sizeof(float) * kDec * NO, s)));
   TACO_TRY(chk(hipMemsetAsync(bo, 0, sizeof(float) * NO, s)));
   TACO_TRY(chk(hipMemcpy2DAsync(wo + kAtt, NO * sizeof(float), Wo, R80 * sizeof(float), R80 * sizeof(float), kDec, D2D, s)));
@@ -322,10 +323,12 @@ int build_dec_composites(const float* P, const ParamLayout& PL, const WsLayout& 
                             kPre1, kMel, TACO_ACT_NONE);
     TACO_TRY(launch_conv_gemm_batch(b1, s));
     ConvGemmBatch b2;
-    b2.n = 2;
-    b2.p[0] = dense_problem(wx, kDec, Wg0, 2 * kDec, nullptr, wg0, 2 * kDec, KX, 2 * kDec, kDec, TACO_ACT_NONE);   // Wx Wg0_x
+    b2.n = 3;
+    b2.p[0] = dense_problem(wx, kDec, Wg0, 2 * kDec, nullptr, wg0, 2 * kDec, KA, 2 * kDec, kDec, TACO_ACT_NONE);   // Wx_po Wg0_x
     b2.p[1] = dense_problem(P + PL.in_proj.b, kDec, Wg0, 2 * kDec, P + PL.gru[0].bg, bg0, 2 * kDec, 1, 2 * kDec, kDec,
                             TACO_ACT_NONE);                                                                        // bi Wg0_x + bg0
+    b2.p[2] = dense_problem(wx + (int64_t)KA * kDec, kDec, Wg0, 2 * kDec, nullptr, wg0 + (int64_t)(KA + kDec) * 2 * kDec, 2 * kDec,
+                            kAtt, 2 * kDec, kDec, TACO_ACT_NONE);                                                  // Wx_c Wg0_x
     TACO_TRY(launch_conv_gemm_batch(b2, s));
   }
   return TACO_OK;
@@ -397,7 +400,26 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
   DecFwdArgs da;
   da.w = dec_weights(P, PL);
   da.c = dec_composite(ws, W, r);
-  da.keys = ws + W.keys; da.values = ws + W.values; da.text_length = text_length;
+  {
+    // context = alignments . values only ever enters the next step through Wx_c (and Wx_c Wg0_x): fold it per memory row, once
+    // per call, so that the decoder step needs no context mat-vec / all-gather round (decoder.hip)
+    const int KA = kPre2 + R80;
+    ConvGemmBatch vb;
+    vb.n = train ? 3 : 2;
+    if (train) {
+      // backward twin: the same fold of the CENTRED memory rows (d alignments are only defined up to a per-step constant;
+      // centring first keeps the rounding of each row's fold relative to what survives the softmax backward)
+      TACO_TRY(launch_center_rows(ws + W.values, text_length, ws + W.vcen, B, Tt, kAtt, s));
+      vb.p[2] = dense_problem(ws + W.vcen, kAtt, da.c.wx + (int64_t)KA * kDec, kDec, nullptr, ws + W.vwxc, kDec, M1, kDec, kAtt,
+                              TACO_ACT_NONE);
+    }
+    vb.p[0] = dense_problem(ws + W.values, kAtt, da.c.wx + (int64_t)KA * kDec, kDec, nullptr, ws + W.vwx, kDec, M1, kDec, kAtt,
+                            TACO_ACT_NONE);
+    vb.p[1] = dense_problem(ws + W.values, kAtt, da.c.wg0 + (int64_t)(KA + kDec) * 2 * kDec, 2 * kDec, nullptr, ws + W.vwg, 2 * kDec,
+                            M1, 2 * kDec, kAtt, TACO_ACT_NONE);
+    TACO_TRY(launch_conv_gemm_batch(vb, s));
+  }
+  da.keys = ws + W.keys; da.values = ws + W.values; da.vwx = ws + W.vwx; da.vwg = ws + W.vwg; da.text_length = text_length;
   da.mel = train ? mel : nullptr;
   da.keep1 = train ? dk1 : nullptr; da.keep2 = train ? dk2 : nullptr; da.sample = train ? sample : nullptr;
   da.out = s2s; da.align = align;
@@ -536,7 +558,7 @@ int prepare_transposes(const float* P, const ParamLayout& L, const TransLayout& 
 // Transposed composites of the decoder backward kernel (from the forward composites, still in the workspace since
 // taco_forward, and the out-projection kernel).
 int build_dec_composites_bwd(const float* P, const ParamLayout& PL, const WsLayout& W, float* ws, int r, hipStream_t s) {
-  const int R80 = kMel * r, NO = dec_out_cols(r);
+  const int R80 = kMel * r, NO = dec_fan_cols(r);
   float *fa = ws + W.bc_fa, *wot = ws + W.bc_wot;
   hipError_t e = hipMemsetAsync(fa, 0, sizeof(float) * kDec * NO, s);
   if (e != hipSuccess) {
@@ -549,10 +571,10 @@ int build_dec_composites_bwd(const float* P, const ParamLayout& PL, const WsLayo
     j.in = in; j.out = out; j.taps = 1; j.K = K; j.N = N; j.tile0 = 0; j.ldi = ldi; j.ldo = ldo;
   };
   const float* wx = ws + W.dc_wx;
-  job(wx + (int64_t)(kPre2 + R80) * kDec, kDec, fa, NO, kAtt, kDec);                 // Wx_c^T -> fa[:, 0:256]
-  job(wx + (int64_t)kPre2 * kDec, kDec, fa + kAtt, NO, R80, kDec);                   // Wx_o^T -> fa[:, 256:256+80r]
+  job(wx + (int64_t)(kPre2 + R80) * kDec, kDec, ws + W.bc_wxct, kAtt, kAtt, kDec);   // Wx_c^T
+  job(wx + (int64_t)kPre2 * kDec, kDec, fa, NO, R80, kDec);                          // Wx_o^T -> fa[:, 0:80r]
   job(P + PL.out_proj.w, R80, wot, kDec, kDec, R80);                                 // Wo^T
-  job(ws + W.dc_wo, NO, wot + (int64_t)R80 * kDec, kDec, kDec, kAtt);                // (Wo Wq)^T
+  job(ws + W.dc_wo, dec_out_cols(r), wot + (int64_t)R80 * kDec, kDec, kDec, kAtt);   // (Wo Wq)^T  (dc_wo is [Wo Wq | Wo | 0], pitch dec_out_cols)
   job(ws + W.dc_wp1o, kPre1, wot + (int64_t)(R80 + kAtt) * kDec, kDec, kDec, kPre1); // (Wo_f W1)^T
   return launch_transpose_batch(tb, s);
 }
@@ -916,8 +938,8 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     }
     w.out_w = PT + TL.out_proj; w.q_w = PT + TL.q_w; w.att_w = PT + TL.att_w; w.att_v = P + PL.att_v;
     a.att_v = P + PL.att_v;
-    a.fa = ws + W.bc_fa; a.wot = ws + W.bc_wot; a.NO = dec_out_cols(r);
-    a.keys = ws + W.keys; a.values = ws + W.values; a.text_length = text_length;
+    a.fa = ws + W.bc_fa; a.wot = ws + W.bc_wot; a.NO = dec_fan_cols(r);
+    a.keys = ws + W.keys; a.vwx = ws + W.vwxc; a.text_length = text_length;
     a.keep1 = dec_keep1; a.keep2 = dec_keep2; a.sample = sample;
     a.dout = dS2S; a.out = seq2seq_output; a.align = alignments; a.stash = st; a.gstash = gs;
     a.dkeys = ws + W.dkeys; a.datt_v = ws + W.dattv;
@@ -935,21 +957,27 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
       return TACO_ELAUNCH;
     }
   }
-  // ---- attention memory: dvalues[b] = alignments[b]^T . dctx[b] ; keys = values . Wm ----
+  // ---- attention memory.  The kernel never forms the context or its gradient (decoder.hip); everything they carried follows
+  //      from E[b] = sum_t alignments[b,t-1]^T dx[b,t]  (Tt x 256 per row; one batched launch):
+  //        d values = E Wx_c^T ,   sum_t ctx_{t-1}^T dx_t = sum_b values[b]^T E[b]   (the context rows of Gx below)
+  //      keys = values . Wm ----
   {
     GemmTnArgs a;
-    a.A = alignments; a.lda = Tt; a.Y = gs + kGsCtx; a.ldy = kGsRec; a.W = ws + W.dvalues; a.ldw = kAtt;
-    a.M = Td; a.N = kAtt; a.K = Tt; a.taps = 1; a.T = Td; a.pad_l = 0; a.batch = B;
+    a.A = alignments; a.lda = Tt; a.Y = gs + kGsX; a.ldy = kGsRec; a.W = ws + W.dvalues; a.ldw = kAtt;
+    a.M = Td; a.N = kDec; a.K = Tt; a.taps = 1; a.T = Td; a.pad_l = 1; a.batch = B;
     a.strideA = (int64_t)Td * Tt; a.strideY = (int64_t)Td * kGsRec; a.strideW = (int64_t)Tt * kAtt;
     TACO_TRY(launch_gemm_tn(a, false, s));
   }
   TACO_TRY(tn(ws + W.values, kAtt, 2 * kCb, ws + W.dkeys, kAtt, kAtt, G + PL.mem_w, kAtt, M1, M1, 0, s));
   float* dValTot = sc.gE;   // (M1,256)
   {
+    ConvGemmProblem p0 = dense_problem(ws + W.dvalues, kAtt, ws + W.bc_wxct, kAtt, nullptr, dValTot, 2 * kCb, M1, kAtt, kDec,
+                                       TACO_ACT_NONE);
+    TACO_TRY(launch_conv_gemm(p0, s));
     ConvGemmProblem p = dense_problem(ws + W.dkeys, kAtt, PT + TL.mem_w, 2 * kCb, nullptr, dValTot, 2 * kCb, M1, 2 * kCb, kAtt,
                                       TACO_ACT_NONE);
-    p.residual = ws + W.dvalues;
-    p.ldr = kAtt;
+    p.residual = dValTot;
+    p.ldr = 2 * kCb;
     TACO_TRY(launch_conv_gemm(p, s));
   }
   float* dEnc = sc.gG;      // (M1,256)
@@ -968,7 +996,7 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     // from Gx = sum_t [cell_output ; context]_{t-1}^T dx_t below: the kernel never forms the attention vector or its gradient.
     TACO_TRY(tn(st + kStP2, kStRec, kPre2, gs + kGsX, kGsRec, kDec, G + PL.in_proj.w, kDec, MD, Td, 0, s, 1, G + PL.in_proj.b));
     TACO_TRY(tn(seq2seq_output, R80, R80, gs + kGsX, kGsRec, kDec, ws + W.bc_g, kDec, MD, Td, 1, s));
-    TACO_TRY(tn(st + kStCtx, kStRec, kAtt, gs + kGsX, kGsRec, kDec, ws + W.bc_g + (int64_t)R80 * kDec, kDec, MD, Td, 1, s));
+    TACO_TRY(tn(ws + W.values, kAtt, kAtt, ws + W.dvalues, kAtt, kDec, ws + W.bc_g + (int64_t)R80 * kDec, kDec, M1, M1, 0, s));
     for (int l = 0; l < 3; ++l) {
       const float* inp = l == 0 ? st + kStX : st + kStH + (l - 1) * kDec;
       const float* dG = gs + kGsG + l * 512;

@@ -17,7 +17,7 @@ torch.cuda.synchronize()
 tab = {n: (o, s) for n, o, s, d in lib.workspace_table(m.shape, True)}
 o, s = tab['dec.err']
 tr = m.workspace[o + 16:o + 16 + 4 * 2 * 20].view(torch.int64).cpu().numpy().reshape(-1, 4)
-names = ['g0+x', 'c0', 'g1', 'c1', 'g2', 'c2', 'out+q+p1n', 'e+p2n', 'ctx']
+names = ['g0+x', 'c0', 'g1', 'c1', 'g2', 'c2', 'out+q+p1n', 'e+p2n']
 t0 = tr[0, 0]
 print('phase   start_us  matvec  barrier+finalize  gather   total   (wall_clock64 = 100 MHz ticks)')
 for i, n in enumerate(names):
@@ -34,7 +34,7 @@ print('shader clock during the decoder kernel: %.0f MHz' % ((ck[1] - ck[0]) / ((
 m.backward()
 torch.cuda.synchronize()
 tb = m.workspace[o + 16 + 256:o + 16 + 256 + 4 * 2 * 20].view(torch.int64).cpu().numpy().reshape(-1, 4)
-bn = ['fan+dp2', 'outT', 'c2T', 'g2T', 'c1T', 'g1T', 'c0T', 'g0T']
+bn = ['fan+dal+dp2', 'outT', 'c2T', 'g2T', 'c1T', 'g1T', 'c0T', 'g0T']
 t0 = tb[0, 0]
 print('BACKWARD phase start_us matvec finalize gather total')
 for i, n in enumerate(bn):
@@ -44,5 +44,5 @@ for i, n in enumerate(bn):
     print('%-5s %9.2f %8.2f %12.2f %10.2f %8.2f' % (n, a, b - a, c_ - b, d - c_, nxt - a))
 
 mk = m.workspace[o + 16 + 256 + 320:o + 16 + 256 + 320 + 2 * 32].view(torch.int64).cpu().numpy()
-print('bwd attention marks (us since 3a start):', ['%.2f' % ((mk[i] - mk[10]) / 100.0) for i in range(10, 19)],
-      ' [10 start,11 dal done,12 gathered,13 barrier,14 softmax-bwd done,15 energy-bwd done,16 barrier,17 dq exchanged,18 barrier]')
+print('bwd marks (us since FAN start):', ['%.2f' % ((mk[i] - mk[10]) / 100.0) for i in range(10, 19)],
+      ' [10 start,11 dal rows done,12 fan gathered,13 barrier,14 softmax-bwd done,15 energy-bwd + dp1 mat-vec done,16 barrier,17 dq/dp1 exchanged,18 barrier]')
