@@ -262,7 +262,7 @@ def main():
         rooflines = [
             {'what': dom, 'bound': 'latency', 'achieved': achieved, 'peak': PEAK, 'unit': 'TFLOP/s', 'frac': achieved / PEAK,
              'avg_ms': dom_ms, 'us_per_decoder_step': dom_ms * 1e3 / Td, 'flops_per_launch': flops, 'traffic': traffic,
-             'note': 'persistent per-row recurrence: %d strictly sequential steps x 9-10 dependent exchange rounds, no MFMA, '
+             'note': 'persistent per-row recurrence: %d strictly sequential steps x 8-9 dependent exchange rounds, no MFMA, '
                      'not HBM bound; the fp32 peak is quoted for scale only (DESIGN.md 5)' % Td},
             {'what': 'whole train step', 'bound': 'mfma', 'achieved': step_flops / sec_per_step / 1e12, 'peak': PEAK,
              'unit': 'TFLOP/s', 'frac': step_flops / sec_per_step / 1e12 / PEAK, 'flops_per_step': step_flops,

@@ -23,7 +23,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default)
 
-#define TACO_VERSION 110
+#define TACO_VERSION 111
 
 #define TACO_OK 0
 #define TACO_EINVAL (-1)   /* bad argument / unsupported shape   */

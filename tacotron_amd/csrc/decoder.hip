@@ -13,9 +13,11 @@
 // fence, placement independent; one hop measures 0.3-0.5 us).  Every spin is bounded; a timeout raises `err` and the
 // launch drains.
 //
-// A step is 9 exchange rounds forward and 10 backward: wherever two linear maps of the reference's cell follow each other
+// A step is 8 exchange rounds forward and 9 backward: wherever two linear maps of the reference's cell follow each other
 // without a nonlinearity (attention layer -> input projection -> GRU-1 gates, output projection -> query layer / next
-// pre_net), the host forms their product once per call (DecComposite, model.hip) and the kernel runs them as one round.
+// pre_net), the host forms their product once per call (DecComposite, model.hip) and the kernel runs them as one round;
+// the context (linear in the alignments, consumed only by the next step's input projection) is folded the same way against the
+// row's own attention memory (VWx / VWg), which removes its mat-vec and all-gather from the step altogether.
 // The next round's first weight rows are prefetched into registers while the all-gather is in flight.
 //
 // The backward kernel walks the steps in reverse with the same structure on pre-transposed weights and emits the
@@ -223,6 +225,80 @@ __device__ __forceinline__ float4 mv_accum(const float* __restrict__ W, int ldw,
       wp += ldw;
       acc.x = fmaf(xs, w0.x, acc.x); acc.y = fmaf(xs, w0.y, acc.y); acc.z = fmaf(xs, w0.z, acc.z); acc.w = fmaf(xs, w0.w, acc.w);
     }
+  }
+  return acc;
+}
+// Two (W, x) segments with the same pitch treated as ONE K range [0, K1 + K2) (K1 % 4 == 0): the k-groups split the
+// concatenation, so a thread's chunk is ceil((K1+K2)/groups) rows instead of ceil(K1/groups) + ceil(K2/groups), each rounded
+// up to 4 -- round G0 (shared weights for [p2 ; out ; h1], the row's own VW for the alignments) is the longest mat-vec of a
+// step and every row it does not load is off the critical path.  Groups of four rows never straddle the boundary.
+struct Seg2 {
+  const float* W1; const float* x1; int K1;
+  const float* W2; const float* x2; int K2;
+};
+__device__ __forceinline__ void prefetch_w2(Pref& pf, const Seg2& g, int ldw, int N, const Xchg& X) {
+  const int tid = opaque_tid();
+  const Slice S = slice_of(X, N);
+  const int kg = tid >> S.lg4, c4 = tid & (S.n4 - 1);
+  const int K = g.K1 + g.K2;
+  pf.W = g.W1;
+  const int Kc = (((K + (1 << S.lgKG) - 1) >> S.lgKG) + 3) & ~3;
+  const int k0 = kg * Kc;
+  const int k1 = min(K, k0 + Kc);
+  const int col = (S.g0 + c4) * 4;
+#pragma unroll
+  for (int i = 0; i < kPF; ++i) {
+    const int k = k0 + i;
+    const bool ok = k < k1 && !(X.fake & 1);
+    const float* row = (k < g.K1 ? g.W1 + (int64_t)(ok ? k : 0) * ldw : g.W2 + (int64_t)(ok ? k - g.K1 : 0) * ldw);
+    pf.w[i] = *reinterpret_cast<const float4*>(row + col);   // clamped address, value unused if !ok
+  }
+}
+template <bool PF>
+__device__ __forceinline__ float4 mv_accum2(const Seg2& g, int ldw, int N, const Xchg& X, const Pref& pf, float4 acc) {
+  if (X.fake & 1) ldw = 0;
+  const int tid = opaque_tid();
+  const Slice S = slice_of(X, N);
+  const int kg = tid >> S.lg4, c4 = tid & (S.n4 - 1);
+  const int K = g.K1 + g.K2;
+  const int Kc = (((K + (1 << S.lgKG) - 1) >> S.lgKG) + 3) & ~3;
+  const int k0 = kg * Kc;
+  const int k1 = min(K, k0 + Kc);
+  const int col = (S.g0 + c4) * 4;
+  int k = k0;
+  if (PF && pf.W == g.W1) {
+#pragma unroll
+    for (int q = 0; q < kPF / 4; ++q) {
+      if (k + 3 < k1) {
+        const float4 xv = *reinterpret_cast<const float4*>(k < g.K1 ? g.x1 + k : g.x2 + (k - g.K1));
+        const float4 w0 = pf.w[4 * q + 0], w1 = pf.w[4 * q + 1], w2 = pf.w[4 * q + 2], w3 = pf.w[4 * q + 3];
+        acc.x = fmaf(xv.x, w0.x, acc.x); acc.y = fmaf(xv.x, w0.y, acc.y); acc.z = fmaf(xv.x, w0.z, acc.z); acc.w = fmaf(xv.x, w0.w, acc.w);
+        acc.x = fmaf(xv.y, w1.x, acc.x); acc.y = fmaf(xv.y, w1.y, acc.y); acc.z = fmaf(xv.y, w1.z, acc.z); acc.w = fmaf(xv.y, w1.w, acc.w);
+        acc.x = fmaf(xv.z, w2.x, acc.x); acc.y = fmaf(xv.z, w2.y, acc.y); acc.z = fmaf(xv.z, w2.z, acc.z); acc.w = fmaf(xv.z, w2.w, acc.w);
+        acc.x = fmaf(xv.w, w3.x, acc.x); acc.y = fmaf(xv.w, w3.y, acc.y); acc.z = fmaf(xv.w, w3.z, acc.z); acc.w = fmaf(xv.w, w3.w, acc.w);
+        k += 4;
+      }
+    }
+  }
+#pragma unroll 2
+  for (; k + 3 < k1; k += 4) {
+    const bool first = k < g.K1;
+    const float4 xv = *reinterpret_cast<const float4*>(first ? g.x1 + k : g.x2 + (k - g.K1));
+    const float* wp = (first ? g.W1 + (int64_t)k * ldw : g.W2 + (int64_t)(k - g.K1) * ldw) + col;
+    const float4 w0 = *reinterpret_cast<const float4*>(wp);
+    const float4 w1 = *reinterpret_cast<const float4*>(wp + ldw);
+    const float4 w2 = *reinterpret_cast<const float4*>(wp + 2 * (int64_t)ldw);
+    const float4 w3 = *reinterpret_cast<const float4*>(wp + 3 * (int64_t)ldw);
+    acc.x = fmaf(xv.x, w0.x, acc.x); acc.y = fmaf(xv.x, w0.y, acc.y); acc.z = fmaf(xv.x, w0.z, acc.z); acc.w = fmaf(xv.x, w0.w, acc.w);
+    acc.x = fmaf(xv.y, w1.x, acc.x); acc.y = fmaf(xv.y, w1.y, acc.y); acc.z = fmaf(xv.y, w1.z, acc.z); acc.w = fmaf(xv.y, w1.w, acc.w);
+    acc.x = fmaf(xv.z, w2.x, acc.x); acc.y = fmaf(xv.z, w2.y, acc.y); acc.z = fmaf(xv.z, w2.z, acc.z); acc.w = fmaf(xv.z, w2.w, acc.w);
+    acc.x = fmaf(xv.w, w3.x, acc.x); acc.y = fmaf(xv.w, w3.y, acc.y); acc.z = fmaf(xv.w, w3.z, acc.z); acc.w = fmaf(xv.w, w3.w, acc.w);
+  }
+  for (; k < k1; ++k) {   // (only the tail of the second segment: K1 % 4 == 0)
+    const bool first = k < g.K1;
+    const float xs = first ? g.x1[k] : g.x2[k - g.K1];
+    const float4 w0 = *reinterpret_cast<const float4*>((first ? g.W1 + (int64_t)k * ldw : g.W2 + (int64_t)(k - g.K1) * ldw) + col);
+    acc.x = fmaf(xs, w0.x, acc.x); acc.y = fmaf(xs, w0.y, acc.y); acc.z = fmaf(xs, w0.z, acc.z); acc.w = fmaf(xs, w0.w, acc.w);
   }
   return acc;
 }
@@ -507,14 +583,19 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
   auto p1_put = [&](int n, float v) { S.p1[n] = v; };
   auto p2_put = [&](int n, float v) { S.u0[n] = v; };
   Pref pf;   // next round's first weight rows, fetched during the current round's all-gather
-  const NextMv nx_x{cw.wx, kDec, KA, kDec}, nx_o{cw.wo, NO, kDec, NO};
+  // (a second register set holding the first rows of G0's gate mat-vec, fetched once round E's all-gather has landed so that
+  //  the loads fly during the softmax, was measured: 196 VGPRs, 26.9 -> 29.1 us per step)
+  const NextMv nx_o{cw.wo, NO, kDec, NO};
+  const Seg2 sx{cw.wx, S.u0, KA, vwx, S.als, len};             // x     = [p2 ; out] Wx_po + al VWx
+  const Seg2 sg{cw.wg0, S.u0, KA + kDec, vwg, S.als, len};     // gates = [p2 ; out ; h1] Wg0' + al VWg
   {
     const int64_t bt0 = (int64_t)b * Td;
     X.epoch = 0x7fffffffu;   // prologue tag, distinct from every step tag
     if (a.prein && lead && tid < kMel) a.prein[bt0 * kMel + tid] = S.fr[tid];
     phase(w.pre_w1, kPre1, kMel, kPre1, S.fr, S.part, X, XF_P1, p1_epi(bt0, BO_P1), p1_put);
     lds_barrier();
-    phase(w.pre_w2, kPre2, kPre1, kPre2, S.p1, S.part, X, XF_P2, p2_epi(bt0), p2_put, pf, nx_x);
+    phase(w.pre_w2, kPre2, kPre1, kPre2, S.p1, S.part, X, XF_P2, p2_epi(bt0), p2_put, pf, NextMv());
+    prefetch_w2(pf, sx, kDec, kDec, X);
     lds_barrier();
   }
   // parked one step ahead in registers: dropout multipliers and the teacher frame of step t+1
@@ -575,13 +656,10 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
       };
       tstamp(X, 0);
       {
+        // (step 0: the alignments are still the zero state, the VW rows multiply zeros)
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 ax = mv_accum<true>(cw.wx, kDec, KA, kDec, S.u0, X, pf, z4);
-        if (t > 0) ax = mv_accum<false>(vwx, kDec, len, kDec, S.als, X, pf, ax);
-        mv_store(kDec, X, ax, S.part);
-        float4 ag = mv_accum<false>(cw.wg0, 2 * kDec, KA + kDec, 2 * kDec, S.u0, X, pf, z4);
-        if (t > 0) ag = mv_accum<false>(vwg, 2 * kDec, len, 2 * kDec, S.als, X, pf, ag);
-        mv_store(2 * kDec, X, ag, S.part + kPartRegion);
+        mv_store(kDec, X, mv_accum2<true>(sx, kDec, kDec, X, pf, z4), S.part);
+        mv_store(2 * kDec, X, mv_accum2<false>(sg, 2 * kDec, 2 * kDec, X, pf, z4), S.part + kPartRegion);
       }
       tstamp(X, 1);
       lds_barrier();
@@ -708,7 +786,7 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
         phase_mv(w.pre_w2, kPre2, kPre1, kPre2, S.p1, S.part, X, pf);
         lds_barrier();
         phase_fin(kPre2, S.part, X, XF_P2, p2_epi(bt + 1), p2_put);
-        prefetch_w(pf, nx_x.W, nx_x.ldw, nx_x.K, nx_x.N, X);
+        prefetch_w2(pf, sx, kDec, kDec, X);
       }
       tstamp(X, 2);
       tmark(X, 1);
