@@ -832,10 +832,12 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
 // backward
 // ------------------------------------------------------------------------------------------------------------
 // Backward step, 9 exchange rounds, mirroring the folded forward step:
-//   FAN   d out_t += dx_{t+1} Wx_o^T ,  d alignments_t[s] = VWx[s] . dx_{t+1}  (memory rows dealt to peers)   and
+//   FAN   d alignments_t[s] = VWx[s] . dx_{t+1}  (memory rows dealt to peers)   and
 //         d p2_{t+1} = dx_{t+1} Wi_p^T  (pre_net of step t+1, one step late)
 //   DQ    softmax / energy backward (unit split), dq all-gather   and   d p1_{t+1} = d p2pre_{t+1} W2^T
-//   OUT   d(x + h3) = [d out ; dq ; d p1pre_{t+1} (if step t+1 was fed out_t)] [Wo^T ; (Wo Wq)^T ; (Wo_f W1)^T]
+//   OUT   d(x + h3) = [d out (direct) ; dq ; d p1pre_{t+1} (if step t+1 was fed out_t)] [Wo^T ; (Wo Wq)^T ; (Wo_f W1)^T]
+//                     + dx_{t+1} (Wx_o^T Wo^T)      (cell_output_t -> x_{t+1} -> back: a second input segment, a.wdx; the total
+//                     d cell_output is only needed for the output projection's weight gradient and is formed by a GEMM afterwards)
 //   C2 G2 C1 G1 C0 G0   GRU layers top down; G0 leaves dx_t
 // The gradients the folded links skip (d attention, d context, total d cell_output) are only needed for WEIGHT / memory
 // gradients and are recovered there from small products (model.hip).
@@ -908,7 +910,6 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
   const int b = blockIdx.x >> (31 - __builtin_clz(P));
   const int B = a.B, Tt = a.Tt, Td = a.Td, r = a.r;
   const int R80 = kMel * r;
-  const int NO = a.NO;
   const int TtP = (Tt + 3) & ~3;
   DecBwdSmem S = carve_bwd(smem, TtP);
   const DecWeights& w = a.wT;
@@ -995,8 +996,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
   };
   auto p2T_put = [&](int n, float v) { dp1[n] = v; };
   Pref pf;   // next round's first weight rows, fetched during the current round's all-gather
-  const NextMv nx_fa{a.fa, NO, kDec, NO}, nx_p2T{w.pre_w2, kPre1, kPre2, kPre1};
-  prefetch_w(pf, nx_fa.W, nx_fa.ldw, nx_fa.K, nx_fa.N, X);
+  const NextMv nx_p2T{w.pre_w2, kPre1, kPre2, kPre1}, nx_dp2{w.in_w, kPre2 + kAtt, kDec, kPre2};
 
   for (int t = Td - 1; t >= 0; --t) {
     X.epoch = (unsigned)(Td - t);
@@ -1020,21 +1020,10 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
       if (tid < Tt) pre_al = a.align[(bt - 1) * Tt + tid];
     }
     lds_barrier();
-    // 1. round FAN: dx_{t+1} through [Wx_o^T | 0] (a.fa, (256, NO)) -> d cell_output_t (added to the direct part), through
-    //    Wi_p^T (wT.in_w columns [0,128)) -> d p2_{t+1}, and against this wave's rows of VWx -> d alignments_t (the context of
-    //    step t only ever fed x_{t+1}, so d alignments = VWx . dx_{t+1}: no d context, no round of its own)
+    // 1. round FAN: dx_{t+1} against this wave's rows of VWx -> d alignments_t (the context of step t only ever fed x_{t+1}, so
+    //    d alignments = VWx . dx_{t+1}: no d context, no round of its own), and through Wi_p^T (wT.in_w columns [0,128)) ->
+    //    d p2_{t+1}
     {
-      auto fa_epi = [&](int n, float y) {
-        if (n < R80) {
-          const float g = dov[n] + y;
-          gs[kGsO + n] = g;
-          return g;
-        }
-        return 0.f;
-      };
-      auto fa_put = [&](int n, float v) {
-        if (n < R80) dov[n] = v;
-      };
       tstamp(X, 0);
       tmark(X, 10);
       {
@@ -1056,37 +1045,22 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
           dal(s, reinterpret_cast<const float4*>(vwx + (int64_t)s * kDec)[lane]);
       }
       tmark(X, 11);
-      phase_mv(a.fa, NO, kDec, NO, S.dx, S.part, X, pf);
-      if (pend) phase_mv(w.in_w, kPre2 + kAtt, kDec, kPre2, S.dx, S.part + kPartRegion, X);
-      tstamp(X, 1);
-      lds_barrier();
-      phase_fin(NO, S.part, X, XB_FA, fa_epi, fa_put);
-      if (pend) phase_fin(kPre2, S.part + kPartRegion, X, XB_DP2, dp2_epi, dp2_put);
-      tstamp(X, 2);
-      if (pend) prefetch_w(pf, nx_p2T.W, nx_p2T.ldw, nx_p2T.K, nx_p2T.N, X);
-      if (P > 1) {
-        // slot A: this thread's granule of [d out | d p2] (d p2 rides behind d out when both fit NT threads);  slot B: its
-        // d alignments granule.  Both are polled concurrently.
-        const Slice SF = slice_of(X, NO), SP = slice_of(X, kPre2);
-        const bool p2_in_a = pend && NO + kPre2 <= NT;
-        int idxA = XB_FA + tid;
-        bool needA = tid < NO && !(tid >= SF.nbeg && tid < SF.nbeg + SF.nloc);
-        if (p2_in_a && tid >= NO) {
-          const int n = tid - NO;
-          idxA = XB_DP2 + n;
-          needA = n < kPre2 && !(n >= SP.nbeg && n < SP.nbeg + SP.nloc);
-        }
+      if (pend) {
+        phase_mv(w.in_w, kPre2 + kAtt, kDec, kPre2, S.dx, S.part, X, pf);
+        tstamp(X, 1);
+        lds_barrier();
+        phase_fin(kPre2, S.part, X, XB_DP2, dp2_epi, dp2_put);
+        tstamp(X, 2);
+        prefetch_w(pf, nx_p2T.W, nx_p2T.ldw, nx_p2T.K, nx_p2T.N, X);
+      }
+      if (P > 1) {   // d p2 slices and the other peers' d alignments rows, polled concurrently
+        const Slice SP = slice_of(X, kPre2);
+        const bool needA = pend && tid < kPre2 && !(tid >= SP.nbeg && tid < SP.nbeg + SP.nloc);
         const bool needB = tid < len && (tid & (P - 1)) != X.peer;
         float vA, vB;
-        xget2(X, idxA, needA, XB_DAL + tid, needB, vA, vB);
-        if (needA) {
-          if (tid < NO) fa_put(tid, vA);
-          else dp2_put(tid - NO, vA);
-        }
+        xget2(X, XB_DP2 + tid, needA, XB_DAL + tid, needB, vA, vB);
+        if (needA) dp2_put(tid, vA);
         if (needB) S.des[tid] = vB;
-        for (int n = tid + NT; n < NO; n += NT)
-          if (!(n >= SF.nbeg && n < SF.nbeg + SF.nloc)) fa_put(n, xget(X, XB_FA + n));
-        if (pend && !p2_in_a && tid < kPre2 && !(tid >= SP.nbeg && tid < SP.nbeg + SP.nloc)) dp2_put(tid, xget(X, XB_DP2 + tid));
         for (int s = tid + NT; s < len; s += NT)
           if ((s & (P - 1)) != X.peer) S.des[s] = xget(X, XB_DAL + s);
       }
@@ -1153,7 +1127,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
         if (P > 1) xput(X, XB_DQP + n, dsum);
       }
       if (pend) phase_fin(kPre1, S.part, X, XB_P2, p2T_epi, p2T_put);
-      prefetch_w(pf, a.wot, kDec, R80 + kAtt + (use_p1 ? kPre1 : 0), kDec, X);
+      prefetch_w2(pf, Seg2{a.wot, S.vo, R80 + kAtt + (use_p1 ? kPre1 : 0), a.wdx, S.dx, kDec}, kDec, kDec, X);
       if (P > 1) {   // dq slices and the other peers' slices of d p1, polled concurrently
         const Slice SB = slice_of(X, kPre1);
         const bool needA = tid < kAtt && !(tid >= ub && tid < ub + un);
@@ -1169,13 +1143,25 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
     tmark(X, 18);
     // record d p1pre_{t+1} (or 0) for the output projection's weight gradient
     if (lead && tid < kPre1) gs[kGsP1S + tid] = use_p1 ? dp1[tid] : 0.f;
-    // 4. round OUT: dy = [d cell_output ; dq ; d p1pre_{t+1}] . [Wo^T ; (Wo Wq)^T ; (Wo_f W1)^T]   (a.wot, (80r+512, 256))
-    phase(a.wot, kDec, R80 + kAtt + (use_p1 ? kPre1 : 0), kDec, S.vo, S.part, X, XB_OUT, [&](int n, float y) { return y; },
-          [&](int n, float v) {
-            S.dy[n] = v;
-            S.dht[n] = S.dh[2 * kDec + n] + v;   // dL/dh3' = carried + residual path
-          },
-          pf, NextMv{w.cw[2], 2 * kDec, kDec, 2 * kDec});
+    // 4. round OUT: dy = [d cell_output (direct) ; dq ; d p1pre_{t+1}] . [Wo^T ; (Wo Wq)^T ; (Wo_f W1)^T]   (a.wot, (80r+512, 256))
+    //               + dx_{t+1} . (Wx_o^T Wo^T)   (a.wdx, (256, 256))
+    {
+      const Seg2 so{a.wot, S.vo, R80 + kAtt + (use_p1 ? kPre1 : 0), a.wdx, S.dx, kDec};
+      auto o_put = [&](int n, float v) {
+        S.dy[n] = v;
+        S.dht[n] = S.dh[2 * kDec + n] + v;   // dL/dh3' = carried + residual path
+      };
+      tstamp(X, 0);
+      mv_store(kDec, X, mv_accum2<true>(so, kDec, kDec, X, pf, make_float4(0.f, 0.f, 0.f, 0.f)), S.part);
+      tstamp(X, 1);
+      lds_barrier();
+      phase_fin(kDec, S.part, X, XB_OUT, [&](int n, float y) { return y; }, o_put);
+      tstamp(X, 2);
+      prefetch_w(pf, w.cw[2], 2 * kDec, kDec, 2 * kDec, X);
+      phase_gather(kDec, X, XB_OUT, o_put);
+      tstamp(X, 3);
+      X.tslot++;
+    }
     lds_barrier();
     // 6. GRU layers, top down
     for (int l = 2; l >= 0; --l) {
@@ -1232,7 +1218,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
                 S.dh[l * kDec + n - kDec] += y;
               }
             },
-            pf, l > 0 ? NextMv{w.cw[l - 1], 2 * kDec, kDec, 2 * kDec} : (t > 0 ? nx_fa : NextMv{w.in_w, kPre2 + kAtt, kDec, kPre2}));
+            pf, l > 0 ? NextMv{w.cw[l - 1], 2 * kDec, kDec, 2 * kDec} : nx_dp2);
       lds_barrier();
     }
     if (lead && tid < kDec) gs[kGsX + tid] = S.dx[tid];

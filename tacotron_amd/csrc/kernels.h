@@ -256,9 +256,8 @@ int launch_decoder_fwd(DecFwdArgs a, hipStream_t s);
 
 struct DecBwdArgs {
   DecWeights wT;         // every matrix TRANSPOSED (out,in); biases unused
-  const float* fa;       // (256, NO)  [Wx_o^T | 0]: dx_{t+1} -> d cell_output_t   (NO = dec_fan_cols(r))
   const float* wot;      // (80r+512, 256)  [Wo^T ; (Wo Wq)^T ; (Wo[:, last frame] W1)^T]
-  int NO;
+  const float* wdx;      // (256, 256)  Wx_o^T Wo^T: dx_{t+1} -> d(x + h3)_t through cell_output_t
   const float* att_v;    // (256)
   const float* keys;
   const float* vwx;      // (B,Tt,256)  values . Wx_c:  d alignments_t[s] = vwx[s] . dx_{t+1}

@@ -246,6 +246,7 @@ void build_ws_layout(const TacoShape& s, bool train, const TransLayout& T, WsLay
     W.ds2s_tot = a.add("bwd.ds2s_tot", {MD, R80});
     W.bc_fa = a.add("bwd.comp.fa", {kDec, dec_fan_cols(s.r)});      // [Wx_o^T | 0]
     W.bc_wxct = a.add("bwd.comp.wxct", {kDec, kAtt});               // Wx_c^T
+    W.bc_wdx = a.add("bwd.comp.wdx", {kDec, kDec});                 // Wx_o^T Wo^T: dx_{t+1} -> d(x + h3)_t
     W.bc_wot = a.add("bwd.comp.wot", {R80 + 2 * kAtt, kDec});       // [Wo^T ; (Wo Wq)^T ; (Wo_f W1)^T]
     W.bc_g = a.add("bwd.comp.g", {R80 + kAtt, kDec});               // sum_t [out_t ; ctx_t]^T dx_{t+1}
     W.bc_h1 = a.add("bwd.comp.h1", {kDec, kAtt});                   // sum_t (x + h3)_t^T dq_t
@@ -267,7 +268,7 @@ void build_ws_layout(const TacoShape& s, bool train, const TransLayout& T, WsLay
     W.scratch = a.add("bwd.scratch", {64});
   } else {
     W.ds2s = W.dout_pad = W.paramsT = W.gstash = W.dkeys = W.dvalues = W.ds2s_tot = -1;
-    W.bc_wxct = -1;
+    W.bc_wxct = W.bc_wdx = -1;
     W.bc_fa = W.bc_wot = W.bc_g = W.bc_h1 = W.bc_h2 = W.bc_cq = W.bc_cp = W.dattv = -1;
     W.post_dpj1 = W.post_dz1 = W.post_dpool = W.post_dx = -1;
     W.gA = W.gB = W.gC = W.gD = W.gE = W.gF = W.gG = W.scratch = -1;

@@ -576,7 +576,9 @@ int build_dec_composites_bwd(const float* P, const ParamLayout& PL, const WsLayo
   job(P + PL.out_proj.w, R80, wot, kDec, kDec, R80);                                 // Wo^T
   job(ws + W.dc_wo, dec_out_cols(r), wot + (int64_t)R80 * kDec, kDec, kDec, kAtt);   // (Wo Wq)^T  (dc_wo is [Wo Wq | Wo | 0], pitch dec_out_cols)
   job(ws + W.dc_wp1o, kPre1, wot + (int64_t)(R80 + kAtt) * kDec, kDec, kDec, kPre1); // (Wo_f W1)^T
-  return launch_transpose_batch(tb, s);
+  TACO_TRY(launch_transpose_batch(tb, s));
+  // dx_{t+1} -> d cell_output_t -> d(x + h3)_t without the stop in between: Wx_o^T Wo^T = fa[:, 0:80r] . wot[0:80r, :]
+  return launch_conv_gemm(dense_problem(fa, NO, wot, kDec, nullptr, ws + W.bc_wdx, kDec, kDec, kDec, R80, TACO_ACT_NONE), s);
 }
 
 struct BwdScratch {
@@ -938,7 +940,7 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     }
     w.out_w = PT + TL.out_proj; w.q_w = PT + TL.q_w; w.att_w = PT + TL.att_w; w.att_v = P + PL.att_v;
     a.att_v = P + PL.att_v;
-    a.fa = ws + W.bc_fa; a.wot = ws + W.bc_wot; a.NO = dec_fan_cols(r);
+    a.wot = ws + W.bc_wot; a.wdx = ws + W.bc_wdx;
     a.keys = ws + W.keys; a.vwx = ws + W.vwxc; a.text_length = text_length;
     a.keep1 = dec_keep1; a.keep2 = dec_keep2; a.sample = sample;
     a.dout = dS2S; a.out = seq2seq_output; a.align = alignments; a.stash = st; a.gstash = gs;
@@ -949,6 +951,15 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     const int slot = prof_begin(1, s);
     TACO_TRY(launch_decoder_bwd(a, s));
     prof_end(1, slot, s);
+    // total d cell_output_t = direct part + dx_{t+1} Wx_o^T  (the kernel carries the second term straight into d(x + h3); the
+    // sum is what the output projection's weight gradient below needs): one GEMM over the B*Td rows, A row t+1 against row t
+    {
+      ConvGemmProblem p = dense_problem(gs + kGsX, kGsRec, ws + W.bc_fa, dec_fan_cols(r), nullptr, gs + kGsO, kGsRec, MD, R80, kDec,
+                                        TACO_ACT_NONE);
+      p.T = Td; p.pad_l = -1;
+      p.residual = dS2S; p.ldr = R80;
+      TACO_TRY(launch_conv_gemm(p, s));
+    }
     // d attention_v = sum over batch rows of the kernel's per-row partials, in row order (no atomics)
     TACO_TRY(launch_colsum_batched(ws + W.dattv, kAtt, G + PL.att_v, 1, B, kAtt, s));
     // the scratch buffers the deferred post-net GEMMs read are reused from here on
