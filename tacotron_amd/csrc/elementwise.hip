@@ -327,21 +327,47 @@ __global__ void mask_rows_kernel(const float* __restrict__ x, const int32_t* __r
 // order (reproducible).  Used for the attention memory of the decoder backward: d alignments only matter up to a per-step
 // constant (the softmax backward removes the alignment-weighted mean), and removing the rows' common component BEFORE the
 // fold with Wx_c keeps the per-row rounding errors relative to what the softmax backward actually sees.
-__global__ void center_rows_kernel(const float* __restrict__ x, const int32_t* __restrict__ len, float* __restrict__ out,
-                                   int T, int C) {
+__global__ __launch_bounds__(256) void center_rows_kernel(const float* __restrict__ x, const int32_t* __restrict__ len,
+                                                          float* __restrict__ out, int T, int C) {
+  // block = 4 row lanes x 64 column quads (256 columns); grid = (C/256 ceil, B, 4 row quarters).  Every block forms the column
+  // means of its sequence itself (lane l sums rows l, l+4, ...; the four lanes are added in a fixed order: reproducible) and
+  // writes one quarter of the rows.
+  __shared__ float4 red[3][64];
   const int b = blockIdx.y;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int q = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c4 = blockIdx.x * 64 + q, C4 = C >> 2;
+  const bool act = c4 < C4;
   int n = len[b];
   n = n < 1 ? 1 : (n > T ? T : n);
-  const float* xb = x + (int64_t)b * T * C + c;
-  float* ob = out + (int64_t)b * T * C + c;
-  float acc = 0.f;
+  const float4* xb = reinterpret_cast<const float4*>(x + (int64_t)b * T * C) + (act ? c4 : 0);
+  float4* ob = reinterpret_cast<float4*>(out + (int64_t)b * T * C) + (act ? c4 : 0);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 8
-  for (int s = 0; s < n; ++s) acc += xb[(int64_t)s * C];
-  const float mean = acc / (float)n;
-#pragma unroll 8
-  for (int s = 0; s < T; ++s) ob[(int64_t)s * C] = s < n ? xb[(int64_t)s * C] - mean : 0.f;
+  for (int s = rl; s < n; s += 4) {
+    const float4 v = xb[(int64_t)s * C4];
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  if (rl > 0) red[rl - 1][q] = acc;
+  __syncthreads();
+  if (rl == 0) {
+    for (int l = 0; l < 3; ++l) { acc.x += red[l][q].x; acc.y += red[l][q].y; acc.z += red[l][q].z; acc.w += red[l][q].w; }
+    const float inv = 1.0f / (float)n;
+    red[0][q] = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+  }
+  __syncthreads();
+  const float4 mean = red[0][q];
+  if (!act) return;
+  const int per = (T + gridDim.z - 1) / gridDim.z;
+  const int s0 = blockIdx.z * per, s1 = min(T, s0 + per);
+#pragma unroll 4
+  for (int s = s0 + rl; s < s1; s += 4) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (s < n) {
+      v = xb[(int64_t)s * C4];
+      v.x -= mean.x; v.y -= mean.y; v.z -= mean.z; v.w -= mean.w;
+    }
+    ob[(int64_t)s * C4] = v;
+  }
 }
 
 __global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int64_t n) {
@@ -551,7 +577,8 @@ int launch_embedding_bwd(const float* dout, const int32_t* ids, float* dtable, i
   return TACO_OK;
 }
 int launch_center_rows(const float* x, const int32_t* len, float* out, int B, int T, int C, hipStream_t s) {
-  hipLaunchKernelGGL(center_rows_kernel, dim3((C + 255) / 256, B), dim3(256), 0, s, x, len, out, T, C);
+  TACO_REQUIRE(C % 4 == 0, "center_rows: C %% 4 != 0");
+  hipLaunchKernelGGL(center_rows_kernel, dim3((C + 255) / 256, B, 4), dim3(256), 0, s, x, len, out, T, C);
   TACO_LAUNCH_CHECK("center_rows");
   return TACO_OK;
 }

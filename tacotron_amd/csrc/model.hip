@@ -393,8 +393,7 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
   TACO_TRY(cbhg_fwd(P, PL.enc, ws + W.p2, B, Tt, eb, train, s));
   // attention memory (BahdanauAttention.__init__; tacotron.py:48-52)
   TACO_TRY(launch_mask_rows(eb.out, text_length, ws + W.values, B, Tt, kAtt, s));
-  TACO_TRY(launch_conv_gemm(dense_problem(ws + W.values, kAtt, P + PL.mem_w, kAtt, nullptr, ws + W.keys, kAtt, M1, kAtt,
-                                          2 * kCb, TACO_ACT_NONE), s));
+  // (keys = values . Wm rides in the same grouped launch as the context folds below: three products of `values`)
   // decoder (tacotron.py:134-138)
   TACO_TRY(side_join(s, sd));
   DecFwdArgs da;
@@ -404,15 +403,18 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
     // context = alignments . values only ever enters the next step through Wx_c (and Wx_c Wg0_x): fold it per memory row, once
     // per call, so that the decoder step needs no context mat-vec / all-gather round (decoder.hip)
     const int KA = kPre2 + R80;
-    ConvGemmBatch vb;
-    vb.n = train ? 3 : 2;
     if (train) {
       // backward twin: the same fold of the CENTRED memory rows (d alignments are only defined up to a per-step constant;
-      // centring first keeps the rounding of each row's fold relative to what survives the softmax backward)
-      TACO_TRY(launch_center_rows(ws + W.values, text_length, ws + W.vcen, B, Tt, kAtt, s));
-      vb.p[2] = dense_problem(ws + W.vcen, kAtt, da.c.wx + (int64_t)KA * kDec, kDec, nullptr, ws + W.vwxc, kDec, M1, kDec, kAtt,
-                              TACO_ACT_NONE);
+      // centring first keeps the rounding of each row's fold relative to what survives the softmax backward).  Only
+      // taco_backward reads it: side stream, joined at the end of the forward pass.
+      hipStream_t sv = side_fork(s);
+      TACO_TRY(launch_center_rows(ws + W.values, text_length, ws + W.vcen, B, Tt, kAtt, sv));
+      TACO_TRY(launch_conv_gemm(dense_problem(ws + W.vcen, kAtt, da.c.wx + (int64_t)KA * kDec, kDec, nullptr, ws + W.vwxc, kDec, M1,
+                                              kDec, kAtt, TACO_ACT_NONE), sv));
     }
+    ConvGemmBatch vb;
+    vb.n = 3;
+    vb.p[2] = dense_problem(ws + W.values, kAtt, P + PL.mem_w, kAtt, nullptr, ws + W.keys, kAtt, M1, kAtt, 2 * kCb, TACO_ACT_NONE);
     vb.p[0] = dense_problem(ws + W.values, kAtt, da.c.wx + (int64_t)KA * kDec, kDec, nullptr, ws + W.vwx, kDec, M1, kDec, kAtt,
                             TACO_ACT_NONE);
     vb.p[1] = dense_problem(ws + W.values, kAtt, da.c.wg0 + (int64_t)(KA + kDec) * 2 * kDec, 2 * kDec, nullptr, ws + W.vwg, 2 * kDec,
