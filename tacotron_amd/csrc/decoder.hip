@@ -933,7 +933,8 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
   len = len < 1 ? 1 : (len > Tt ? Tt : len);
   const float* keys = a.keys + (int64_t)b * Tt * kAtt;
   const float* vwx = a.vwx + (int64_t)b * Tt * kDec;   // this row's values . Wx_c
-  float* dkeys = a.dkeys + (int64_t)b * Tt * kAtt;
+  float* dkeys = a.dkeys + (int64_t)b * Tt * a.ldk;
+  const int ldk = a.ldk;
 
   for (int i = tid; i < 768; i += NT) S.dh[i] = 0.f;
   if (tid < 256) S.dx[tid] = 0.f;
@@ -1105,7 +1106,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
           const float th = tanh_fast(keys[(int64_t)s * kAtt + ub + ul] + qu);
           const float pre = de * vu * (1.f - th * th);
           dqa += pre;
-          dkeys[(int64_t)s * kAtt + ub + ul] += pre;
+          dkeys[(int64_t)s * ldk + ub + ul] += pre;
           dvu += de * th;
         }
         S.red[sg * un + ul] = dqa;
@@ -1242,7 +1243,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
 #pragma unroll
     for (int i = 0; i < kKR; ++i) {
       const int s = sg + i * NSG;
-      if (s < len) dkeys[(int64_t)s * kAtt + ub + ul] = dkr[i];
+      if (s < len) dkeys[(int64_t)s * ldk + ub + ul] = dkr[i];
     }
     S.red[sg * un + ul] = dvu;
   }

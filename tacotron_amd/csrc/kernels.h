@@ -270,7 +270,8 @@ struct DecBwdArgs {
   const float* align;    // (B,Td,Tt)
   const float* stash;    // (B,Td,kStRec)
   float* gstash;         // (B,Td,kGsRec)
-  float* dkeys;          // (B,Tt,256) zero-initialised, accumulated
+  float* dkeys;          // (B,Tt,256) with row pitch ldk, zero-initialised, accumulated
+  int ldk;
   float* datt_v;         // (B,256) per-row partial gradients of attention_v (written, not accumulated)
   void* xchg;
   int* err;

@@ -91,7 +91,7 @@ struct WsLayout {
   int64_t loss;  // 4 floats
   // backward
   int64_t ds2s, dout_pad, paramsT, gstash, dkeys, dvalues, ds2s_tot;
-  int64_t bc_wxct, bc_wdx;
+  int64_t bc_wxct, bc_wdx, bc_wmx;
   int64_t bc_fa, bc_wot, bc_g, bc_h1, bc_h2, bc_cq, bc_cp;   // decoder backward composites and small weight-gradient factors
   int64_t dattv;      // (B,256) per-row attention_v gradient partials
   int64_t post_dpj1, post_dz1, post_dpool, post_dx;   // post-net backward operands that outlive cbhg_bwd (deferred weight gradients)

@@ -241,11 +241,14 @@ void build_ws_layout(const TacoShape& s, bool train, const TransLayout& T, WsLay
     W.dout_pad = a.add("bwd.dout_pad", {M2, 1028});
     W.paramsT = a.add("bwd.paramsT", {T.total});
     W.gstash = a.add("bwd.gstash", {MD, kGsRec});
-    W.dkeys = a.add("bwd.dkeys", {M1, kAtt});
-    W.dvalues = a.add("bwd.dvalues", {M1, kAtt});                    // E[b] = sum_t al_{t-1}^T dx_t  (d values = E Wx_c^T)
+    // one (M1, 512) buffer: columns [0,256) d keys (decoder backward kernel), [256,512) E[b] = sum_t al_{t-1}^T dx_t; the
+    // encoder-output gradient is then ONE product [d keys | E] . [Wm^T ; Wx_c^T]
+    W.dkeys = a.add("bwd.dkeys_e", {M1, 2 * kAtt});
+    W.dvalues = W.dkeys + kAtt;
     W.ds2s_tot = a.add("bwd.ds2s_tot", {MD, R80});
     W.bc_fa = a.add("bwd.comp.fa", {kDec, dec_fan_cols(s.r)});      // [Wx_o^T | 0]
-    W.bc_wxct = a.add("bwd.comp.wxct", {kDec, kAtt});               // Wx_c^T
+    W.bc_wmx = a.add("bwd.comp.wmx", {2 * kAtt, 2 * kCb});          // [Wm^T ; Wx_c^T]
+    W.bc_wxct = W.bc_wmx + (int64_t)kAtt * 2 * kCb;
     W.bc_wdx = a.add("bwd.comp.wdx", {kDec, kDec});                 // Wx_o^T Wo^T: dx_{t+1} -> d(x + h3)_t
     W.bc_wot = a.add("bwd.comp.wot", {R80 + 2 * kAtt, kDec});       // [Wo^T ; (Wo Wq)^T ; (Wo_f W1)^T]
     W.bc_g = a.add("bwd.comp.g", {R80 + kAtt, kDec});               // sum_t [out_t ; ctx_t]^T dx_{t+1}
@@ -268,7 +271,7 @@ void build_ws_layout(const TacoShape& s, bool train, const TransLayout& T, WsLay
     W.scratch = a.add("bwd.scratch", {64});
   } else {
     W.ds2s = W.dout_pad = W.paramsT = W.gstash = W.dkeys = W.dvalues = W.ds2s_tot = -1;
-    W.bc_wxct = W.bc_wdx = -1;
+    W.bc_wxct = W.bc_wdx = W.bc_wmx = -1;
     W.bc_fa = W.bc_wot = W.bc_g = W.bc_h1 = W.bc_h2 = W.bc_cq = W.bc_cp = W.dattv = -1;
     W.post_dpj1 = W.post_dz1 = W.post_dpool = W.post_dx = -1;
     W.gA = W.gB = W.gC = W.gD = W.gE = W.gF = W.gG = W.scratch = -1;

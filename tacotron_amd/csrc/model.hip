@@ -573,7 +573,8 @@ int build_dec_composites_bwd(const float* P, const ParamLayout& PL, const WsLayo
     j.in = in; j.out = out; j.taps = 1; j.K = K; j.N = N; j.tile0 = 0; j.ldi = ldi; j.ldo = ldo;
   };
   const float* wx = ws + W.dc_wx;
-  job(wx + (int64_t)(kPre2 + R80) * kDec, kDec, ws + W.bc_wxct, kAtt, kAtt, kDec);   // Wx_c^T
+  job(P + PL.mem_w, kAtt, ws + W.bc_wmx, 2 * kCb, 2 * kCb, kAtt);                     // Wm^T     } stacked: [d keys | E] . [Wm^T ; Wx_c^T]
+  job(wx + (int64_t)(kPre2 + R80) * kDec, kDec, ws + W.bc_wxct, kAtt, kAtt, kDec);   // Wx_c^T   }
   job(wx + (int64_t)kPre2 * kDec, kDec, fa, NO, R80, kDec);                          // Wx_o^T -> fa[:, 0:80r]
   job(P + PL.out_proj.w, R80, wot, kDec, kDec, R80);                                 // Wo^T
   job(ws + W.dc_wo, dec_out_cols(r), wot + (int64_t)R80 * kDec, kDec, kDec, kAtt);   // (Wo Wq)^T  (dc_wo is [Wo Wq | Wo | 0], pitch dec_out_cols)
@@ -856,8 +857,8 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
   float* PT = ws + W.paramsT;
 
   hipError_t e = hipMemsetAsync(G, 0, (size_t)PL.total * sizeof(float), s);
-  if (e == hipSuccess)   // dkeys and dvalues are neighbours in the workspace: one fill
-    e = hipMemsetAsync(ws + W.dkeys, 0, (size_t)(W.dvalues + (int64_t)M1 * kAtt - W.dkeys) * sizeof(float), s);
+  if (e == hipSuccess)   // [d keys | E]: one (M1, 512) buffer, one fill
+    e = hipMemsetAsync(ws + W.dkeys, 0, (size_t)M1 * 2 * kAtt * sizeof(float), s);
   if (e != hipSuccess) {
     taco_set_error("taco_backward: memset: %s", hipGetErrorString(e));
     return TACO_ELAUNCH;
@@ -946,24 +947,13 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     a.keys = ws + W.keys; a.vwx = ws + W.vwxc; a.text_length = text_length;
     a.keep1 = dec_keep1; a.keep2 = dec_keep2; a.sample = sample;
     a.dout = dS2S; a.out = seq2seq_output; a.align = alignments; a.stash = st; a.gstash = gs;
-    a.dkeys = ws + W.dkeys; a.datt_v = ws + W.dattv;
+    a.dkeys = ws + W.dkeys; a.ldk = 2 * kAtt; a.datt_v = ws + W.dattv;
     a.xchg = ws + W.xchg; a.err = reinterpret_cast<int*>(ws + W.err) + 1;
     a.trace = getenv("TACO_DEC_TRACE") ? reinterpret_cast<long long*>(ws + W.err + 16) + 128 : nullptr;
     a.B = B; a.Tt = Tt; a.Td = Td; a.r = r; a.P = 1;
     const int slot = prof_begin(1, s);
     TACO_TRY(launch_decoder_bwd(a, s));
     prof_end(1, slot, s);
-    // total d cell_output_t = direct part + dx_{t+1} Wx_o^T  (the kernel carries the second term straight into d(x + h3); the
-    // sum is what the output projection's weight gradient below needs): one GEMM over the B*Td rows, A row t+1 against row t
-    {
-      ConvGemmProblem p = dense_problem(gs + kGsX, kGsRec, ws + W.bc_fa, dec_fan_cols(r), nullptr, gs + kGsO, kGsRec, MD, R80, kDec,
-                                        TACO_ACT_NONE);
-      p.T = Td; p.pad_l = -1;
-      p.residual = dS2S; p.ldr = R80;
-      TACO_TRY(launch_conv_gemm(p, s));
-    }
-    // d attention_v = sum over batch rows of the kernel's per-row partials, in row order (no atomics)
-    TACO_TRY(launch_colsum_batched(ws + W.dattv, kAtt, G + PL.att_v, 1, B, kAtt, s));
     // the scratch buffers the deferred post-net GEMMs read are reused from here on
     if (defer && hipStreamWaitEvent(s, ssx.ev_post, 0) != hipSuccess) {
       taco_set_error("taco_backward: event wait failed");
@@ -976,23 +966,14 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
   //      keys = values . Wm ----
   {
     GemmTnArgs a;
-    a.A = alignments; a.lda = Tt; a.Y = gs + kGsX; a.ldy = kGsRec; a.W = ws + W.dvalues; a.ldw = kAtt;
+    a.A = alignments; a.lda = Tt; a.Y = gs + kGsX; a.ldy = kGsRec; a.W = ws + W.dvalues; a.ldw = 2 * kAtt;
     a.M = Td; a.N = kDec; a.K = Tt; a.taps = 1; a.T = Td; a.pad_l = 1; a.batch = B;
-    a.strideA = (int64_t)Td * Tt; a.strideY = (int64_t)Td * kGsRec; a.strideW = (int64_t)Tt * kAtt;
+    a.strideA = (int64_t)Td * Tt; a.strideY = (int64_t)Td * kGsRec; a.strideW = (int64_t)Tt * 2 * kAtt;
     TACO_TRY(launch_gemm_tn(a, false, s));
   }
-  TACO_TRY(tn(ws + W.values, kAtt, 2 * kCb, ws + W.dkeys, kAtt, kAtt, G + PL.mem_w, kAtt, M1, M1, 0, s));
-  float* dValTot = sc.gE;   // (M1,256)
-  {
-    ConvGemmProblem p0 = dense_problem(ws + W.dvalues, kAtt, ws + W.bc_wxct, kAtt, nullptr, dValTot, 2 * kCb, M1, kAtt, kDec,
-                                       TACO_ACT_NONE);
-    TACO_TRY(launch_conv_gemm(p0, s));
-    ConvGemmProblem p = dense_problem(ws + W.dkeys, kAtt, PT + TL.mem_w, 2 * kCb, nullptr, dValTot, 2 * kCb, M1, 2 * kCb, kAtt,
-                                      TACO_ACT_NONE);
-    p.residual = dValTot;
-    p.ldr = 2 * kCb;
-    TACO_TRY(launch_conv_gemm(p, s));
-  }
+  float* dValTot = sc.gE;   // (M1,256) = d keys Wm^T + E Wx_c^T
+  TACO_TRY(launch_conv_gemm(dense_problem(ws + W.dkeys, 2 * kAtt, ws + W.bc_wmx, 2 * kCb, nullptr, dValTot, 2 * kCb, M1, 2 * kCb,
+                                          2 * kAtt, TACO_ACT_NONE), s));
   float* dEnc = sc.gG;      // (M1,256)
   TACO_TRY(launch_mask_rows(dValTot, text_length, dEnc, B, Tt, 2 * kCb, s));
   // ---- decoder weight gradients: dense GEMMs over the B*Td stashed rows, all independent -> one grouped launch, on the
@@ -1001,7 +982,19 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
   {
     hipStream_t main_s = s;
     hipStream_t s = side_fork(main_s);   // shadows the main stream inside this block
+    // total d cell_output_t = direct part + dx_{t+1} Wx_o^T  (the kernel carries the second term straight into d(x + h3); the
+    // sum is what the output projection's weight gradient below needs): one GEMM over the B*Td rows, A row t+1 against row t
+    {
+      ConvGemmProblem p = dense_problem(gs + kGsX, kGsRec, ws + W.bc_fa, dec_fan_cols(r), nullptr, gs + kGsO, kGsRec, MD, R80, kDec,
+                                        TACO_ACT_NONE);
+      p.T = Td; p.pad_l = -1;
+      p.residual = ws + W.ds2s_tot; p.ldr = R80;
+      TACO_TRY(launch_conv_gemm(p, s));
+    }
+    // d attention_v = sum over batch rows of the kernel's per-row partials, in row order (no atomics)
+    TACO_TRY(launch_colsum_batched(ws + W.dattv, kAtt, G + PL.att_v, 1, B, kAtt, s));
     TnGroup dec_group(s);
+    TACO_TRY(tn(ws + W.values, kAtt, 2 * kCb, ws + W.dkeys, 2 * kAtt, kAtt, G + PL.mem_w, kAtt, M1, M1, 0, s));   // d Wm = values^T d keys
     const float* prein = ws + W.prein;
     TACO_TRY(tn(prein, kMel, kMel, gs + kGsP1, kGsRec, kPre1, G + PL.dec_pre1.w, kPre1, MD, Td, 0, s, 1, G + PL.dec_pre1.b));
     TACO_TRY(tn(st + kStP1, kStRec, kPre1, gs + kGsP2, kGsRec, kPre2, G + PL.dec_pre2.w, kPre2, MD, Td, 0, s, 1, G + PL.dec_pre2.b));
@@ -1009,7 +1002,7 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     // from Gx = sum_t [cell_output ; context]_{t-1}^T dx_t below: the kernel never forms the attention vector or its gradient.
     TACO_TRY(tn(st + kStP2, kStRec, kPre2, gs + kGsX, kGsRec, kDec, G + PL.in_proj.w, kDec, MD, Td, 0, s, 1, G + PL.in_proj.b));
     TACO_TRY(tn(seq2seq_output, R80, R80, gs + kGsX, kGsRec, kDec, ws + W.bc_g, kDec, MD, Td, 1, s));
-    TACO_TRY(tn(ws + W.values, kAtt, kAtt, ws + W.dvalues, kAtt, kDec, ws + W.bc_g + (int64_t)R80 * kDec, kDec, M1, M1, 0, s));
+    TACO_TRY(tn(ws + W.values, kAtt, kAtt, ws + W.dvalues, 2 * kAtt, kDec, ws + W.bc_g + (int64_t)R80 * kDec, kDec, M1, M1, 0, s));
     for (int l = 0; l < 3; ++l) {
       const float* inp = l == 0 ? st + kStX : st + kStH + (l - 1) * kDec;
       const float* dG = gs + kGsG + l * 512;
