@@ -37,6 +37,14 @@ typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) u64 gu64;
 typedef __attribute__((address_space(1))) int gi32;
 
+// TIMING PROBES (garbage results, real timing; tools/dec_probe.py) exist only in the probe build (-DTACO_DEC_PROBES ->
+// libtaco_probe.so): compiled into the production kernels their branches cost 1.4 us per step (instruction-cache footprint).
+#ifdef TACO_DEC_PROBES
+constexpr bool kProbes = true;
+#else
+constexpr bool kProbes = false;
+#endif
+
 struct Xchg {
   u64* base;        // this row's granule area
   unsigned epoch;   // step tag, never 0
@@ -46,8 +54,11 @@ struct Xchg {
   int* dead;        // LDS: set once this workgroup has given up polling
   long long* trace; // optional: 4 wall_clock64 stamps per phase (enabled for one workgroup at one step), else null
   int tslot;
-  int fake;         // TIMING PROBE ONLY (TACO_DEC_FAKEW=1): every weight row aliases row 0 (L1 hits), results are garbage
+  int fake;         // probe build only.  1 (TACO_DEC_FAKEW): every weight row aliases row 0 (L1 hits); 2 (TACO_DEC_FAKEX): no polling;
+                    // 8 (TACO_DEC_NOPF): prefetched rows cost no memory traffic; 16 (TACO_DEC_NOLIVE): nor do the live rows
 };
+
+__device__ __forceinline__ bool probe(const Xchg& X, int bit) { return kProbes && (X.fake & bit) != 0; }
 
 // stamp k (0 entry, 1 partials done, 2 own slice published, 3 gather done) of the current phase
 __device__ __forceinline__ void tstamp(const Xchg& X, int k) {
@@ -60,7 +71,7 @@ __device__ __forceinline__ void xput(const Xchg& X, int idx, float v) {
 }
 __device__ __forceinline__ float xget(const Xchg& X, int idx) {
   if (*X.dead) return 0.f;
-  if (X.fake & 2) return 0.f;   // timing probe: no polling at all
+  if (probe(X, 2)) return 0.f;   // timing probe: no polling at all
   gu64* g = (gu64*)(X.base + idx);
   for (unsigned spin = 0;; ++spin) {
     const u64 x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -89,7 +100,7 @@ __device__ __forceinline__ void tmark(const Xchg& X, int id) {
 __device__ __forceinline__ void xget2(const Xchg& X, int idxA, bool needA, int idxB, bool needB, float& vA, float& vB) {
   vA = vB = 0.f;
   if (*X.dead) return;
-  if (X.fake & 2) return;
+  if (probe(X, 2)) return;
   gu64* gA = (gu64*)(X.base + idxA);
   gu64* gB = (gu64*)(X.base + idxB);
   for (unsigned spin = 0; needA || needB; ++spin) {
@@ -161,6 +172,7 @@ __device__ __forceinline__ void prefetch_w(Pref& pf, const float* __restrict__ W
   const Slice S = slice_of(X, N);
   const int kg = tid >> S.lg4, c4 = tid & (S.n4 - 1);
   pf.W = W;
+  if (probe(X, 8)) return;   // timing probe: the prefetched rows cost no memory traffic at all (registers keep stale values)
   {
     const int Kc = (((K + (1 << S.lgKG) - 1) >> S.lgKG) + 3) & ~3;
     const int k0 = kg * Kc;
@@ -169,7 +181,7 @@ __device__ __forceinline__ void prefetch_w(Pref& pf, const float* __restrict__ W
 #pragma unroll
     for (int i = 0; i < kPF; ++i) {
       const bool ok = k0 + i < k1;
-      pf.w[i] = *reinterpret_cast<const float4*>(wp + (int64_t)(ok && !(X.fake & 1) ? k0 + i : 0) * ldw);   // clamped address, value unused if !ok
+      pf.w[i] = *reinterpret_cast<const float4*>(wp + (int64_t)(ok && !(probe(X, 1)) ? k0 + i : 0) * ldw);   // clamped address, value unused if !ok
     }
   }
 }
@@ -180,7 +192,7 @@ __device__ __forceinline__ void prefetch_w(Pref& pf, const float* __restrict__ W
 template <bool PF>
 __device__ __forceinline__ float4 mv_accum(const float* __restrict__ W, int ldw, int K, int N, const float* x, const Xchg& X,
                                            const Pref& pf, float4 acc) {
-  if (X.fake & 1) ldw = 0;
+  if (probe(X, 1)) ldw = 0;
   const int tid = opaque_tid();
   const Slice S = slice_of(X, N);
   const int n4 = S.n4;
@@ -204,6 +216,16 @@ __device__ __forceinline__ float4 mv_accum(const float* __restrict__ W, int ldw,
           k += 4;
           wp += 4 * (int64_t)ldw;
         }
+      }
+    }
+    if (probe(X, 16)) {   // timing probe: the live rows cost no memory traffic (same FMAs and LDS reads on a constant)
+      const float4 wc = make_float4(1.f, 2.f, 3.f, 4.f);
+      for (; k + 3 < k1; k += 4) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + k);
+        acc.x = fmaf(xv.x, wc.x, acc.x); acc.y = fmaf(xv.x, wc.y, acc.y); acc.z = fmaf(xv.x, wc.z, acc.z); acc.w = fmaf(xv.x, wc.w, acc.w);
+        acc.x = fmaf(xv.y, wc.x, acc.x); acc.y = fmaf(xv.y, wc.y, acc.y); acc.z = fmaf(xv.y, wc.z, acc.z); acc.w = fmaf(xv.y, wc.w, acc.w);
+        acc.x = fmaf(xv.z, wc.x, acc.x); acc.y = fmaf(xv.z, wc.y, acc.y); acc.z = fmaf(xv.z, wc.z, acc.z); acc.w = fmaf(xv.z, wc.w, acc.w);
+        acc.x = fmaf(xv.w, wc.x, acc.x); acc.y = fmaf(xv.w, wc.y, acc.y); acc.z = fmaf(xv.w, wc.z, acc.z); acc.w = fmaf(xv.w, wc.w, acc.w);
       }
     }
 #pragma unroll 2
@@ -242,6 +264,7 @@ __device__ __forceinline__ void prefetch_w2(Pref& pf, const Seg2& g, int ldw, in
   const int kg = tid >> S.lg4, c4 = tid & (S.n4 - 1);
   const int K = g.K1 + g.K2;
   pf.W = g.W1;
+  if (probe(X, 8)) return;
   const int Kc = (((K + (1 << S.lgKG) - 1) >> S.lgKG) + 3) & ~3;
   const int k0 = kg * Kc;
   const int k1 = min(K, k0 + Kc);
@@ -249,14 +272,14 @@ __device__ __forceinline__ void prefetch_w2(Pref& pf, const Seg2& g, int ldw, in
 #pragma unroll
   for (int i = 0; i < kPF; ++i) {
     const int k = k0 + i;
-    const bool ok = k < k1 && !(X.fake & 1);
+    const bool ok = k < k1 && !(probe(X, 1));
     const float* row = (k < g.K1 ? g.W1 + (int64_t)(ok ? k : 0) * ldw : g.W2 + (int64_t)(ok ? k - g.K1 : 0) * ldw);
     pf.w[i] = *reinterpret_cast<const float4*>(row + col);   // clamped address, value unused if !ok
   }
 }
 template <bool PF>
 __device__ __forceinline__ float4 mv_accum2(const Seg2& g, int ldw, int N, const Xchg& X, const Pref& pf, float4 acc) {
-  if (X.fake & 1) ldw = 0;
+  if (probe(X, 1)) ldw = 0;
   const int tid = opaque_tid();
   const Slice S = slice_of(X, N);
   const int kg = tid >> S.lg4, c4 = tid & (S.n4 - 1);
@@ -278,6 +301,16 @@ __device__ __forceinline__ float4 mv_accum2(const Seg2& g, int ldw, int N, const
         acc.x = fmaf(xv.w, w3.x, acc.x); acc.y = fmaf(xv.w, w3.y, acc.y); acc.z = fmaf(xv.w, w3.z, acc.z); acc.w = fmaf(xv.w, w3.w, acc.w);
         k += 4;
       }
+    }
+  }
+  if (probe(X, 16)) {
+    const float4 wc = make_float4(1.f, 2.f, 3.f, 4.f);
+    for (; k + 3 < k1; k += 4) {
+      const float4 xv = *reinterpret_cast<const float4*>(k < g.K1 ? g.x1 + k : g.x2 + (k - g.K1));
+      acc.x = fmaf(xv.x, wc.x, acc.x); acc.y = fmaf(xv.x, wc.y, acc.y); acc.z = fmaf(xv.x, wc.z, acc.z); acc.w = fmaf(xv.x, wc.w, acc.w);
+      acc.x = fmaf(xv.y, wc.x, acc.x); acc.y = fmaf(xv.y, wc.y, acc.y); acc.z = fmaf(xv.y, wc.z, acc.z); acc.w = fmaf(xv.y, wc.w, acc.w);
+      acc.x = fmaf(xv.z, wc.x, acc.x); acc.y = fmaf(xv.z, wc.y, acc.y); acc.z = fmaf(xv.z, wc.z, acc.z); acc.w = fmaf(xv.z, wc.w, acc.w);
+      acc.x = fmaf(xv.w, wc.x, acc.x); acc.y = fmaf(xv.w, wc.y, acc.y); acc.z = fmaf(xv.w, wc.z, acc.z); acc.w = fmaf(xv.w, wc.w, acc.w);
     }
   }
 #pragma unroll 2
@@ -1280,6 +1313,11 @@ int pick_cluster(K kernel, size_t smem, int B, int want) {
 // Training uses at most 8 peers so that results are bit-identical for every per-GPU batch <= 32 (the summation order
 // depends on the cluster width; data-parallel shards of a batch must reproduce the unsharded gradients exactly).  Inference
 // has no such contract and takes 16 peers when they fit (B <= 16): -7 % per decoder step.  TACO_DEC_CLUSTER overrides.
+int probe_bits() {
+  if (!kProbes) return 0;
+  return (getenv("TACO_DEC_FAKEW") ? 1 : 0) | (getenv("TACO_DEC_FAKEX") ? 2 : 0) | (getenv("TACO_DEC_NOPF") ? 8 : 0) |
+         (getenv("TACO_DEC_NOLIVE") ? 16 : 0);
+}
 int env_cluster(int dflt) {
   const char* e = getenv("TACO_DEC_CLUSTER");
   if (!e) return dflt;
@@ -1314,7 +1352,7 @@ int launch_decoder_fwd(DecFwdArgs a, hipStream_t s) {
   }
   a.P = pick_cluster(kern, smem, a.B, env_cluster(a.mel ? 8 : 16));
   g_last_cluster[0] = a.P;
-  a.fakew = (getenv("TACO_DEC_FAKEW") ? 1 : 0) | (getenv("TACO_DEC_FAKEX") ? 2 : 0);
+  a.fakew = probe_bits();
   if (a.P > 1) {
     hipError_t e = hipMemsetAsync(a.xchg, 0, (size_t)decoder_xchg_bytes(a.B, a.Tt), s);
     if (e != hipSuccess) {
@@ -1344,7 +1382,7 @@ int launch_decoder_bwd(DecBwdArgs a, hipStream_t s) {
   }
   a.P = pick_cluster(kern, smem, a.B, env_cluster(8));
   g_last_cluster[1] = a.P;
-  a.fakew = (getenv("TACO_DEC_FAKEW") ? 1 : 0) | (getenv("TACO_DEC_FAKEX") ? 2 : 0);
+  a.fakew = probe_bits();
   if (a.P > 1) {
     hipError_t e = hipMemsetAsync(a.xchg, 0, (size_t)decoder_xchg_bytes(a.B, a.Tt), s);
     if (e != hipSuccess) {
