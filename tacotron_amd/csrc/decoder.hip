@@ -189,9 +189,11 @@ __device__ __forceinline__ void prefetch_w(Pref& pf, const float* __restrict__ W
 // Mat-vec of one (W, x) segment accumulated into `acc` (the thread's four columns over its k-chunk of THIS segment); several
 // segments with different matrices may feed one output vector (round G0: shared weights for [p2 ; out ; h1], the row's own
 // VW for the alignments).  mv_store then reduces over the k-groups of the wave and leaves the per-wave partials in `part`.
+// lw / lrows: launch-resident copy (LDS, one private float4 slot per thread and row: lw[i * NT + tid]) of rows kPF .. kPF+lrows-1
+// of this thread's k-chunk -- they follow the prefetched rows without touching the vector-memory pipe (lres_fill).
 template <bool PF>
 __device__ __forceinline__ float4 mv_accum(const float* __restrict__ W, int ldw, int K, int N, const float* x, const Xchg& X,
-                                           const Pref& pf, float4 acc) {
+                                           const Pref& pf, float4 acc, const float4* lw = nullptr, int lrows = 0) {
   if (probe(X, 1)) ldw = 0;
   const int tid = opaque_tid();
   const Slice S = slice_of(X, N);
@@ -215,6 +217,23 @@ __device__ __forceinline__ float4 mv_accum(const float* __restrict__ W, int ldw,
           acc.x = fmaf(xv.w, w3.x, acc.x); acc.y = fmaf(xv.w, w3.y, acc.y); acc.z = fmaf(xv.w, w3.z, acc.z); acc.w = fmaf(xv.w, w3.w, acc.w);
           k += 4;
           wp += 4 * (int64_t)ldw;
+        }
+      }
+      if (lw) {
+        const int tl = threadIdx.x;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          if (4 * g < lrows && k + 3 < k1) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + k);
+            const float4 w0 = lw[(4 * g + 0) * NT + tl], w1 = lw[(4 * g + 1) * NT + tl], w2 = lw[(4 * g + 2) * NT + tl],
+                         w3 = lw[(4 * g + 3) * NT + tl];
+            acc.x = fmaf(xv.x, w0.x, acc.x); acc.y = fmaf(xv.x, w0.y, acc.y); acc.z = fmaf(xv.x, w0.z, acc.z); acc.w = fmaf(xv.x, w0.w, acc.w);
+            acc.x = fmaf(xv.y, w1.x, acc.x); acc.y = fmaf(xv.y, w1.y, acc.y); acc.z = fmaf(xv.y, w1.z, acc.z); acc.w = fmaf(xv.y, w1.w, acc.w);
+            acc.x = fmaf(xv.z, w2.x, acc.x); acc.y = fmaf(xv.z, w2.y, acc.y); acc.z = fmaf(xv.z, w2.z, acc.z); acc.w = fmaf(xv.z, w2.w, acc.w);
+            acc.x = fmaf(xv.w, w3.x, acc.x); acc.y = fmaf(xv.w, w3.y, acc.y); acc.z = fmaf(xv.w, w3.z, acc.z); acc.w = fmaf(xv.w, w3.w, acc.w);
+            k += 4;
+            wp += 4 * (int64_t)ldw;
+          }
         }
       }
     }
@@ -250,6 +269,17 @@ __device__ __forceinline__ float4 mv_accum(const float* __restrict__ W, int ldw,
   }
   return acc;
 }
+// Copies rows kPF .. kPF+lrows-1 of every thread's k-chunk of mat-vec (W, K, N) into its private LDS slots (once per launch).
+__device__ __forceinline__ void lres_fill(float4* lw, int lrows, const float* __restrict__ W, int ldw, int K, int N, const Xchg& X) {
+  const int tid = threadIdx.x;
+  const Slice S = slice_of(X, N);
+  const int kg = tid >> S.lg4, c4 = tid & (S.n4 - 1);
+  const int Kc = (((K + (1 << S.lgKG) - 1) >> S.lgKG) + 3) & ~3;
+  const int k0 = kg * Kc + kPF, k1 = min(K, kg * Kc + Kc);
+  const float* wp = W + (S.g0 + c4) * 4;
+  for (int i = 0; i < lrows; ++i) lw[i * NT + tid] = *reinterpret_cast<const float4*>(wp + (int64_t)(k0 + i < k1 ? k0 + i : 0) * ldw);
+}
+
 // Two (W, x) segments with the same pitch treated as ONE K range [0, K1 + K2) (K1 % 4 == 0): the k-groups split the
 // concatenation, so a thread's chunk is ceil((K1+K2)/groups) rows instead of ceil(K1/groups) + ceil(K2/groups), each rounded
 // up to 4 -- round G0 (shared weights for [p2 ; out ; h1], the row's own VW for the alignments) is the longest mat-vec of a
@@ -355,8 +385,8 @@ __device__ __forceinline__ void mv_store(int N, const Xchg& X, float4 acc, float
 }
 template <bool PF>
 __device__ __forceinline__ void phase_mv_impl(const float* __restrict__ W, int ldw, int K, int N, const float* x,
-                                              float* part, const Xchg& X, const Pref& pf) {
-  mv_store(N, X, mv_accum<PF>(W, ldw, K, N, x, X, pf, make_float4(0.f, 0.f, 0.f, 0.f)), part);
+                                              float* part, const Xchg& X, const Pref& pf, const float4* lw = nullptr, int lrows = 0) {
+  mv_store(N, X, mv_accum<PF>(W, ldw, K, N, x, X, pf, make_float4(0.f, 0.f, 0.f, 0.f), lw, lrows), part);
 }
 
 // after a workgroup barrier: reduce the partial rows, run the owner epilogue, update local state, publish the slice
@@ -366,8 +396,8 @@ __device__ __forceinline__ void phase_mv(const float* __restrict__ W, int ldw, i
   phase_mv_impl<false>(W, ldw, K, N, x, part, X, none);
 }
 __device__ __forceinline__ void phase_mv(const float* __restrict__ W, int ldw, int K, int N, const float* x, float* part,
-                                         const Xchg& X, const Pref& pf) {
-  phase_mv_impl<true>(W, ldw, K, N, x, part, X, pf);
+                                         const Xchg& X, const Pref& pf, const float4* lw = nullptr, int lrows = 0) {
+  phase_mv_impl<true>(W, ldw, K, N, x, part, X, pf, lw, lrows);
 }
 
 template <class Epi, class Put>
@@ -431,9 +461,10 @@ struct NextMv {
 };
 template <class Epi, class Put>
 __device__ __forceinline__ void phase(const float* __restrict__ W, int ldw, int K, int N, const float* x, float* part,
-                                      Xchg& X, int reg, Epi epi, Put put, Pref& pf, NextMv nx) {
+                                      Xchg& X, int reg, Epi epi, Put put, Pref& pf, NextMv nx, const float4* lw = nullptr,
+                                      int lrows = 0) {
   tstamp(X, 0);
-  phase_mv(W, ldw, K, N, x, part, X, pf);
+  phase_mv(W, ldw, K, N, x, part, X, pf, lw, lrows);
   tstamp(X, 1);
   lds_barrier();
   phase_fin(N, part, X, reg, epi, put);
@@ -594,6 +625,11 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
     const int s = s_first + i * s_stride;
     kres[i] = s < len ? reinterpret_cast<const float4*>(keys + (int64_t)s * kAtt)[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  // launch-resident second halves of the GRU-2 / GRU-3 gate chunks (free LDS behind the state; sizes chosen by the launcher)
+  float4* const lw1 = reinterpret_cast<float4*>(smem + kFwdSmemFixed + 2 * TtP);
+  float4* const lw2 = lw1 + a.lres0 * NT;
+  lres_fill(lw1, a.lres0, w.gw[1], 2 * kDec, 2 * kDec, 2 * kDec, X);
+  lres_fill(lw2, a.lres1, w.gw[2], 2 * kDec, 2 * kDec, 2 * kDec, X);
   lds_barrier();
 
   // pre_net (tacotron.py:38-44, 64-71) of step tt: two layers, each an exchange round.  Step 0 runs them standalone here;
@@ -725,7 +761,7 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
                 if (n < kDec) S.catc[kDec + n] = v;   // r * h
                 else S.us[n - kDec] = v;              // u
               },
-              pf, NextMv{w.cw[l], kDec, 2 * kDec, kDec});
+              pf, NextMv{w.cw[l], kDec, 2 * kDec, kDec}, l == 1 ? lw1 : lw2, l == 1 ? a.lres0 : a.lres1);
         lds_barrier();
       }
       phase(w.cw[l], kDec, 2 * kDec, kDec, S.catc, S.part, X, XF_C + l * 768,
@@ -1011,6 +1047,13 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
   }
   lds_barrier();
 
+  // launch-resident second halves of the GRU-3 / GRU-2 gate chunks (transposed weights; free LDS behind the state)
+  float4* const lw2 = reinterpret_cast<float4*>(smem + kBwdSmemFixed + 2 * TtP);
+  float4* const lw1 = lw2 + a.lres0 * NT;
+  lres_fill(lw2, a.lres0, w.gw[2], 2 * kDec, 2 * kDec, 2 * kDec, X);
+  lres_fill(lw1, a.lres1, w.gw[1], 2 * kDec, 2 * kDec, 2 * kDec, X);
+  lds_barrier();
+
   // The pre-net backward of a step is off the critical path and runs one step late: its layer-2 input gradient comes out
   // of the next processed step's FAN round (it needs the same dx), layer 1 rides in that step's DAL round.
   // `pend` = such a deferred pre-net (of step t+1) exists.
@@ -1252,7 +1295,8 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
                 S.dh[l * kDec + n - kDec] += y;
               }
             },
-            pf, l > 0 ? NextMv{w.cw[l - 1], 2 * kDec, kDec, 2 * kDec} : nx_dp2);
+            pf, l > 0 ? NextMv{w.cw[l - 1], 2 * kDec, kDec, 2 * kDec} : nx_dp2, l == 2 ? lw2 : (l == 1 ? lw1 : nullptr),
+            l == 2 ? a.lres0 : (l == 1 ? a.lres1 : 0));
       lds_barrier();
     }
     if (lead && tid < kDec) gs[kGsX + tid] = S.dx[tid];
@@ -1313,6 +1357,19 @@ int pick_cluster(K kernel, size_t smem, int B, int want) {
 // Training uses at most 8 peers so that results are bit-identical for every per-GPU batch <= 32 (the summation order
 // depends on the cluster width; data-parallel shards of a batch must reproduce the unsharded gradients exactly).  Inference
 // has no such contract and takes 16 peers when they fit (B <= 16): -7 % per decoder step.  TACO_DEC_CLUSTER overrides.
+// The LDS the state leaves free holds launch-resident weight rows: 8 or 4 rows x 512 threads x 16 bytes for each of two gate
+// mat-vecs (TACO_DEC_NO_LRES=1 disables it, for A/B runs).
+void lres_plan(size_t& smem, int& r0, int& r1) {
+  r0 = r1 = 0;
+  if (getenv("TACO_DEC_NO_LRES")) return;
+  for (int l = 0; l < 2; ++l)
+    for (int rows = 8; rows >= 4; rows -= 4)
+      if (smem + (size_t)rows * NT * 16 <= 158 * 1024) {
+        (l == 0 ? r0 : r1) = rows;
+        smem += (size_t)rows * NT * 16;
+        break;
+      }
+}
 int probe_bits() {
   if (!kProbes) return 0;
   return (getenv("TACO_DEC_FAKEW") ? 1 : 0) | (getenv("TACO_DEC_FAKEX") ? 2 : 0) | (getenv("TACO_DEC_NOPF") ? 8 : 0) |
@@ -1339,8 +1396,9 @@ int launch_decoder_fwd(DecFwdArgs a, hipStream_t s) {
                a.Tt, a.Td, a.r);
   TACO_REQUIRE(a.xchg && a.err, "decoder_fwd: exchange area missing");
   const int TtP = (a.Tt + 3) & ~3;
-  const size_t smem = (size_t)(kFwdSmemFixed + 2 * TtP) * sizeof(float);
+  size_t smem = (size_t)(kFwdSmemFixed + 2 * TtP) * sizeof(float);
   TACO_REQUIRE(smem <= 160 * 1024, "decoder_fwd: Tt=%d needs %zu bytes of LDS (> 160 KiB)", a.Tt, smem);
+  lres_plan(smem, a.lres0, a.lres1);
   void (*kern)(DecFwdArgs) = a.trace ? decoder_fwd_kernel<true> : decoder_fwd_kernel<false>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1369,8 +1427,9 @@ int launch_decoder_bwd(DecBwdArgs a, hipStream_t s) {
   TACO_REQUIRE(a.B > 0 && a.Tt > 0 && a.Td > 0 && a.r >= 1 && a.r <= 5, "decoder_bwd: bad dims");
   TACO_REQUIRE(a.xchg && a.err, "decoder_bwd: exchange area missing");
   const int TtP = (a.Tt + 3) & ~3;
-  const size_t smem = (size_t)(kBwdSmemFixed + 2 * TtP) * sizeof(float);
+  size_t smem = (size_t)(kBwdSmemFixed + 2 * TtP) * sizeof(float);
   TACO_REQUIRE(smem <= 160 * 1024, "decoder_bwd: Tt=%d needs %zu bytes of LDS (> 160 KiB)", a.Tt, smem);
+  lres_plan(smem, a.lres0, a.lres1);
   void (*kern)(DecBwdArgs) = a.trace ? decoder_bwd_kernel<true> : decoder_bwd_kernel<false>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

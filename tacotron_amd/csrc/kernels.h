@@ -249,6 +249,7 @@ struct DecFwdArgs {
   int B, Tt, Td, r;
   int P;                 // cluster width (workgroups per row); chosen by launch_decoder_fwd
   int fakew = 0;         // timing probe (TACO_DEC_FAKEW): see Xchg::fake
+  int lres0 = 0, lres1 = 0;  // launch-resident weight rows (LDS) of the GRU-2 / GRU-3 gate mat-vecs; chosen by launch_decoder_fwd
 };
 int64_t decoder_xchg_bytes(int B, int Tt);
 int decoder_last_cluster(int which);   // cluster width (workgroups per row) of the last forward (0) / backward (1) launch
@@ -279,6 +280,7 @@ struct DecBwdArgs {
   int B, Tt, Td, r;
   int P;
   int fakew = 0;
+  int lres0 = 0, lres1 = 0;  // launch-resident weight rows (LDS) of the GRU-3 / GRU-2 gate mat-vecs; chosen by launch_decoder_bwd
 };
 int launch_decoder_bwd(DecBwdArgs a, hipStream_t s);
 
