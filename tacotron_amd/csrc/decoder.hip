@@ -668,11 +668,15 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
     lds_barrier();
   }
   // parked one step ahead in registers: dropout multipliers and the teacher frame of step t+1
-  float km1n = 1.f, km2n = 1.f, frn = 0.f;
+  float km1n = 1.f, km2n = 1.f, frn = 0.f, p2n = 0.f;
+  // teacher-forced steps: the pre-net output p2 is known before the launch (a.pre2, formed by two GEMMs over all B*Td frames,
+  // model.hip); the kernel then only loads it, and runs the pre-net riders of the OUT / E rounds on steps fed by the previous output
+  const bool hoisted = a.pre2 != nullptr;
   auto park_next = [&](int tn) {   // tn = step whose pre-net inputs are fetched
     km1n = km2n = 1.f;
     frn = 0.f;
     if (tn < Td) {
+      if (hoisted && tid < kPre2) p2n = a.pre2[((int64_t)b * Td + tn) * a.ldpre2 + tid];
       if (a.keep1 && tid < kPre1) km1n = a.keep1[((int64_t)b * Td + tn) * kPre1 + tid] ? 2.f : 0.f;
       if (a.keep2 && tid < kPre2) km2n = a.keep2[((int64_t)b * Td + tn) * kPre2 + tid] ? 2.f : 0.f;
       if (a.mel && tid < kMel) frn = a.mel[((int64_t)b * Td + tn) * R80 + kMel * (r - 1) + tid];
@@ -694,7 +698,9 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
     if (tid < kPre1) S.km1[tid] = km1n;
     if (tid < kPre2) S.km2[tid] = km2n;
     if (tid < kMel) S.fr[tid] = frn;
+    if (hoisted && tid < kPre2) S.p1[tid] = p2n;   // parked p2 of step t+1 (S.p1 is free until this step's OUT round)
     park_next(t + 2);
+    const bool rider = has_next && (from_out || !hoisted);   // pre-net of step t+1 computed in this step's OUT / E rounds
 
     // ---- round G0: InputProjectionWrapper x = [pre_net ; attention] Wi + bi (tacotron.py:56-59) with the attention layer
     //      and the context folded in (alignments of step t-1 against this row's VWx / VWg), and GRU-1's gates straight from
@@ -813,17 +819,18 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
       const int p1b = from_out ? BO_P1O : BO_P1;
       tstamp(X, 0);
       phase_mv(cw.wo, NO, kDec, NO, S.ys, S.part, X, pf);
-      if (has_next) {
+      if (rider) {
         if (from_out) phase_mv(cw.wp1o, kPre1, kDec, kPre1, S.ys, S.part + kPartRegion, X);
         else phase_mv(w.pre_w1, kPre1, kMel, kPre1, S.fr, S.part + kPartRegion, X);
       }
       tstamp(X, 1);
       lds_barrier();
       phase_fin(NO, S.part, X, XF_O, o_epi, o_put);
-      if (has_next) phase_fin(kPre1, S.part + kPartRegion, X, XF_P1, p1_epi(bt + 1, p1b), p1_put);
+      if (rider) phase_fin(kPre1, S.part + kPartRegion, X, XF_P1, p1_epi(bt + 1, p1b), p1_put);
       tstamp(X, 2);
-      if (has_next) prefetch_w(pf, w.pre_w2, kPre2, kPre1, kPre2, X);
-      phase_gather2(NO, XF_O, o_put, has_next ? kPre1 : 0, XF_P1, p1_put, X);
+      if (rider) prefetch_w(pf, w.pre_w2, kPre2, kPre1, kPre2, X);
+      else if (has_next) prefetch_w2(pf, sx, kDec, kDec, X);
+      phase_gather2(NO, XF_O, o_put, rider ? kPre1 : 0, XF_P1, p1_put, X);
       tstamp(X, 3);
       X.tslot++;
     }
@@ -851,18 +858,20 @@ __global__ __launch_bounds__(NT) void decoder_fwd_kernel(DecFwdArgs a) {
       }
       for (int s = s_first + kAR * s_stride; s < len; s += s_stride)
         score(s, reinterpret_cast<const float4*>(keys + (int64_t)s * kAtt)[lane]);
-      if (has_next) {
+      if (rider) {
         phase_mv(w.pre_w2, kPre2, kPre1, kPre2, S.p1, S.part, X, pf);
         lds_barrier();
         phase_fin(kPre2, S.part, X, XF_P2, p2_epi(bt + 1), p2_put);
         prefetch_w2(pf, sx, kDec, kDec, X);
+      } else if (has_next) {
+        if (tid < kPre2) S.u0[tid] = S.p1[tid];   // the hoisted pre-net output of step t+1 (G0's p2 segment; barrier below)
       }
       tstamp(X, 2);
       tmark(X, 1);
       if (P > 1) {   // energies of the other peers' rows and their slices of p2, polled concurrently
         const Slice SB = slice_of(X, kPre2);
         const bool needA = tid < len && (tid & (P - 1)) != X.peer;
-        const bool needB = has_next && tid < kPre2 && !(tid >= SB.nbeg && tid < SB.nbeg + SB.nloc);
+        const bool needB = rider && tid < kPre2 && !(tid >= SB.nbeg && tid < SB.nbeg + SB.nloc);
         float vA, vB;
         xget2(X, XF_E + tid, needA, XF_P2 + tid, needB, vA, vB);
         if (needA) S.es[tid] = vA;
@@ -1082,6 +1091,9 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
     const int64_t bt = (int64_t)b * Td + t;
     float* gs = a.gstash + bt * kGsRec;
     const bool next_from_out = (t + 1 < Td) && a.sample && a.sample[(int64_t)t * B + b];
+    // the pre-net backward of step t+1 rides in this step's FAN / DQ rounds only where the recurrence needs it (step t+1 was
+    // fed by this step's output); with a.hoisted the teacher-forced steps' pre-net gradients are GEMMs after the launch (model.hip)
+    const bool rider = pend && (next_from_out || !a.hoisted);
 
     // 0. land the prefetched record in LDS, start fetching the one for step t-1
 #pragma unroll
@@ -1122,7 +1134,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
           dal(s, reinterpret_cast<const float4*>(vwx + (int64_t)s * kDec)[lane]);
       }
       tmark(X, 11);
-      if (pend) {
+      if (rider) {
         phase_mv(w.in_w, kPre2 + kAtt, kDec, kPre2, S.dx, S.part, X, pf);
         tstamp(X, 1);
         lds_barrier();
@@ -1132,7 +1144,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
       }
       if (P > 1) {   // d p2 slices and the other peers' d alignments rows, polled concurrently
         const Slice SP = slice_of(X, kPre2);
-        const bool needA = pend && tid < kPre2 && !(tid >= SP.nbeg && tid < SP.nbeg + SP.nloc);
+        const bool needA = rider && tid < kPre2 && !(tid >= SP.nbeg && tid < SP.nbeg + SP.nloc);
         const bool needB = tid < len && (tid & (P - 1)) != X.peer;
         float vA, vB;
         xget2(X, XB_DP2 + tid, needA, XB_DAL + tid, needB, vA, vB);
@@ -1148,7 +1160,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
     lds_barrier();
     tmark(X, 13);
     // d p1pre of step t+1 reaches this step's cell_output only if that step was fed by it (sampled rows)
-    const bool use_p1 = pend && next_from_out;
+    const bool use_p1 = rider && next_from_out;
     // 3b. softmax backward: de = al * (dal - sum al*dal)   (every wave computes the dot redundantly)
     {
       float dot = 0.f;
@@ -1188,7 +1200,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
         S.red[sg * un + ul] = dqa;
       }
       // same round: deferred pre-net layer 2 of step t+1: d p1 = d p2pre . W2^T (wT.pre_w2 is (128, 256))
-      if (pend) phase_mv(w.pre_w2, kPre1, kPre2, kPre1, S.dp2, S.part, X, pf);
+      if (rider) phase_mv(w.pre_w2, kPre1, kPre2, kPre1, S.dp2, S.part, X, pf);
       tmark(X, 15);
     }
     lds_barrier();
@@ -1203,12 +1215,12 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
         gs[kGsQ + n] = dsum;
         if (P > 1) xput(X, XB_DQP + n, dsum);
       }
-      if (pend) phase_fin(kPre1, S.part, X, XB_P2, p2T_epi, p2T_put);
+      if (rider) phase_fin(kPre1, S.part, X, XB_P2, p2T_epi, p2T_put);
       prefetch_w2(pf, Seg2{a.wot, S.vo, R80 + kAtt + (use_p1 ? kPre1 : 0), a.wdx, S.dx, kDec}, kDec, kDec, X);
       if (P > 1) {   // dq slices and the other peers' slices of d p1, polled concurrently
         const Slice SB = slice_of(X, kPre1);
         const bool needA = tid < kAtt && !(tid >= ub && tid < ub + un);
-        const bool needB = pend && tid < kPre1 && !(tid >= SB.nbeg && tid < SB.nbeg + SB.nloc);
+        const bool needB = rider && tid < kPre1 && !(tid >= SB.nbeg && tid < SB.nbeg + SB.nloc);
         float vA, vB;
         xget2(X, XB_DQP + tid, needA, XB_P2 + tid, needB, vA, vB);
         if (needA) dq_put(tid, vA);
@@ -1308,7 +1320,7 @@ __global__ __launch_bounds__(NT) void decoder_bwd_kernel(DecBwdArgs a) {
     lds_barrier();
   }
   // deferred pre-net of step 0 (its layer-1 input gradient is not needed: nothing precedes step 0)
-  if (pend) {
+  if (pend && !a.hoisted) {
     X.epoch = (unsigned)(Td + 1);
     phase(w.in_w, kPre2 + kAtt, kDec, kPre2, S.dx, S.part, X, XB_DP2, dp2_epi, dp2_put, pf, nx_p2T);
     lds_barrier();

@@ -370,6 +370,19 @@ __global__ __launch_bounds__(256) void center_rows_kernel(const float* __restric
   }
 }
 
+// g[r][c] = y[r][c] > 0 ? scale * g[r][c] : 0  (ReLU + dropout backward against the stored, already masked activation; both
+// tensors are column blocks of wider records: row pitches ldg / ldy)
+__global__ void mask_pos_kernel(float* __restrict__ g, int ldg, const float* __restrict__ y, int ldy, int64_t rows, int cols,
+                                float scale) {
+  const int64_t total = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols;
+    const int c = (int)(i - r * cols);
+    const float v = g[r * ldg + c];
+    g[r * ldg + c] = y[r * ldy + c] > 0.f ? scale * v : 0.f;
+  }
+}
+
 __global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     y[i] = a[i] + b[i];
@@ -580,6 +593,10 @@ int launch_center_rows(const float* x, const int32_t* len, float* out, int B, in
   TACO_REQUIRE(C % 4 == 0, "center_rows: C %% 4 != 0");
   hipLaunchKernelGGL(center_rows_kernel, dim3((C + 255) / 256, B, 4), dim3(256), 0, s, x, len, out, T, C);
   TACO_LAUNCH_CHECK("center_rows");
+  return TACO_OK;
+}
+int launch_mask_pos(float* g, int ldg, const float* y, int ldy, int64_t rows, int cols, float scale, hipStream_t s) {
+  EW_LAUNCH(mask_pos_kernel, rows * cols, s, g, ldg, y, ldy, rows, cols, scale);
   return TACO_OK;
 }
 int launch_colsum_batched(const float* x, int ld, float* out, int B, int T, int N, hipStream_t s) {

@@ -94,6 +94,7 @@ int launch_gemm_naive(const ConvGemmProblem& p, hipStream_t stream);
 
 // ---------------------------------------------------------------- elementwise.hip
 int launch_embedding(const float* table, const int32_t* ids, float* out, int64_t rows, int V, hipStream_t s, int width = kEmbed);
+int launch_mask_pos(float* g, int ldg, const float* y, int ldy, int64_t rows, int cols, float scale, hipStream_t s);
 int launch_center_rows(const float* x, const int32_t* len, float* out, int B, int T, int C, hipStream_t s);
 int launch_embedding_bwd(const float* dout, const int32_t* ids, float* dtable, int64_t rows, int V, hipStream_t s, int width = kEmbed);
 // y = maxpool2_same(x*scale+shift) along T; x,y (B*T, C)
@@ -243,6 +244,8 @@ struct DecFwdArgs {
   float* align;          // (B,Td,Tt)
   float* stash;          // (B,Td,kStRec) or null
   float* prein;          // (B,Td,80) pre-net input frames actually used (train stash) or null
+  const float* pre2;     // (B,Td,128) with row pitch ldpre2: pre-net output of every TEACHER-FORCED step, formed before the launch
+  int ldpre2;            //   (train: the P2 slot of the stash, which the kernel overwrites on the steps fed by the previous output); null: all in-kernel
   void* xchg;            // decoder_xchg_bytes(B,Tt): granule area for the in-launch all-gathers
   int* err;              // set to 1 by the kernel if a bounded spin timed out
   long long* trace;      // optional (TACO_DEC_TRACE=1): per-phase wall_clock64 stamps of block 0 at step Td/2
@@ -281,6 +284,8 @@ struct DecBwdArgs {
   int P;
   int fakew = 0;
   int lres0 = 0, lres1 = 0;  // launch-resident weight rows (LDS) of the GRU-3 / GRU-2 gate mat-vecs; chosen by launch_decoder_bwd
+  int hoisted = 0;           // 1: the pre-net gradients of the teacher-forced steps are formed after the launch (model.hip); the kernel
+                             //    runs the pre-net backward only where a step was fed by the previous output
 };
 int launch_decoder_bwd(DecBwdArgs a, hipStream_t s);
 

@@ -369,6 +369,21 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
     // composites) is built here, beside the encoder, instead of at the head of taco_backward's critical path
     TACO_TRY(prepare_transposes(P, PL, L.T, ws + W.paramsT, r, sd));
     TACO_TRY(build_dec_composites_bwd(P, PL, W, ws, r, sd));
+    // decoder pre_net (tacotron.py:38-44, 64-71) of every TEACHER-FORCED step: its input (the last frame of mel[t]) is known now,
+    // so the two layers are two GEMMs over all B*Td frames, straight into the P1 / P2 slots of the decoder stash, beside the
+    // encoder.  The decoder kernel loads P2 on teacher-forced steps and runs (and overwrites) the pre-net only where a step is
+    // fed by the previous output (scheduled sampling).
+    {
+      const int MDf = B * Td;
+      ConvGemmProblem q1 = dense_problem(mel + kMel * (r - 1), R80, P + PL.dec_pre1.w, kPre1, P + PL.dec_pre1.b,
+                                         ws + W.stash + kStP1, kStRec, MDf, kPre1, kMel, TACO_ACT_RELU);
+      q1.keep = dk1;
+      TACO_TRY(launch_conv_gemm(q1, sd));
+      ConvGemmProblem q2 = dense_problem(ws + W.stash + kStP1, kStRec, P + PL.dec_pre2.w, kPre2, P + PL.dec_pre2.b,
+                                         ws + W.stash + kStP2, kStRec, MDf, kPre2, kPre1, TACO_ACT_RELU);
+      q2.keep = dk2;
+      TACO_TRY(launch_conv_gemm(q2, sd));
+    }
   }
   // embedding + encoder pre_net (tacotron.py:111-114, 128)
   TACO_TRY(launch_embedding(P + PL.emb, text, ws + W.emb, M1, sh.V, s));
@@ -427,6 +442,8 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
   da.out = s2s; da.align = align;
   da.stash = train ? ws + W.stash : nullptr;
   da.prein = train ? ws + W.prein : nullptr;
+  da.pre2 = train ? ws + W.stash + kStP2 : nullptr;
+  da.ldpre2 = kStRec;
   da.xchg = ws + W.xchg; da.err = reinterpret_cast<int*>(ws + W.err);
   da.trace = getenv("TACO_DEC_TRACE") ? reinterpret_cast<long long*>(ws + W.err + 16) : nullptr;
   da.B = B; da.Tt = Tt; da.Td = Td; da.r = r; da.P = 1;
@@ -948,6 +965,7 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     a.keep1 = dec_keep1; a.keep2 = dec_keep2; a.sample = sample;
     a.dout = dS2S; a.out = seq2seq_output; a.align = alignments; a.stash = st; a.gstash = gs;
     a.dkeys = ws + W.dkeys; a.ldk = 2 * kAtt; a.datt_v = ws + W.dattv;
+    a.hoisted = 1;
     a.xchg = ws + W.xchg; a.err = reinterpret_cast<int*>(ws + W.err) + 1;
     a.trace = getenv("TACO_DEC_TRACE") ? reinterpret_cast<long long*>(ws + W.err + 16) + 128 : nullptr;
     a.B = B; a.Tt = Tt; a.Td = Td; a.r = r; a.P = 1;
@@ -993,6 +1011,18 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     }
     // d attention_v = sum over batch rows of the kernel's per-row partials, in row order (no atomics)
     TACO_TRY(launch_colsum_batched(ws + W.dattv, kAtt, G + PL.att_v, 1, B, kAtt, s));
+    // decoder pre_net backward for ALL steps (the kernel only ran it where the recurrence needed it, i.e. into steps fed by the
+    // previous output): d p2pre = [p2 > 0] keep2 (dx Wi_p^T), d p1pre = [p1 > 0] keep1 (d p2pre W2^T) -- two GEMMs over the B*Td rows
+    {
+      ConvGemmProblem q2 = dense_problem(gs + kGsX, kGsRec, PT + TL.in_proj, kPre2 + kAtt, nullptr, gs + kGsP2, kGsRec, MD, kPre2,
+                                         kDec, TACO_ACT_NONE);
+      TACO_TRY(launch_conv_gemm(q2, s));
+      TACO_TRY(launch_mask_pos(gs + kGsP2, kGsRec, st + kStP2, kStRec, MD, kPre2, dec_keep2 ? 2.f : 1.f, s));
+      ConvGemmProblem q1 = dense_problem(gs + kGsP2, kGsRec, PT + TL.dec_pre2, kPre1, nullptr, gs + kGsP1, kGsRec, MD, kPre1, kPre2,
+                                         TACO_ACT_NONE);
+      TACO_TRY(launch_conv_gemm(q1, s));
+      TACO_TRY(launch_mask_pos(gs + kGsP1, kGsRec, st + kStP1, kStRec, MD, kPre1, dec_keep1 ? 2.f : 1.f, s));
+    }
     TnGroup dec_group(s);
     TACO_TRY(tn(ws + W.values, kAtt, 2 * kCb, ws + W.dkeys, 2 * kAtt, kAtt, G + PL.mem_w, kAtt, M1, M1, 0, s));   // d Wm = values^T d keys
     const float* prein = ws + W.prein;

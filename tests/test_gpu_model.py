@@ -519,7 +519,9 @@ def test_s2_envelope(built_lib):
     d1 = float((Rs.s2s - s2s0[:, :180]).abs().max())
     d2 = float((Rs.al - al0[:, :180]).abs().max())
     print('  S2 prefix vs S1 run: max|ds2s|=%.2e max|dalign|=%.2e (bitwise: %s)' % (d1, d2, d1 == 0 and d2 == 0))
-    assert d1 <= 1e-6 and d2 <= 1e-7
+    # (not bitwise: the pre-net of the teacher-forced steps is a batched GEMM over all B*Td frames, and which GEMM kernel a launch
+    #  takes depends on its row count -- 16000 rows here, 5760 in the S1 run -- so p2 differs in the last bits)
+    assert d1 <= 5e-6 and d2 <= 1e-6
     del Rs
     # forward vs the CPU restatement (fp64, no autograd)
     with torch.no_grad():
