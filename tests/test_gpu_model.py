@@ -388,6 +388,15 @@ def test_medium_shape_with_gemm2_forced(built_lib, variant, monkeypatch):
     test_backward_without_masks_and_ragged_lengths(built_lib)
 
 
+@pytest.mark.parametrize('knob', ['TACO_DEFER_POST_TN', 'TACO_DEC_NO_LRES'])
+def test_medium_shape_with_optional_paths(built_lib, knob, monkeypatch):
+    """The opt-in / A-B switches of the train step keep parity: post-net weight gradients deferred under the BPTT kernel
+    (TACO_DEFER_POST_TN=1) and the decoder kernels without launch-resident weight rows in LDS (TACO_DEC_NO_LRES=1)."""
+    monkeypatch.setenv(knob, '1')
+    test_medium_shape_forward_backward(built_lib)
+    test_backward_without_masks_and_ragged_lengths(built_lib)
+
+
 def _full_case(B, Tt, Td, r, V, seed_masks=0):
     from tacotron_amd.data import synthetic_batch
     batch = synthetic_batch(B, Tt, Td, r, V)
