@@ -167,10 +167,14 @@ def main():
     c = Config()
     c.r, c.vocab_size, c.num_speakers = 2, 60, args.speakers
     B, Tt, Td = args.batch, args.text_len, args.dec_steps
-    reducer = GradReducer() if world > 1 else None
+    # TACO_FORCE_DIST=1: take the whole distributed path (RCCL process group, communication stream, segment events, bucketed
+    # collectives, barriers) at world size 1 too -- `torchrun --nproc-per-node 1 bench.py --gpus 1` then executes every branch
+    # the 8-GPU run takes
+    forced = torch.distributed.is_initialized() and world == 1
+    reducer = GradReducer(force=forced) if (world > 1 or forced) else None
 
     def barrier():
-        if world > 1:
+        if world > 1 or forced:
             torch.distributed.barrier()
 
     def make_model(Td_, speakers):
@@ -184,6 +188,22 @@ def main():
     sec_per_step, fwd_ms, bwd_ms = time_steps(model, args.steps, args.warmup, barrier, world)
     loss = float(model.loss)
     model.check()
+    allreduce = None
+    if reducer is not None and rank == 0:
+        # separate untimed pass: events around every segment's collectives on the communication stream
+        reducer.timing = True
+        for _ in range(3):
+            model.step()
+        seg_us = reducer.segment_times_us()
+        reducer.timing = False
+        allreduce = {'backend': torch.distributed.get_backend(), 'world': world, 'bucket_floats': reducer.bucket,
+                     'overlap_bptt': reducer.overlap_bptt, 'lds_reserve_kb': reducer.lds_reserve_kb,
+                     'segments': [dict(d, us=seg_us[d['segment']]) for d in reducer.describe(model)],
+                     'note': 'completion order post-net, decoder, encoder; us = first collective enqueued -> last one done on the '
+                             'communication stream, median of 3 untimed steps'}
+    elif reducer is not None:
+        for _ in range(3):
+            model.step()   # (collectives need every rank)
     fam = None
     if rank == 0 and world == 1 and not args.no_extras:
         fam = family_profile(model)
@@ -262,6 +282,8 @@ def main():
         rooflines = [
             {'what': dom, 'bound': 'latency', 'achieved': achieved, 'peak': PEAK, 'unit': 'TFLOP/s', 'frac': achieved / PEAK,
              'avg_ms': dom_ms, 'us_per_decoder_step': dom_ms * 1e3 / Td, 'flops_per_launch': flops, 'traffic': traffic,
+             'traffic_source': 'profiles/pmc_latest.json (rocprofv3 --pmc passes of tools/profile_round.sh; a committed constant, '
+                               'used only when its source hash equals this build -- not measured in this run)' if traffic else None,
              'note': 'persistent per-row recurrence: %d strictly sequential steps x 8-9 dependent exchange rounds, no MFMA, '
                      'not HBM bound; the fp32 peak is quoted for scale only (DESIGN.md 5)' % Td},
             {'what': 'whole train step', 'bound': 'mfma', 'achieved': step_flops / sec_per_step / 1e12, 'peak': PEAK,
@@ -294,9 +316,12 @@ def main():
             'roofline': dict(rooflines[0], kernel=dom, launches_timed=len(bwd_ms if dom.startswith('decoder_bwd') else fwd_ms)),
             'rooflines': rooflines,
             'kernels_ms': {'decoder_fwd_kernel': fa, 'decoder_bwd_kernel': ba,
-                           'us_per_decoder_step_fwd': fa * 1e3 / Td, 'us_per_decoder_step_bwd': ba * 1e3 / Td},
+                           'us_per_decoder_step_fwd': fa * 1e3 / Td, 'us_per_decoder_step_bwd': ba * 1e3 / Td,
+                           'non_decoder_critical_path_ms': sec_per_step * 1e3 - fa - ba},
             'final_loss': loss, 'build': source_hash(),
         }
+        if allreduce:
+            res['allreduce'] = allreduce
         if s2:
             res['s2'] = s2
         if vctk:
@@ -306,7 +331,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(B, Tt, Td, c.r, c.vocab_size)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -23,7 +23,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default)
 
-#define TACO_VERSION 111
+#define TACO_VERSION 112
 
 #define TACO_OK 0
 #define TACO_EINVAL (-1)   /* bad argument / unsupported shape   */
@@ -157,6 +157,18 @@ int taco_clear_error(const TacoShape* shape, int train, void* workspace, void* s
  * current device is final, so an all-reduce enqueued on `stream` afterwards overlaps the rest of the backward pass. */
 int taco_grad_segments(const TacoShape* shape, int64_t* bounds);
 int taco_wait_grad_segment(int seg, void* stream);
+/* Process-wide data-parallel options (defaults 0, 0; environment TACO_DP_OVERLAP_BPTT / TACO_DEC_LDS_RESERVE_KB before the
+ * first call).  The decoder BPTT is a persistent launch that needs ALL its B * 8 workgroups co-resident, one per CU, with up to
+ * 158 KB of LDS each; a collective's kernel that took CUs first would leave clusters spinning on peers that cannot start.
+ *   overlap_bptt = 0 (default): segment 2's event is recorded AFTER the BPTT kernel, so a collective waiting for it never
+ *     competes with that launch -- its bytes travel under the encoder backward instead;
+ *   overlap_bptt = 1: segment 2 is announced before the BPTT kernel (its all-reduce runs underneath it).  Combine with
+ *     lds_reserve_kb > 0: every persistent decoder workgroup then leaves that much LDS of its CU free, so that one
+ *     communication workgroup per CU fits beside it whichever is dispatched first (tests/test_gpu_dist.py measures both orders). */
+int taco_dp_config(int overlap_bptt, int lds_reserve_kb);
+/* Communication-kernel stand-in for those tests: `blocks` workgroups x `threads` threads, `lds_bytes` of LDS each, spinning
+ * for `usec` microseconds.  Does no work. */
+int taco_debug_spin(int blocks, int threads, int lds_bytes, int usec, void* stream);
 
 /* ---- spectrogram boundary ---------------------------------------------------------------------------- */
 /* test.py:64 `out * stft_std + stft_mean` followed by audio.reshape_frames(forward=False) (audio.py:29-35), on the device.
@@ -174,7 +186,7 @@ int taco_denorm_unframe(const float* output, const float* stft_mean, const float
  *                        that results are reproducible)
  *   wave   (B, 300 (F - 1)) output samples
  *   workspace: taco_griffinlim_workspace_bytes(B, F) bytes.  Hand-written 2048-point FFT, no vendor library. */
-int64_t taco_griffinlim_workspace_bytes(int B, int F);
+int64_t taco_griffinlim_workspace_bytes(int B, int F);   /* F >= 5 frames (as taco_griffinlim), else TACO_EINVAL */
 int taco_griffinlim(const float* mag_t, const float* phase0, float* wave, void* workspace, int B, int F, int n_iter, void* stream);
 
 /* Bernoulli(p_keep) bytes from a counter-based hash RNG (replaces TF's dropout / Bernoulli sampler state). */
@@ -184,7 +196,7 @@ int taco_fill_bernoulli(uint8_t* out, int64_t n, float p_one, uint64_t seed, voi
 /* Launch-level timing with hipEventRecord pairs on the launch stream (rings of 4096 event pairs per category; no
  * synchronisation at record time).  Categories: 0 = persistent decoder forward kernel, 1 = decoder backward kernel,
  * 2 = MFMA GEMM family (conv_gemm / gemm_tn / fused highway stack launches), 3 = bi-GRU recurrences.
- * taco_profile_enable(mask): bit c switches category c on (mask 1 is read as "both decoder kernels", mask 0 = off).
+ * taco_profile_enable(mask): bit c switches category c on (mask 0 = off).
  * taco_profile_read2 synchronises on the recorded events, writes up to `cap` elapsed times (milliseconds) and the
  * algorithmic FLOPs of each launch (2 M N K taps) to the HOST arrays, oldest first, clears the ring, returns the count.
  * Launches that overlap on two streams are each timed by their own events (their times then sum to more than the wall). */

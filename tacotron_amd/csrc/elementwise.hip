@@ -715,3 +715,33 @@ int launch_bernoulli(uint8_t* out, int64_t n, float p_one, uint64_t seed, hipStr
   TACO_LAUNCH_CHECK("bernoulli");
   return TACO_OK;
 }
+
+// ---- communication-kernel stand-in (taco_debug_spin): `blocks` workgroups of `threads` threads holding `lds_bytes` of LDS
+//      each, spinning for `usec` microseconds of wall time.  The footprint of a collective kernel for co-residency tests of
+//      the persistent decoder launches (tests/test_gpu_dist.py); does no work.
+__global__ void spin_kernel(long long ticks, int lds_words) {
+  extern __shared__ __attribute__((aligned(16))) int spin_lds[];
+  for (int i = threadIdx.x; i < lds_words; i += blockDim.x) spin_lds[i] = i;   // touch the allocation
+  __syncthreads();
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+  if (lds_words > 0 && spin_lds[(threadIdx.x * 7) % lds_words] == -12345) spin_lds[0] = 1;   // keeps the touch alive
+}
+int launch_spin(int blocks, int threads, int lds_bytes, int usec, hipStream_t s) {
+  TACO_REQUIRE(blocks > 0 && threads > 0 && threads <= 1024 && lds_bytes >= 0 && lds_bytes <= 160 * 1024 && usec >= 0,
+               "debug_spin: bad arguments");
+  if (lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(spin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) {
+      taco_set_error("debug_spin: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return TACO_ELAUNCH;
+    }
+  }
+  int rate_khz = 100000;   // wall_clock64 ticks at the constant s_memrealtime rate (100 MHz on gfx950); ask the runtime
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, dev);
+  if (rate_khz <= 0) rate_khz = 100000;
+  hipLaunchKernelGGL(spin_kernel, dim3(blocks), dim3(threads), (size_t)lds_bytes, s, (long long)usec * rate_khz / 1000, lds_bytes / 4);
+  TACO_LAUNCH_CHECK("debug_spin");
+  return TACO_OK;
+}

@@ -146,6 +146,16 @@ int launch_sumsq(const float* x, int64_t n, float* out, hipStream_t s);  // out[
 int launch_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float cap, int64_t step,
                      const float* sumsq, float* gnorm_out, const int32_t* err, hipStream_t s);
 int launch_bernoulli(uint8_t* out, int64_t n, float p_one, uint64_t seed, hipStream_t s);
+int launch_spin(int blocks, int threads, int lds_bytes, int usec, hipStream_t s);   // communication-kernel stand-in (tests)
+
+// ---------------------------------------------------------------- data-parallel options (model.hip, taco_dp_config)
+// overlap_bptt: segment 2's all-reduce may start BEFORE the decoder BPTT kernel (else: after it); lds_reserve_bytes: LDS every
+// persistent decoder workgroup leaves free on its CU for a co-resident communication workgroup.
+struct DpConfig {
+  int overlap_bptt = 0;
+  int lds_reserve_bytes = 0;
+};
+const DpConfig& taco_dp();
 
 // ---------------------------------------------------------------- bigru.hip
 struct BiGruWeights {

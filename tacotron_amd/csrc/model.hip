@@ -51,7 +51,23 @@ struct ProfRing {
 ProfRing g_prof[4];
 int g_prof_mask = 0;   // bit c: category c is recorded
 
+DpConfig g_dp;
+bool g_dp_init = false;
+
 }  // namespace
+
+// Data-parallel options: process-wide, set by taco_dp_config (the host's GradReducer) or, before the first call, by the
+// environment (TACO_DP_OVERLAP_BPTT=1, TACO_DEC_LDS_RESERVE_KB=n).
+const DpConfig& taco_dp() {
+  if (!g_dp_init) {
+    g_dp_init = true;
+    const char* e = getenv("TACO_DP_OVERLAP_BPTT");
+    if (e) g_dp.overlap_bptt = atoi(e) != 0;
+    e = getenv("TACO_DEC_LDS_RESERVE_KB");
+    if (e) g_dp.lds_reserve_bytes = atoi(e) * 1024;
+  }
+  return g_dp;
+}
 
 int taco_prof_begin(int which, hipStream_t s) {
   if (!(g_prof_mask & (1 << which))) return -1;
@@ -937,7 +953,11 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     TACO_TRY(record_segment(2, side));
   } else {
     TACO_TRY(side_join(s, side));
-    TACO_TRY(record_segment(2, s));
+    // Default (taco_dp_config overlap_bptt = 0): segment 2 is ANNOUNCED only after the BPTT kernel below, so that a collective
+    // waiting for it can never compete with the persistent decoder launch for CUs (that kernel needs all B * P workgroups
+    // co-resident; a communication kernel that takes CUs first would leave part of every cluster spinning on peers that
+    // cannot start).  The bytes then travel under the encoder backward instead -- 2 ms of ordinary kernels.
+    if (taco_dp().overlap_bptt) TACO_TRY(record_segment(2, s));
   }
 
   // ---- decoder BPTT ----
@@ -972,6 +992,7 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     const int slot = prof_begin(1, s);
     TACO_TRY(launch_decoder_bwd(a, s));
     prof_end(1, slot, s);
+    if (!defer && !taco_dp().overlap_bptt) TACO_TRY(record_segment(2, s));
     // the scratch buffers the deferred post-net GEMMs read are reused from here on
     if (defer && hipStreamWaitEvent(s, ssx.ev_post, 0) != hipSuccess) {
       taco_set_error("taco_backward: event wait failed");
@@ -1220,7 +1241,7 @@ extern "C" int taco_denorm_unframe(const float* output, const float* stft_mean, 
 }
 
 extern "C" int64_t taco_griffinlim_workspace_bytes(int B, int F) {
-  if (B <= 0 || F < 2) return TACO_EINVAL;
+  if (B <= 0 || F < 5) return TACO_EINVAL;   // launch_griffinlim needs F >= 5 (centre padding of 1024 samples at hop 300)
   return griffinlim_workspace_floats(B, F) * (int64_t)sizeof(float);
 }
 
@@ -1236,9 +1257,20 @@ extern "C" int taco_fill_bernoulli(uint8_t* out, int64_t n, float p_one, uint64_
 
 extern "C" int taco_debug_last_cluster(int which) { return decoder_last_cluster(which); }
 
+extern "C" int taco_dp_config(int overlap_bptt, int lds_reserve_kb) {
+  TACO_REQUIRE(lds_reserve_kb >= 0 && lds_reserve_kb <= 96, "taco_dp_config: lds_reserve_kb=%d out of range [0, 96]", lds_reserve_kb);
+  (void)taco_dp();   // (environment defaults first, so that they do not overwrite this call later)
+  g_dp.overlap_bptt = overlap_bptt != 0;
+  g_dp.lds_reserve_bytes = lds_reserve_kb * 1024;
+  return TACO_OK;
+}
+
+extern "C" int taco_debug_spin(int blocks, int threads, int lds_bytes, int usec, void* stream) {
+  return launch_spin(blocks, threads, lds_bytes, usec, as_stream(stream));
+}
+
 extern "C" int taco_profile_enable(int mask) {
-  // historical callers pass 1 for "the two decoder kernels"
-  g_prof_mask = mask == 1 ? 3 : mask;
+  g_prof_mask = mask & 15;
   return TACO_OK;
 }
 

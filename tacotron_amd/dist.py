@@ -13,12 +13,16 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).  Returns (rank, world, local_rank)."""
+def init_from_env(backend=None, force=None):
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).  Returns (rank, world, local_rank).
+    force (default: TACO_FORCE_DIST=1): create the process group at world size 1 too, so that the whole distributed path
+    (RCCL init, communication stream, segment events, collectives) executes on a single GPU."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    if force is None:
+        force = os.environ.get('TACO_FORCE_DIST', '0') not in ('', '0')
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
@@ -32,56 +36,116 @@ def init_from_env(backend=None):
 class GradReducer:
     """SUM all-reduce of the flat gradient buffer, overlapped with the backward pass.
 
-    `taco_backward` finalises the buffer in three contiguous segments (post-net first, then decoder, then encoder;
-    `lib.grad_segments`) and records a HIP event per segment.  `reduce_after_backward` enqueues, on a communication
-    stream, a device-side wait for each event followed by that segment's bucketed all-reduce -- so the post-net
-    gradients (7.3 MB) travel over xGMI under the decoder BPTT, the decoder segment (6.4 MB) under the encoder backward,
-    and the host never blocks.  The loss triple and the decoder error words ride along, so every rank takes (or skips)
-    the same Adam update and replicas stay bit-identical."""
+    `taco_backward` finalises the buffer in three contiguous segments (post-net, decoder, encoder; `lib.grad_segments`) and
+    records a HIP event per segment.  `reduce_after_backward` enqueues, on a communication stream, a device-side wait for each
+    event followed by that segment's bucketed all-reduce, so the bytes travel while the rest of the backward pass runs and
+    the host never blocks.
 
-    def __init__(self, bucket_floats=2 * 1024 * 1024, group=None):
+    What the collectives may overlap WITH is a deliberate choice.  The decoder BPTT is a persistent launch whose B*8
+    workgroups must all be co-resident (one per CU, up to 158 KB of LDS each); an RCCL kernel dispatched first would hold CUs
+    that part of every cluster needs, and that part's peers would spin until it gets them.  Default (`overlap_bptt=False`):
+    the library announces the post-net segment only AFTER the BPTT kernel, so both early segments (13.7 MB) reduce under the
+    encoder backward (2 ms of ordinary kernels) and no collective ever runs beside a persistent decoder launch.
+    `overlap_bptt=True` (opt-in, validated on one GPU by tests/test_gpu_dist.py with an RCCL-footprint stand-in): the
+    post-net segment reduces underneath the BPTT kernel, whose workgroups then leave `lds_reserve_kb` of LDS per CU free so a
+    communication workgroup fits beside them in either dispatch order.
+
+    The loss triple rides along (SUM); the decoder error words ride along with MAX -- they are sticky 0/1 flags, and a SUM
+    would multiply a set flag by the world size every step until the int32 wraps to 0 (after 32/log2(W) steps)."""
+
+    def __init__(self, bucket_floats=2 * 1024 * 1024, group=None, overlap_bptt=None, lds_reserve_kb=64, force=False):
         self.bucket = int(bucket_floats)
         self.group = group
         on = dist.is_initialized()
         self.world = dist.get_world_size(group) if on else 1
         self.rank = dist.get_rank(group) if on else 0
+        self.active = self.world > 1 or (force and on)
         self.comm = None
+        if overlap_bptt is None:
+            overlap_bptt = os.environ.get('TACO_DP_OVERLAP_BPTT', '0') not in ('', '0')
+        self.overlap_bptt = bool(overlap_bptt)
+        self.lds_reserve_kb = int(lds_reserve_kb) if self.overlap_bptt else 0
+        self._configured = False
+        self.timing = False          # True: record events around every segment's collectives (bench.py `allreduce` object)
+        self._events = []
+
+    def _configure(self):
+        if not self._configured:
+            from . import lib
+            lib.dp_config(self.overlap_bptt, self.lds_reserve_kb)
+            self._configured = True
 
     def _buckets(self, t, lo, hi):
         for off in range(lo, hi, self.bucket):
             yield t[off:min(hi, off + self.bucket)]
 
-    def all_reduce(self, grads: torch.Tensor, loss: torch.Tensor | None = None, extra: torch.Tensor | None = None):
+    def _flags(self, works, loss, err):
+        if loss is not None:
+            works.append(dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if err is not None:
+            works.append(dist.all_reduce(err, op=dist.ReduceOp.MAX, group=self.group, async_op=True))
+
+    def all_reduce(self, grads: torch.Tensor, loss: torch.Tensor | None = None, err: torch.Tensor | None = None):
         """Plain form: everything after backward has finished (also what the CPU tests drive)."""
-        if self.world == 1:
+        if not self.active:
             return
         works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                  for b in self._buckets(grads, 0, grads.numel())]
-        for t in (loss, extra):
-            if t is not None:
-                works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._flags(works, loss, err)
         for w in works:
             w.wait()
 
     def reduce_after_backward(self, model):
         """Call right after `model.backward()` has been ENQUEUED (it need not have run yet)."""
-        if self.world == 1:
+        if not self.active:
             return
         grads = model.grads
         if not grads.is_cuda:
             return self.all_reduce(grads, model._loss, model._err)
         from . import lib
+        self._configure()
         if self.comm is None:
             self.comm = torch.cuda.Stream()
         bounds = lib.grad_segments(model.shape)
         works = []
+        evs = []
         with torch.cuda.stream(self.comm):
             for seg in (2, 1, 0):                       # completion order inside taco_backward
                 lib.wait_grad_segment(seg, self.comm)   # device-side: the collectives below start when the segment is final
+                if self.timing:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record(self.comm)
                 for b in self._buckets(grads, bounds[seg], bounds[seg + 1]):
                     works.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-            for t in (model._loss, model._err):
-                works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                if self.timing:
+                    for w in works:
+                        w.wait()                        # (comm stream waits for the backend's stream; device side)
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record(self.comm)
+                    evs.append((seg, e0, e1))
+            self._flags(works, model._loss, model._err)
         for w in works:
             w.wait()                                    # the CURRENT stream waits for the collective (no host block with RCCL)
         torch.cuda.current_stream().wait_stream(self.comm)
+        if self.timing:
+            self._events.append(evs)
+
+    def describe(self, model):
+        """Static facts of the exchange for reports: bytes and bucket count per segment."""
+        from . import lib
+        b = lib.grad_segments(model.shape)
+        names = {2: 'post-net', 1: 'decoder', 0: 'encoder'}
+        return [{'segment': names[s], 'bytes': 4 * (b[s + 1] - b[s]), 'buckets': -(-(b[s + 1] - b[s]) // self.bucket)}
+                for s in (2, 1, 0)]
+
+    def segment_times_us(self):
+        """Median microseconds per segment of the recorded steps (timing=True); host synchronisation."""
+        if not self._events:
+            return None
+        torch.cuda.synchronize()
+        out = {}
+        for seg in (2, 1, 0):
+            xs = sorted(e0.elapsed_time(e1) * 1e3 for evs in self._events for s, e0, e1 in evs if s == seg)
+            out[{2: 'post-net', 1: 'decoder', 0: 'encoder'}[seg]] = xs[len(xs) // 2]
+        self._events = []
+        return out

@@ -63,6 +63,8 @@ EXPORTS = {
     'taco_clear_error': (C.c_int, [_SH, _I, _P, _P]),
     'taco_grad_segments': (C.c_int, [_SH, C.POINTER(C.c_int64)]),
     'taco_wait_grad_segment': (C.c_int, [_I, _P]),
+    'taco_dp_config': (C.c_int, [_I, _I]),
+    'taco_debug_spin': (C.c_int, [_I, _I, _I, _I, _P]),
     'taco_denorm_unframe': (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'taco_griffinlim_workspace_bytes': (C.c_int64, [_I, _I]),
     'taco_griffinlim': (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
@@ -221,6 +223,17 @@ def grad_segments(shape):
 def wait_grad_segment(seg, stream):
     """Device-side wait of `stream` (a torch.cuda.Stream) for segment `seg` of this thread's last taco_backward."""
     _check(_lib.taco_wait_grad_segment(int(seg), C.c_void_p(stream.cuda_stream)), 'taco_wait_grad_segment')
+
+
+def dp_config(overlap_bptt=False, lds_reserve_kb=0):
+    """Process-wide data-parallel options (include/taco_hip.h taco_dp_config)."""
+    _check(_lib.taco_dp_config(int(bool(overlap_bptt)), int(lds_reserve_kb)), 'taco_dp_config')
+
+
+def debug_spin(blocks, threads, lds_bytes, usec, stream=None):
+    """Communication-kernel stand-in (co-residency tests): spins `usec` microseconds on `stream` (default: current)."""
+    sp = stream_ptr() if stream is None else C.c_void_p(stream.cuda_stream)
+    _check(_lib.taco_debug_spin(int(blocks), int(threads), int(lds_bytes), int(usec), sp), 'taco_debug_spin')
 
 
 def denorm_unframe(output, stft_mean, stft_std, r, want_spec=True, want_mag_t=False):

@@ -1,5 +1,6 @@
 """train.py -- host driver with the reference's CLI and loop contract (train.py:16-126): -t/--train-set, -d/--debug,
--r/--restore; LR annealing every 1000 steps, loss-explosion guard, checkpoint every SAVE_EVERY steps.
+-r/--restore; LR annealing every 1000 steps, loss-explosion guard, checkpoint + listening sample every SAVE_EVERY steps
+(train.py:85-103; the TensorBoard wrapping is out of scope, the sample is written as .wav / .npy under log/<save_path>/).
 Without a preprocessed corpus under data/<set>/ it trains on synthetic Nancy-shaped batches."""
 from __future__ import annotations
 
@@ -14,6 +15,26 @@ from .config import SAVE_EVERY, Config
 from .data import synthetic_batch
 from .dist import GradReducer, init_from_env
 from .model import Tacotron
+
+
+def save_sample(model, out_dir, step, n_iter=50):
+    """train.py:92-103: `ideal` = the target spectrogram of utterance 0 through Griffin-Lim, `sample` = the model's output for
+    it, plus its alignment; both de-normalised with the corpus statistics (identity for synthetic data)."""
+    from . import lib
+    from .griffinlim import invert_spectrogram
+    from .test import write_wav
+    c = model.config
+    os.makedirs(out_dir, exist_ok=True)
+    dev = model.output.device
+    mean = torch.as_tensor(model.stft_mean if model.stft_mean is not None else np.zeros(c.fft_size * c.r), dtype=torch.float32, device=dev)
+    std = torch.as_tensor(model.stft_std if model.stft_std is not None else np.ones(c.fft_size * c.r), dtype=torch.float32, device=dev)
+    pair = torch.stack([model.inputs['stft'][0], model.output[0]]).contiguous()       # (2, Td, 1025 r): ideal, sample
+    wav = invert_spectrogram(pair, mean, std, c.r, n_iter=n_iter, seed=step).cpu().numpy()
+    spec = lib.denorm_unframe(pair, mean, std, c.r).cpu().numpy()
+    write_wav(os.path.join(out_dir, 'ideal_%d.wav' % step), wav[0])
+    write_wav(os.path.join(out_dir, 'sample_%d.wav' % step), wav[1])
+    np.save(os.path.join(out_dir, 'sample_%d_spec.npy' % step), spec[1])
+    np.save(os.path.join(out_dir, 'attention_%d.npy' % step), model.alignments[0].cpu().numpy())
 
 
 def load_corpus(data_path, seed=0):
@@ -52,7 +73,7 @@ def latest_checkpoint(ckpt_prefix):
     return best
 
 
-def train(config, num_steps=1000000, log_every=50):
+def train(config, num_steps=1000000, log_every=50, save_every=SAVE_EVERY):
     rank, world, local = init_from_env()
     torch.cuda.set_device(local)
     corpus = load_corpus(config.data_path)
@@ -91,7 +112,7 @@ def train(config, num_steps=1000000, log_every=50):
         model.set_inputs(next_batch(step))
         model.step(lr)
         gs = model.global_step
-        if gs % log_every == 0 or gs % SAVE_EVERY == 0:
+        if gs % log_every == 0 or gs % save_every == 0:
             loss = float(model.loss)                      # the only host sync, every log_every steps
             model.check()                                 # decoder exchange time-outs surface here (sticky flag; the
             #                                               guarded Adam update skipped itself in the meantime)
@@ -102,9 +123,17 @@ def train(config, num_steps=1000000, log_every=50):
                 break
         if gs % 1000 == 0:
             lr *= config.annealing_rate                   # train.py:82-83
-        if gs % SAVE_EVERY == 0 and gs != 0 and rank == 0:
-            os.makedirs(os.path.dirname(ckpt_prefix) or '.', exist_ok=True)
-            torch.save(model.state_dict(), '%s-%d' % (ckpt_prefix, gs))
+        if gs % save_every == 0 and gs != 0:
+            if rank == 0:
+                print('saving weights')
+                os.makedirs(os.path.dirname(ckpt_prefix) or '.', exist_ok=True)
+                torch.save(model.state_dict(), '%s-%d' % (ckpt_prefix, gs))
+                print('saving sample')
+                save_sample(model, os.path.join('log', config.save_path), gs)
+            if world > 1:
+                # rank 0 spent a while on the host; the others must not run ahead into the next step's collectives (and the
+                # persistent decoder kernels of a rank that waits inside a collective keep spinning on their peers)
+                torch.distributed.barrier()
     return model
 
 

@@ -75,3 +75,40 @@ def test_two_rank_sum_allreduce_matches_full_batch():
         assert abs(l - loss) < 1e-5 * loss
     assert np.array_equal(res[0][1], res[1][1])          # identical reduced gradients on both ranks
     assert np.array_equal(res[0][3], res[1][3])          # replicas stay bit-identical after clip + Adam
+
+
+def _flag_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from tacotron_amd.dist import GradReducer, init_from_env
+    init_from_env('gloo')
+    red = GradReducer(bucket_floats=1 << 10)
+    g = torch.ones(3000)
+    err = torch.tensor([1 if rank == 1 else 0, 0], dtype=torch.int32)   # rank 1's forward kernel timed out; the word is sticky
+    seen = []
+    for _ in range(40):                                                # > 32 steps: a SUM would wrap 2^32 -> 0 at world 2
+        loss = torch.tensor([1.0, 0.0, 0.0])
+        red.all_reduce(g.clone(), loss, err)
+        seen.append(err.tolist())
+    q.put((rank, seen, float(loss[0])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_error_words_stay_set_across_many_reduced_steps():
+    """the sticky decoder error words ride along with MAX, so a flag raised on ONE rank is seen by every
+    rank as exactly 1 for as long as nobody clears it (SUM multiplied it by the world size per step and wrapped to 0)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_flag_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda t: t[0])
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+    for rank, seen, loss in res:
+        assert all(s == [1, 0] for s in seen), (rank, seen[:3], seen[-3:])
+        assert loss == 2.0                                              # the loss is still a SUM

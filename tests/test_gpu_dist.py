@@ -110,3 +110,28 @@ def test_two_process_step_matches_full_batch(built_lib):
     for a, f in zip(res[0][2], full_losses):
         assert abs(a - f) <= 1e-5 * abs(f)
     assert abs(res[0][3] - full_gn) <= 1e-4 * full_gn
+
+
+def test_comm_standin_coresidency_with_decoder_bptt(built_lib):
+    """VERDICT r2 #1a.  An RCCL-footprint stand-in (64 workgroups x 256 threads x 64 KB LDS, spinning) on a second stream while
+    taco_backward runs at S1.  Default mode: the post-net segment is announced AFTER the BPTT kernel, so a collective can never
+    compete with that persistent launch -- the BPTT runs at its solo time.  Opt-in overlap mode with the LDS reserve: the
+    stand-in co-resides with the BPTT workgroups in BOTH dispatch orders -- no exchange time-out, BPTT <= 1.3x solo, and the
+    stand-in is not held back (it ends within 1.25x its own spin time, i.e. under the BPTT kernel)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        'dp_coresidency', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'dp_coresidency.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.measure(spin_us=2000, reps=3, verbose=True)
+    solo = res['solo']['bptt_ms']
+    for name, r in res.items():
+        assert r['err'] == [0, 0], (name, r)
+    d = res['default: segment 2 announced after the BPTT kernel']
+    assert d['bptt_ms'] <= 1.1 * solo
+    assert d['spin_start_after_bwd_start_ms'] >= d['bptt_ms']          # its enqueue point lies behind the BPTT kernel
+    for k in ('overlap_bptt + 64 KB LDS reserve, stand-in behind the segment event',
+              'overlap_bptt + 64 KB LDS reserve, stand-in dispatched first'):
+        r = res[k]
+        assert r['bptt_ms'] <= 1.3 * solo, (k, r, solo)
+        assert r['spin_ms'] <= 1.25 * r['spin_nominal_ms'], (k, r)

@@ -1,0 +1,127 @@
+"""GPU: every BASELINE.json configuration at ITS OWN stated size against the CPU restatement in fp64.
+
+configs[0]  ARCTIC plumbing shape: B=2, r=5, Td=72, Tt=100 -- forward + backward + inference
+configs[3]  free-running inference at Tt=140 (data_input.MAX_TEXT_LEN), Td=180, B=1 and B=32: 180 autoregressive steps with no
+            teacher to pull the trajectory back, so rounding differences can only grow -- the error growth is printed per
+            quarter of the decode and the attention arg-max is compared wherever the oracle's margin allows
+configs[4]  VCTK shape on one GPU: 109 speakers at S1 (B=32, Tt=200, Td=180) -- forward + every gradient incl. the speaker
+            table and the per-layer speaker adapters
+Stated tolerances: outputs rel-L2 <= 1e-4 / max-abs <= 1e-3, alignments max-abs <= 1e-5, loss rel <= 1e-5,
+gradients rel-L2 <= 1e-3 per tensor, arg-max exact where the oracle's top-1/top-2 margin >= 1e-5."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import taco_numpy as on
+from oracle import taco_torch as ot
+from tests.test_gpu_model import Runner, _argmax_check, check_grads, f64
+from tests.util import report, small_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_infer(p, text, text_length, r, Td, speaker=None):
+    with torch.no_grad():
+        pt = ot.to_torch(p, torch.float64)
+        ti = {'text': torch.tensor(text, dtype=torch.int64), 'text_length': torch.tensor(text_length, dtype=torch.int64)}
+        if speaker is not None:
+            ti['speaker'] = torch.tensor(speaker, dtype=torch.int64)
+        s2, o2, a2, _ = ot.forward(pt, ti, r, Td, False, None)
+    return s2.numpy(), o2.numpy(), a2.numpy()
+
+
+def test_config0_arctic_plumbing_shape(built_lib):
+    r, V, B, Tt, Td = 5, 45, 2, 100, 72
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    p = on.init_params(V, r, seed=11, perturb=0.1)
+    inp, masks = small_case(r=r, V=V, B=B, Tt=Tt, Td=Td, seed=5)
+    R = Runner(built_lib, B, Tt, Td, r, V)
+    R.set(p, inp, masks)
+    R.forward()
+    R.backward()
+    lt, s2, o2, a2, ref = ot.loss_and_grads(p, f64(inp), r, Td, f64(masks))
+    r1, m1 = report('cfg0 seq2seq_output', R.s2s.cpu().numpy(), s2)
+    r2, m2 = report('cfg0 output', R.out.cpu().numpy(), o2)
+    r3, m3 = report('cfg0 alignments', R.al.cpu().numpy(), a2)
+    assert r1 < 1e-5 and m1 < 5e-5 and r2 < 1e-5 and m2 < 5e-5 and m3 < 1e-6
+    assert abs(R.loss[0].item() - lt) <= 1e-5 * lt
+    _argmax_check(R.al.cpu().numpy(), a2, inp['text_length'])
+    bad = check_grads(R, ref, tol=1e-3)
+    assert not bad, bad
+    Ri = Runner(built_lib, B, Tt, Td, r, V, train=False)
+    Ri.set(p, {'text': inp['text'], 'text_length': inp['text_length']})
+    Ri.infer()
+    si, oi, ai = _oracle_infer(p, inp['text'], inp['text_length'], r, Td)
+    assert report('cfg0 infer seq2seq_output', Ri.s2s.cpu().numpy(), si)[0] < 1e-4
+    assert report('cfg0 infer output', Ri.out.cpu().numpy(), oi)[0] < 1e-4
+    assert report('cfg0 infer alignments', Ri.al.cpu().numpy(), ai)[1] < 1e-5
+
+
+@pytest.mark.parametrize('B', [1, 32])
+def test_config3_free_running_inference_full_length(built_lib, B):
+    from tacotron_amd.data import synthetic_batch
+    r, V, Tt, Td = 2, 60, 140, 180
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    batch = synthetic_batch(B, Tt, Td, r, V, seed=77, min_len=40)
+    text, tl = batch['text'].numpy(), batch['text_length'].numpy()
+    R = Runner(built_lib, B, Tt, Td, r, V, train=False)
+    R.pb.init_(seed=0)
+    p = R.pb.to_dict()
+    R.set(p, {'text': text, 'text_length': tl})
+    R.infer()
+    si, oi, ai = _oracle_infer(p, text, tl, r, Td)
+    s2s, out, al = R.s2s.cpu().numpy(), R.out.cpu().numpy(), R.al.cpu().numpy()
+    # autoregressive error growth: rel-L2 of the decoder output per quarter of the decode
+    q = Td // 4
+    growth = [float(np.linalg.norm(s2s[:, i * q:(i + 1) * q] - si[:, i * q:(i + 1) * q]) /
+                    np.linalg.norm(si[:, i * q:(i + 1) * q])) for i in range(4)]
+    print('  B=%d free-running decode, rel-L2 of seq2seq_output per quarter of the %d steps: %s' %
+          (B, Td, ' '.join('%.2e' % g for g in growth)))
+    r1, m1 = report('cfg3 B=%d seq2seq_output' % B, s2s, si)
+    r2, m2 = report('cfg3 B=%d output' % B, out, oi)
+    r3, m3 = report('cfg3 B=%d alignments' % B, al, ai)
+    assert r1 < 1e-4 and m1 < 1e-3 and r2 < 1e-4 and m2 < 1e-3 and m3 < 1e-5
+    assert growth[3] < 1e-4
+    _argmax_check(al, ai, tl)
+    for b, L in enumerate(tl):
+        if L < Tt:
+            assert float(np.abs(al[b, :, L:]).max()) == 0
+
+
+def test_config4_vctk_109_speakers_full_size(built_lib):
+    from tacotron_amd.data import synthetic_batch
+    B, Tt, Td, r, V, S = 32, 200, 180, 2, 60, 109
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    batch = synthetic_batch(B, Tt, Td, r, V, num_speakers=S)
+    inp = {k: batch[k].numpy() for k in ('text', 'text_length', 'mel', 'stft', 'speaker')}
+    rng = np.random.default_rng(1)
+    masks = {'enc_keep1': rng.integers(0, 2, (B, Tt, 256)), 'enc_keep2': rng.integers(0, 2, (B, Tt, 128)),
+             'dec_keep1': rng.integers(0, 2, (B, Td, 256)), 'dec_keep2': rng.integers(0, 2, (B, Td, 128)),
+             'sample': rng.integers(0, 2, (Td, B))}
+    R = Runner(built_lib, B, Tt, Td, r, V, S=S)
+    R.pb.init_(seed=0)
+    p = R.pb.to_dict()
+    R.set(p, inp, masks)
+    R.forward()
+    R.backward()
+    lt, s2, o2, a2, ref = ot.loss_and_grads(p, f64(inp), r, Td, f64(masks))
+    r1, m1 = report('cfg4 seq2seq_output', R.s2s.cpu().numpy(), s2)
+    r2, m2 = report('cfg4 output', R.out.cpu().numpy(), o2)
+    r3, m3 = report('cfg4 alignments', R.al.cpu().numpy(), a2)
+    assert r1 < 1e-4 and m1 < 1e-3 and r2 < 1e-4 and m2 < 1e-3 and m3 < 1e-5
+    assert abs(R.loss[0].item() - lt) <= 1e-5 * lt
+    _argmax_check(R.al.cpu().numpy(), a2, inp['text_length'])
+    spk_names = [k for k in ref if 'speaker' in k or 'spk' in k]
+    assert spk_names, 'the oracle lists no speaker parameters'
+    print('  speaker-path tensors:', spk_names)
+    # only the speakers drawn in this batch have a table gradient
+    used = np.unique(inp['speaker'])
+    tab = [k for k in ref if ref[k] is not None and ref[k].shape == (S, 16)]
+    assert len(tab) == 1
+    got_tab = R.pb.to_dict(R.grads)[tab[0]]
+    unused = np.setdiff1d(np.arange(S), used)
+    assert np.all(got_tab[unused] == 0) and np.all(np.abs(got_tab[used]).sum(1) > 0)
+    bad = check_grads(R, ref, tol=1e-3)
+    assert not bad, bad

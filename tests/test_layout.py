@@ -20,7 +20,8 @@ def test_exports_match_header(built_lib):
     for name in sorted(declared):
         assert hasattr(raw, name), 'libtaco_hip.so does not export %s' % name
     assert declared == set(built_lib.EXPORTS), (declared ^ set(built_lib.EXPORTS))
-    assert built_lib.version() == 111
+    declared_v = int(re.search(r'#define\s+TACO_VERSION\s+(\d+)', hdr).group(1))
+    assert built_lib.version() == declared_v
 
 
 @pytest.mark.parametrize('V,r,S', [(60, 2, 1), (20, 5, 1), (33, 3, 1), (60, 2, 109), (20, 2, 7)])

@@ -1,0 +1,105 @@
+"""Data-parallel co-residency probe (VERDICT r2 #1a): does a collective-sized kernel on a second stream disturb the
+persistent decoder BPTT launch (256 workgroups x 512 threads, up to 158 KB LDS each -- one per CU, every CU), and the other way
+round?  RCCL cannot run with one GPU, so an RCCL-footprint stand-in is used: 64 workgroups x 256 threads x 64 KB LDS spinning
+for a fixed time (taco_debug_spin).  Measured per mode (taco_dp_config) and per dispatch order:
+
+  bptt_ms      decoder_bwd_kernel launch -> end (HIP events on its stream; includes any wait for CUs)
+  spin_ms      stand-in enqueue-point -> end on the communication stream (nominal = its spin time; more = it waited for CUs)
+  bwd_ms       whole taco_backward on the main stream
+  err          decoder error words (exchange time-outs)
+
+usage: python tools/dp_coresidency.py  [> profiles/r03_dp_coresidency.txt]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+SPIN_BLOCKS, SPIN_THREADS, SPIN_LDS = 64, 256, 64 * 1024
+
+
+def build_model(B=32, Tt=200, Td=180):
+    from tacotron_amd.config import Config
+    from tacotron_amd.data import synthetic_batch
+    from tacotron_amd.model import Tacotron
+    c = Config()
+    c.r, c.vocab_size = 2, 60
+    m = Tacotron(c, synthetic_batch(B, Tt, Td, 2, 60), train=True, seed=0)
+    return m, m.draw_masks()
+
+
+def one(m, masks, order, spin_us, comm):
+    """order: None (no stand-in), 'first' (stand-in enqueued just before taco_backward), 'segment' (on the communication stream
+    behind taco_wait_grad_segment(2), i.e. exactly where GradReducer would enqueue the post-net all-reduce)."""
+    from tacotron_amd import lib
+    m.forward(masks)
+    torch.cuda.synchronize()
+    lib.profile_read(1)
+    lib.profile_enable(2)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    main = torch.cuda.current_stream()
+    if order == 'first':
+        comm.wait_stream(main)
+        with torch.cuda.stream(comm):
+            e0.record(comm)
+            lib.debug_spin(SPIN_BLOCKS, SPIN_THREADS, SPIN_LDS, spin_us, comm)
+            e1.record(comm)
+    b0.record(main)
+    m.backward()
+    b1.record(main)
+    if order == 'segment':
+        with torch.cuda.stream(comm):
+            lib.wait_grad_segment(2, comm)
+            e0.record(comm)
+            lib.debug_spin(SPIN_BLOCKS, SPIN_THREADS, SPIN_LDS, spin_us, comm)
+            e1.record(comm)
+    torch.cuda.synchronize()
+    lib.profile_enable(0)
+    bptt = lib.profile_read(1)
+    err = m._err.tolist()
+    res = {'bptt_ms': bptt[0], 'bwd_ms': b0.elapsed_time(b1), 'err': err,
+           'spin_ms': e0.elapsed_time(e1) if order else None,
+           'spin_start_after_bwd_start_ms': b0.elapsed_time(e0) if order else None}
+    if err[0] or err[1]:
+        lib.clear_error(m.shape, True, m.workspace)
+    return res
+
+
+def measure(spin_us=2000, reps=3, verbose=True):
+    from tacotron_amd import lib
+    m, masks = build_model()
+    comm = torch.cuda.Stream()
+    out = {}
+    for _ in range(2):
+        one(m, masks, None, 0, comm)
+
+    def med(xs, k):
+        v = sorted(x[k] for x in xs if x[k] is not None)
+        return v[len(v) // 2] if v else None
+
+    cases = [('solo', (0, 0), None, 0),
+             ('default: segment 2 announced after the BPTT kernel', (0, 0), 'segment', spin_us),
+             ('overlap_bptt + 64 KB LDS reserve, stand-in behind the segment event', (1, 64), 'segment', spin_us),
+             ('overlap_bptt + 64 KB LDS reserve, stand-in dispatched first', (1, 64), 'first', 2 * spin_us),
+             ('overlap_bptt, NO reserve, stand-in behind the segment event', (1, 0), 'segment', spin_us),
+             ('overlap_bptt, NO reserve, stand-in dispatched first', (1, 0), 'first', 2 * spin_us)]
+    for name, (ov, kb), order, us in cases:
+        lib.dp_config(ov, kb)
+        runs = [one(m, masks, order, us, comm) for _ in range(reps)]
+        r = {k: med(runs, k) for k in ('bptt_ms', 'bwd_ms', 'spin_ms', 'spin_start_after_bwd_start_ms')}
+        r['err'] = [max(x['err'][0] for x in runs), max(x['err'][1] for x in runs)]
+        r['spin_nominal_ms'] = us / 1e3
+        out[name] = r
+        if verbose:
+            print('%-72s bptt %.2f ms  backward %.2f ms  stand-in %s (nominal %.1f, enqueue point %s ms after backward start)  err %s' %
+                  (name, r['bptt_ms'], r['bwd_ms'], '%.2f ms' % r['spin_ms'] if r['spin_ms'] is not None else '-', us / 1e3,
+                   '%.2f' % r['spin_start_after_bwd_start_ms'] if r['spin_start_after_bwd_start_ms'] is not None else '-', r['err']))
+    lib.dp_config(0, 0)
+    return out
+
+
+if __name__ == '__main__':
+    print('stand-in: %d workgroups x %d threads x %d KB LDS; S1 shape (B=32, Tt=200, Td=180); medians of 3' %
+          (SPIN_BLOCKS, SPIN_THREADS, SPIN_LDS // 1024))
+    measure()
