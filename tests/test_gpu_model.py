@@ -311,7 +311,8 @@ def test_medium_shape_forward_backward(built_lib, grad_tol=2e-4):
     R.set(p, inp, masks)
     R.forward()
     R.backward()
-    lt, s2, o2, a2, ref = ot.loss_and_grads(p, f64(inp), r, Td, f64(masks))
+    adj, _ = l1_tie_adjusted(R, p, inp, masks, r, Td)
+    lt, s2, o2, a2, ref = ot.loss_and_grads(p, f64(adj), r, Td, f64(masks))
     assert report('s2s', R.s2s.cpu().numpy(), s2)[0] < 1e-5
     assert report('out', R.out.cpu().numpy(), o2)[0] < 1e-5
     assert report('align', R.al.cpu().numpy(), a2)[1] < 1e-6
@@ -380,11 +381,10 @@ def test_medium_shape_with_gemm2_forced(built_lib, variant, monkeypatch):
     otherwise keep the 64x64 kernel): batched conv-bank launch, tap-split projections, atomic-accumulate bank backward."""
     monkeypatch.setenv('TACO_GEMM2_MIN_TILES', '1')
     monkeypatch.setenv('TACO_GEMM2_VARIANT', variant)
-    # Gradient tolerance = the stated 1e-3 (SURVEY 8c), not the 2e-4 the other tests happen to meet: with this kernel's k
-    # summation order the encoder pre_net / embedding gradients of rows 0-2 once moved by 2.3e-4 against the fp64 oracle
-    # although every launch alone was within 5e-7 of the other kernel and all forward tensors within 1e-6 (bisected with
-    # tools/v2_bisect.py / v2_flip.py) -- rounding-level sensitivity of the 12-step BPTT at this seed, not a kernel defect.
-    test_medium_shape_forward_backward(built_lib, grad_tol=1e-3)
+    # Same 2e-4 gradient tolerance as everywhere else.  (Round 2 ran this at 1e-3 because the encoder pre_net / embedding
+    # gradients once moved by 2.3e-4 with this kernel's summation order; the cause is the L1 loss's sign() at a rounding-level
+    # tie -- one flipped sign in d loss / d output -- which l1_tie_adjusted now takes out of the comparison.)
+    test_medium_shape_forward_backward(built_lib, grad_tol=2e-4)
     test_backward_without_masks_and_ragged_lengths(built_lib)
 
 
@@ -422,6 +422,40 @@ def _argmax_check(al_hip, al_ref, text_length, min_margin=1e-5):
     return int(ok.sum())
 
 
+def l1_tie_adjusted(R, p, inp, masks, r, Td):
+    """The loss is a plain L1 sum (tacotron.py:158-160), so its gradient w.r.t. the outputs is sign(output - target): a
+    discontinuous function.  Wherever |output - target| is below the forward rounding error (~1e-6) the fp32 HIP path and the
+    fp64 oracle may legitimately sit on opposite sides, and ONE such tie changes d loss / d output by 2 in one of 11.8 M
+    elements -- 6e-4 of its norm at S1, which the backward pass then carries into every parameter gradient (most visibly into
+    those with strong cancellation: embedding, encoder pre_net).  This helper finds those ties with a forward-only oracle run,
+    asserts they really are ties (|oracle residual| <= 1e-5), and returns targets nudged by <= 2e-5 at exactly those positions
+    so that the oracle's sign pattern equals the HIP path's; gradients can then be compared at the stated tolerance without
+    the comparison being decided by a coin flip.  Returns (inputs with adjusted targets, number of ties)."""
+    with torch.no_grad():
+        pt = ot.to_torch(p, torch.float64)
+        ti = {'text': torch.tensor(inp['text'], dtype=torch.int64), 'text_length': torch.tensor(inp['text_length'], dtype=torch.int64),
+              'mel': torch.tensor(inp['mel'], dtype=torch.float64), 'stft': torch.tensor(inp['stft'], dtype=torch.float64)}
+        if 'speaker' in inp:
+            ti['speaker'] = torch.tensor(inp['speaker'], dtype=torch.int64)
+        tm = {k: torch.tensor(np.asarray(v), dtype=torch.float64) for k, v in (masks or {}).items()}
+        s2, o2, _, _ = ot.forward(pt, ti, r, Td, True, tm)
+    adj = dict(inp)
+    n_ties = 0
+    for key, ref, hip in (('mel', s2.numpy(), R.s2s.cpu().numpy()), ('stft', o2.numpy(), R.out.cpu().numpy())):
+        tgt = np.asarray(inp[key], dtype=np.float64)
+        d_ref, d_hip = ref - tgt, hip.astype(np.float64) - tgt
+        ties = np.sign(d_ref) != np.sign(d_hip)
+        if ties.any():
+            assert np.abs(d_ref[ties]).max() <= 1e-5, 'a sign difference that is not a rounding-level tie: %g' % np.abs(d_ref[ties]).max()
+            tgt = tgt.copy()
+            tgt[ties] = ref[ties] - np.sign(d_hip[ties]) * 1e-9    # oracle residual takes the HIP path's sign (or 0 where HIP is exactly on target)
+            adj[key] = tgt
+        n_ties += int(ties.sum())
+        print('  L1 sign ties in %s: %d of %d elements (max |oracle residual| at a tie %.1e)' %
+              (key, int(ties.sum()), ties.size, float(np.abs(d_ref[ties]).max()) if ties.any() else 0.0))
+    return adj, n_ties
+
+
 def test_full_size_vs_oracle(built_lib):
     """BASELINE configs[1] at FULL size (S1: B=32, Tt=200, Td=180, r=2) against the CPU restatement in fp64: outputs,
     alignments, arg-max on all 5,760 (b,t) whose margin is >= 1e-5, loss, and EVERY parameter gradient (180 steps of BPTT).
@@ -436,7 +470,8 @@ def test_full_size_vs_oracle(built_lib):
     R.set(p, inp, masks)
     R.forward()
     R.backward()
-    lt, s2, o2, a2, ref = ot.loss_and_grads(p, f64(inp), r, Td, f64(masks))
+    adj, n_ties = l1_tie_adjusted(R, p, inp, masks, r, Td)
+    lt, s2, o2, a2, ref = ot.loss_and_grads(p, f64(adj), r, Td, f64(masks))
     r1, m1 = report('S1 seq2seq_output', R.s2s.cpu().numpy(), s2)
     r2, m2 = report('S1 output', R.out.cpu().numpy(), o2)
     r3, m3 = report('S1 alignments', R.al.cpu().numpy(), a2)
@@ -448,7 +483,9 @@ def test_full_size_vs_oracle(built_lib):
     #  the 5,760 (b,t) clear the 1e-5 margin; the peaked fixture below covers the sharp regime)
     n = _argmax_check(R.al.cpu().numpy(), a2, inp['text_length'])
     assert n > 1000
-    bad = check_grads(R, ref, tol=1e-3)
+    # with the L1 ties taken out of the comparison the gradients meet the tolerance of the SMALL cases (2e-4), 5x inside the
+    # stated 1e-3 for this size
+    bad = check_grads(R, ref, tol=2e-4)
     assert not bad, bad
 
 
