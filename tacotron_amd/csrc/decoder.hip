@@ -1397,6 +1397,7 @@ int env_cluster(int dflt) {
 }  // namespace
 
 int decoder_last_cluster(int which) { return g_last_cluster[which & 1]; }
+void decoder_note_cluster(int which, int P) { g_last_cluster[which & 1] = P; }
 
 int64_t decoder_xchg_bytes(int B, int Tt) {
   const int TtP = (Tt + 3) & ~3;

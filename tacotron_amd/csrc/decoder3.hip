@@ -1,0 +1,949 @@
+// decoder3.hip -- third-generation persistent attention-decoder FORWARD kernel (tacotron.py:46-105 create_decoder + :134-138
+// dynamic_decode; same TF-r1.2 semantics and the same folded step as decoder.hip: rounds G0 C0 G1 C1 G2 C2 OUT E).
+//
+// What changed against decoder.hip (cluster of 8 workgroups per batch ROW, weights streamed from L2 every step):
+//   * a cluster is 32 workgroups and owns R = 4 (2, 1 for small batches) batch rows.  8 clusters x 32 = 256 workgroups, one
+//     per CU; block b -> (cluster = b % 8, peer = b / 8), so with the dispatcher's round-robin a cluster sits on ONE XCD and
+//     its exchange traffic stays inside that XCD's L2 (a speed assumption only: every granule is self-validating).
+//   * 1/32 of the decoder weight set is 187 KB: it is loaded ONCE per launch into REGISTERS (~94 floats per lane) and stays
+//     there for all Td steps.  The step loop issues no weight load at all; the only vector-memory traffic of a step is the
+//     exchange itself, the stash / output stores and a few prefetched bytes.  (decoder.hip streams 0.8 MB per workgroup per
+//     step through the CU's 64 B/clk vector-memory pipe; its probes price that at 4.7 us of a 24.7 us step, in front of the
+//     exchange polls in the in-order queue.)
+//   * "a wave owns its columns": a mat-vec's K range is split over the lanes of ONE wave (64, 32 or 16 lanes per output
+//     column), partial sums are combined with DPP adds inside the wave, the epilogue runs in the lanes that hold the totals and
+//     publishes straight from there.  No LDS partial sums, no mid-round barrier, no single-wave finalize: a round is
+//     mat-vec -> DPP -> epilogue -> publish -> gather -> ONE barrier.
+//   * the R rows of a cluster share every weight register: one ds_read_b128 fetches x[k] of all four rows, four FMAs use it.
+// The per-row attention-memory folds (VWx / VWg, model.hip) of the wave's own columns are register-resident as well.
+//
+// Scope: Tt <= 256, B <= 32, r in {2, 5} (the two frame-group sizes the drivers and fixtures use); training requires the
+// hoisted pre-net (model.hip always provides it).  Anything else returns TACO_ENOTFOUND and the caller takes decoder.hip.
+#include <type_traits>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int NT = 512;
+constexpr int P3 = 32;       // peers per cluster
+constexpr int TTP = 256;     // padded memory length (Tt <= 256)
+
+typedef unsigned long long u64;
+typedef __attribute__((address_space(1))) u64 gu64;
+typedef __attribute__((address_space(1))) int gi32;
+
+// per-row granule regions (offsets in granules; a cluster's area holds R consecutive copies per column: [n][R])
+constexpr int X3_X = 0;         // 256   in-proj output x             } gathered together as one 768-column vector
+constexpr int X3_G0 = 256;      // 512   GRU-1 gates                  }
+constexpr int X3_C = 768;       // 3*256 new GRU states
+constexpr int X3_G = 1536;      // 2*512 gates of GRU-2, GRU-3
+constexpr int X3_O = 2560;      // NO <= 1024  [q | cell_output | pad]
+constexpr int X3_P1 = 3584;     // 256   pre-net layer 1 of the next step
+constexpr int X3_P2 = 3840;     // 128
+constexpr int X3_E = 3968;      // TTP   energies
+constexpr int kX3Row = 3968 + TTP;   // 4224 <= decoder.hip's kXchgFixed + TtP (the workspace area is shared)
+
+#ifdef TACO_DEC_PROBES
+constexpr bool kProbes3 = true;   // timing probes (garbage results, real timing): libtaco_probe.so only
+#else
+constexpr bool kProbes3 = false;
+#endif
+struct Xc {
+  gu64* base;
+  unsigned epoch;
+  int* err;
+  int* dead;   // LDS
+  bool fast;   // every peer of this cluster runs on the same XCD (checked at kernel start): publish at workgroup scope
+  int fake;    // probe build: bit 2 (TACO_DEC_FAKEX) = no polling at all
+  long long* trace;   // probe build: shader-clock stamps of one workgroup at one step (TACO_DEC_TRACE=1), else null
+  int tslot;
+  int polls;          // probe build: poll iterations of this thread in the traced step
+};
+__device__ __forceinline__ void tstamp(Xc& X) {
+  if (kProbes3 && X.trace) {
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): attribute LDS time to the section that issued it
+    if (threadIdx.x == 0) X.trace[X.tslot] = clock64();
+    X.tslot++;
+  }
+}
+
+// Publishing a granule.  Agent scope (sc1) is the placement-independent form: the store is written through to the memory side
+// and the line leaves the XCD's L2, so every reader -- same XCD or not -- fetches it across the fabric (0.37 us per hop,
+// tools/micro/pingpong).  When ALL 32 peers of a cluster share an XCD (verified at kernel start from HW_REG_XCC_ID, not
+// assumed) the store is issued at workgroup scope instead: it stays in that XCD's L2, where the peers' L1-bypassing agent-scope
+// loads find it (0.21 us per hop).  Which form a cluster uses is decided once per launch, identically by all of its peers.
+template <int R>
+__device__ __forceinline__ void put_granule(const Xc& X, int reg, int n, int rho, float v) {
+  gu64* p = X.base + (unsigned)((reg + n) * R + rho);
+  const u64 g = ((u64)X.epoch << 32) | (u64)__float_as_uint(v);
+  if (X.fast) __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ bool spin_fail(unsigned& spin, const Xc& X) {
+  if ((++spin & 1023u) == 0u) {
+    if (spin > (1u << 23) || __hip_atomic_load((gi32*)X.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+      __hip_atomic_store((gi32*)X.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *X.dead = 1;
+      return true;
+    }
+  }
+  __builtin_amdgcn_s_sleep(1);
+  return false;
+}
+
+// All-gather of an N-column vector (R rows per column) published in region `reg`: every thread polls up to MAXU units of
+// G = min(R, 2) adjacent granules until their tags carry this step's epoch.  own(n): column computed by this workgroup (already
+// in LDS).  put(n, rho, v): LDS state update.
+// threadIdx.x behind an opaque move: everything a round derives from it (columns, row selections, stash / granule / LDS addresses)
+// is recomputed at the head of that round with a handful of VALU ops instead of being hoisted out of the step loop into
+// long-lived registers (first build: 256 VGPRs + 350 spilled; the resident weights need that room)
+__device__ __forceinline__ int opaque_tid() {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+struct NeedAll {
+  __device__ __forceinline__ bool operator()(int, int) const { return true; }
+};
+template <int R, int MAXU, class Own, class Put, class Need = NeedAll>
+__device__ __forceinline__ void gather(Xc& X, int reg, int N, Own own, Put put, Need need = Need()) {
+  constexpr int G = R >= 2 ? 2 : 1;
+  constexpr int UPC = R / G;   // units per column
+  if (*X.dead) return;
+  if (kProbes3 && (X.fake & 2)) return;
+  const int tid = opaque_tid();
+  int un[MAXU], uh[MAXU];
+  bool pend[MAXU];
+  bool any = false;
+#pragma unroll
+  for (int i = 0; i < MAXU; ++i) {
+    const int u = tid + i * NT;
+    un[i] = UPC == 2 ? (u >> 1) : u;
+    uh[i] = UPC == 2 ? (u & 1) : 0;
+    pend[i] = un[i] < N && !own(un[i]);
+    any |= pend[i];
+  }
+  unsigned spin = 0;
+  while (any) {
+    if (kProbes3) X.polls++;
+    u64 g[MAXU][G];
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i)
+      if (pend[i]) {
+        const gu64* p = X.base + (unsigned)((reg + un[i]) * R + uh[i] * G);
+#pragma unroll
+        for (int q = 0; q < G; ++q) g[i][q] = __hip_atomic_load(p + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    any = false;
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i)
+      if (pend[i]) {
+        bool ok = true;
+#pragma unroll
+        for (int q = 0; q < G; ++q) ok &= (unsigned)(g[i][q] >> 32) == X.epoch || !need(un[i], uh[i] * G + q);
+        if (ok) {
+#pragma unroll
+          for (int q = 0; q < G; ++q)
+            if (need(un[i], uh[i] * G + q)) put(un[i], uh[i] * G + q, __uint_as_float((unsigned)g[i][q]));
+          pend[i] = false;
+        } else {
+          any = true;
+        }
+      }
+    if (any && spin_fail(spin, X)) return;
+  }
+}
+
+// ---- register-resident mat-vec: column `col` of W (K x N, pitch ldw) split over LPC lanes; lane lk holds rows lk + LPC*j ----
+template <int KPL>
+struct WReg {
+  float w[KPL];
+};
+template <int KPL, int LPC>
+__device__ __forceinline__ void load_w(WReg<KPL>& r, const float* __restrict__ W, int ldw, int K, int col, int lk, bool active) {
+#pragma unroll
+  for (int j = 0; j < KPL; ++j) {
+    const int k = lk + LPC * j;
+    const float v = W[(int64_t)(k < K ? k : K - 1) * ldw + col];   // (branch-free: clamped address, value dropped when out of range)
+    r.w[j] = (active && k < K) ? v : 0.f;
+  }
+}
+// (native vector types, not arrays: an array element selected by the lane's row index would be placed on the stack -- scratch
+//  memory traffic in every epilogue; a vector element select is a chain of v_cndmask)
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct v1f {
+  float x;
+  __device__ __forceinline__ float& operator[](int) { return x; }
+  __device__ __forceinline__ const float& operator[](int) const { return x; }
+};
+template <int R> struct VecT;
+template <> struct VecT<4> { typedef v4f type; };
+template <> struct VecT<2> { typedef v2f type; };
+template <> struct VecT<1> { typedef v1f type; };
+template <int R>
+struct Acc {
+  typename VecT<R>::type v;
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int q = 0; q < R; ++q) v[q] = 0.f;
+  }
+};
+template <int R>
+struct XV {
+  typename VecT<R>::type v;
+};
+template <int R>
+__device__ __forceinline__ XV<R> lds_rows(const float* xp) {
+  XV<R> o;
+  if constexpr (R == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(xp);
+    o.v[0] = t.x; o.v[1] = t.y; o.v[2] = t.z; o.v[3] = t.w;
+  } else if constexpr (R == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(xp);
+    o.v[0] = t.x; o.v[1] = t.y;
+  } else {
+    o.v[0] = xp[0];
+  }
+  return o;
+}
+// x: LDS vector laid out [k][R].  The k loop is software-pipelined in chunks of CH rows (the next chunk's ds_reads are issued in
+// front of the current chunk's FMAs) with scheduling barriers at the chunk boundaries: left alone, hipcc hoists ALL KPL reads
+// of a mat-vec to its head (KPL x R live registers; with the resident weights that spilled ~500 registers to scratch).
+template <int R, int KPL, int LPC>
+__device__ __forceinline__ void mv(const WReg<KPL>& r, const float* x, int lk, Acc<R>& a) {
+  constexpr int CH = R == 4 ? 2 : 4;
+  constexpr int NCH = (KPL + CH - 1) / CH;
+  const float* xb = x + lk * R;
+  XV<R> cur[CH], nxt[CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i)
+    if (i < KPL) cur[i] = lds_rows<R>(xb + (LPC * i) * R);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
+      if ((c + 1) * CH + i < KPL) nxt[i] = lds_rows<R>(xb + (LPC * ((c + 1) * CH + i)) * R);
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
+      if (c * CH + i < KPL) {
+#pragma unroll
+        for (int q = 0; q < R; ++q) a.v[q] = fmaf(r.w[c * CH + i], cur[i].v[q], a.v[q]);
+      }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) cur[i] = nxt[i];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+// Sum over the LPC lanes of a column group; afterwards the LAST 16-lane row of the group holds the total in every lane.
+// In-row steps: bound_ctrl DPP moves, which hipcc folds into v_add_f32_dpp (one instruction per step).  Cross-row steps
+// (row_bcast with a row mask): written as the fused v_add_f32_dpp by hand -- rows outside the mask keep their value -- since the
+// compiler only emits v_mov_dpp + v_add (+ a zero-initialised temporary) for them.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int LPC>
+__device__ __forceinline__ float col_sum(float v) {
+  v = dpp_add<0xb1>(v);          // quad_perm [1,0,3,2]
+  v = dpp_add<0x4e>(v);          // quad_perm [2,3,0,1]
+  v = dpp_add<0x124>(v);         // row_ror:4
+  v = dpp_add<0x128>(v);         // row_ror:8
+  if (LPC >= 32) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
+  if (LPC >= 64) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
+  return v;
+}
+template <int R, int LPC>
+__device__ __forceinline__ void col_sum_all(Acc<R>& a) {
+#pragma unroll
+  for (int q = 0; q < R; ++q) a.v[q] = col_sum<LPC>(a.v[q]);
+}
+template <int R>
+__device__ __forceinline__ float pick(const Acc<R>& a, int rho) {
+  return R == 1 ? a.v[0] : a.v[rho];
+}
+
+template <int R, int RR>
+struct Dims {
+  static constexpr int R80 = kMel * RR;
+  static constexpr int KA = kPre2 + R80;                      // [p2 ; out]
+  static constexpr int KAP = (KA + 63) / 64 * 64;             // x mat-vec K, padded to the 64-lane split
+  static constexpr int KG = KA + kDec;                        // [p2 ; out ; h1]
+  static constexpr int KGP = (KG + 31) / 32 * 32;
+  static constexpr int U0R = KAP > KGP ? KAP : KGP;           // rows of the u0 buffer
+  static constexpr int NO = (kAtt + R80 <= 512) ? 512 : 1024;
+  static constexpr int CPW_O = NO / P3 / 8;                   // columns per wave in round OUT (2 or 4)
+  static constexpr int LPC_O = 64 / CPW_O;
+  static constexpr int KPL_O = kDec / LPC_O;
+  static constexpr int KPLX = KAP / 64;
+  static constexpr int KPLG0 = KGP / 32;
+  // LDS (floats)
+  static constexpr int o_u0 = 0;
+  static constexpr int o_xs = o_u0 + U0R * R;
+  static constexpr int o_catc = o_xs + 256 * R;
+  static constexpr int o_catd = o_catc + 512 * R;     // second [in | r*h] buffer: consecutive layers alternate (a round never writes its own input)
+  static constexpr int o_cat1 = o_catd + 512 * R;
+  static constexpr int o_cat2 = o_cat1 + 512 * R;
+  static constexpr int o_us = o_cat2 + 512 * R;
+  static constexpr int o_ys = o_us + 256 * R;
+  static constexpr int o_p1 = o_ys + 256 * R;
+  static constexpr int o_qs = o_p1 + 256 * R;        // [R][256]
+  static constexpr int o_es = o_qs + 256 * R;        // [R][TTP]
+  static constexpr int o_als = o_es + TTP * R;       // [TTP][R]  (round G0 reads one s of all rows at a time)
+  static constexpr int o_bias = o_als + TTP * R;
+  static constexpr int b_in = 0, b_g = 256 /* +l*768 */, b_c = 768 /* +l*768 */, b_o = 2560 /* NO */, b_p1o = 3584, b_p2 = 3840;
+  static constexpr int kBias = 3968;
+  static constexpr int o_dead = o_bias + kBias;
+  static constexpr int o_vwg = o_dead + 4;           // launch-resident VWg values of the wave's gate columns: [j][tid] float4 slots holding R rows
+  static constexpr int kFloats = o_vwg + 8 * NT * R;
+};
+
+// Uniform per-row scalars (batch row, text length, flags) of the R rows of a cluster.  Deliberately four named members and
+// literal indices everywhere: as an array read through `rho == q ? v[q] : x` inside an unrolled loop the values end up in a
+// stack object (hipcc folds the select of loads into a load from a selected address before the loop is unrolled) and every
+// epilogue pays scratch loads.  As scalars they live in SGPRs and a lane's row selects among them with v_cndmask.
+struct RV {
+  int v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+  template <int Q>
+  __device__ __forceinline__ int& at() {
+    if constexpr (Q == 0) return v0;
+    else if constexpr (Q == 1) return v1;
+    else if constexpr (Q == 2) return v2;
+    else return v3;
+  }
+  template <int Q>
+  __device__ __forceinline__ int get() const {
+    if constexpr (Q == 0) return v0;
+    else if constexpr (Q == 1) return v1;
+    else if constexpr (Q == 2) return v2;
+    else return v3;
+  }
+};
+template <int R>
+__device__ __forceinline__ int rsel(const RV& v, int rho) {
+  const int a0 = v.v0, a1 = v.v1, a2 = v.v2, a3 = v.v3;   // unconditional reads first: the selects below then pick among VALUES
+  int x = a0;
+  if constexpr (R >= 2) x = rho == 1 ? a1 : x;
+  if constexpr (R >= 3) x = rho == 2 ? a2 : x;
+  if constexpr (R >= 4) x = rho == 3 ? a3 : x;
+  return x;
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+// What a round needs to know about "this lane": which column of the round's vector it works on, and -- if it is one of the
+// lanes that end up holding a column total (lane c*LPC + LPC-16 + rho of its column group) -- which batch row it finishes.
+// Derived from an opaque thread id at the head of every round (see opaque_tid).
+template <int R, int LPC>
+struct Lane {
+  int tid, lane, wave, lk;
+  int rho;          // row within the cluster this lane finishes (valid if res)
+  bool res;
+  __device__ __forceinline__ Lane() {
+    tid = opaque_tid();
+    lane = tid & 63;
+    wave = tid >> 6;
+    lk = lane & (LPC - 1);
+    rho = lk - (LPC - 16);
+    res = rho >= 0 && rho < R;
+    if (!res) rho = 0;
+  }
+};
+
+// TR: training (teacher frames, hoisted pre-net, stash for the backward pass) vs inference
+template <int R, int RR, bool TR>
+__global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
+  typedef Dims<R, RR> D;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // The grid always has 8 x 32 workgroups: block b -> (cluster b % 8, peer b / 8), i.e. with the dispatcher's round-robin a
+  // cluster is the set of workgroups of ONE XCD.  Clusters beyond the batch leave after the placement rendezvous.
+  constexpr int NCL = 8;
+  const int cl = blockIdx.x % NCL, peer = blockIdx.x / NCL;
+  const int B = a.B, Tt = a.Tt, Td = a.Td;
+  const int ncl_used = (B + R - 1) / R;
+  constexpr int R80 = D::R80, KA = D::KA, NO = D::NO;
+  float* const U0 = smem + D::o_u0;
+  float* const XS = smem + D::o_xs;
+  float* const CATA = smem + D::o_catc;
+  float* const CATB = smem + D::o_catd;
+  float* const CAT1 = smem + D::o_cat1;
+  float* const CAT2 = smem + D::o_cat2;
+  float* const US = smem + D::o_us;
+  float* const YS = smem + D::o_ys;
+  float* const P1 = smem + D::o_p1;
+  float* const QS = smem + D::o_qs;
+  float* const ES = smem + D::o_es;
+  float* const ALS = smem + D::o_als;
+  float* const BIAS = smem + D::o_bias;
+  int* const dead = reinterpret_cast<int*>(smem + D::o_dead);
+  const DecWeights& w = a.w;
+  const DecComposite& cw = a.c;
+  Xc X;
+  X.base = (gu64*)(reinterpret_cast<u64*>(a.xchg) + (int64_t)cl * R * kX3Row);
+  // ---- placement rendezvous: every workgroup publishes its XCC id; a cluster whose 32 ids agree exchanges through its L2 ----
+  {
+    gi32* tab = (gi32*)(reinterpret_cast<int*>(a.xchg) + a.xcc_table_ofs);
+    int* sflag = reinterpret_cast<int*>(smem);
+    if (tid == 0) {
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      __hip_atomic_store(tab + blockIdx.x, (int)(xcc & 15u) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid < P3) {
+      int v = 0;
+      for (unsigned spin = 0; spin < (1u << 22); ++spin) {
+        v = __hip_atomic_load(tab + tid * NCL + cl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v != 0) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+      const int v0 = __shfl(v, 0, 64);
+      const bool same = __all(tid >= P3 || (v != 0 && v == v0));
+      if (tid == 0) sflag[0] = same ? 1 : 0;
+    }
+    __syncthreads();
+    X.fast = sflag[0] != 0 && a.fast_ok;
+    __syncthreads();
+    if (cl >= ncl_used) return;
+  }
+  X.err = a.err;
+  X.dead = dead;
+  X.epoch = 0;
+  X.fake = a.fakew;
+  X.trace = nullptr;
+  X.tslot = 0;
+  X.polls = 0;
+  const bool lead = peer == 0;
+
+  // batch rows of this cluster; rows past B are computed on a clamped copy of row B-1 and never stored
+  RV brow, len, valid;
+  static_for<R>([&](auto Q) {
+    constexpr int q = decltype(Q)::value;
+    const int b = cl * R + q;
+    valid.template at<q>() = b < B;
+    brow.template at<q>() = b < B ? b : B - 1;
+    const int l = a.text_length[brow.template get<q>()];
+    len.template at<q>() = l < 1 ? 1 : (l > Tt ? Tt : l);
+  });
+
+  // ---- state ----
+  for (int i = tid; i < D::o_bias; i += NT) smem[i] = 0.f;
+  if (tid == 0) *dead = 0;
+  for (int i = tid; i < kDec; i += NT) BIAS[D::b_in + i] = w.in_b[i];
+  for (int l = 0; l < 3; ++l) {
+    for (int i = tid; i < 2 * kDec; i += NT) BIAS[D::b_g + l * 768 + i] = l == 0 ? cw.bg0[i] : w.gb[l][i];
+    for (int i = tid; i < kDec; i += NT) BIAS[D::b_c + l * 768 + i] = w.cb[l][i];
+  }
+  for (int i = tid; i < NO; i += NT) BIAS[D::b_o + i] = cw.bo[i];
+  for (int i = tid; i < kPre1; i += NT) BIAS[D::b_p1o + i] = cw.bp1o[i];
+  for (int i = tid; i < kPre2; i += NT) BIAS[D::b_p2 + i] = w.pre_b2[i];
+
+  // ---- register-resident weights (this workgroup's column slices) ----
+  // 64-lane columns: one per wave.  x: n = peer*8 + wave; C rounds: same; p1: same; p2: waves 0..3, n = peer*4 + wave.
+  // 32-lane columns: two per wave.  gates: n = peer*16 + wave*2 + (lane >> 5).
+  const int lk32 = lane & 31;
+  WReg<D::KPLX> wx;
+  WReg<D::KPLG0> wg0;
+  WReg<8> wc0, wc1, wc2;
+  WReg<16> wg1, wg2;
+  WReg<D::KPL_O> wo;
+  WReg<4> wp1, wp2;
+  float vwx[R][4];
+  float4 kres[4];
+  {
+    const int n8 = peer * 8 + wave, n16 = peer * 16 + wave * 2 + (lane >> 5), n4 = peer * 4 + (wave & 3);
+    load_w<D::KPLX, 64>(wx, cw.wx, kDec, KA, n8, lane, true);
+    load_w<D::KPLG0, 32>(wg0, cw.wg0, 2 * kDec, D::KG, n16, lk32, true);
+    load_w<8, 64>(wc0, w.cw[0], kDec, 2 * kDec, n8, lane, true);
+    load_w<8, 64>(wc1, w.cw[1], kDec, 2 * kDec, n8, lane, true);
+    load_w<8, 64>(wc2, w.cw[2], kDec, 2 * kDec, n8, lane, true);
+    load_w<16, 32>(wg1, w.gw[1], 2 * kDec, 2 * kDec, n16, lk32, true);
+    load_w<16, 32>(wg2, w.gw[2], 2 * kDec, 2 * kDec, n16, lk32, true);
+    const int nO = peer * (NO / P3) + wave * D::CPW_O + lane / D::LPC_O;
+    load_w<D::KPL_O, D::LPC_O>(wo, cw.wo, NO, kDec, nO, lane & (D::LPC_O - 1), true);
+    load_w<4, 64>(wp1, cw.wp1o, kPre1, kDec, n8, lane, true);
+    load_w<4, 64>(wp2, w.pre_w2, kPre2, kPre1, n4, lane, wave < 4);
+    // attention-memory folds of the wave's own columns: vwx[rho][j] = VWx[b][lane + 64 j][n8] (registers),
+    // VWG slot j of this thread = VWg[b][lk32 + 32 j][n16] for the R rows (LDS, private slots)
+    float* const VWG = smem + D::o_vwg + tid * R;
+    static_for<R>([&](auto Q) {
+      constexpr int q = decltype(Q)::value;
+      const float* vx = a.vwx + (int64_t)brow.template get<q>() * Tt * kDec;
+      const float* vg = a.vwg + (int64_t)brow.template get<q>() * Tt * 2 * kDec;
+      const int ln = len.template get<q>();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int s = lane + 64 * j;
+        vwx[q][j] = s < ln ? vx[(int64_t)s * kDec + n8] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int s = lk32 + 32 * j;
+        VWG[j * NT * R + q] = s < ln ? vg[(int64_t)s * 2 * kDec + n16] : 0.f;
+      }
+    });
+    // energies: slot g = i*256 + wave*32 + peer -> (rho = g % R, s = g / R); the wave keeps its four key rows in registers
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int g = i * 256 + wave * 32 + peer;
+      const int rho = g % R, sidx = g / R;
+      const bool on = sidx < rsel<R>(len, rho);
+      kres[i] = on ? reinterpret_cast<const float4*>(a.keys + ((int64_t)rsel<R>(brow, rho) * Tt + sidx) * kAtt)[lane]
+                   : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  const float4 v4 = reinterpret_cast<const float4*>(w.att_v)[lane];
+  __syncthreads();
+
+  float* const H1 = U0 + KA * R;     // h of GRU-1 lives behind [p2 ; out]
+  float* const stash = a.stash;
+  const unsigned ldp2 = (unsigned)a.ldpre2;
+
+  // ---- step 0 pre-net ----
+  // training: p2 of every teacher-forced step comes from the hoisted GEMMs (a.pre2); inference: the first input frame is zeros
+  // (ops.InferenceHelper.initialize, ops.py:16-18), so p1 = relu(b1) and p2 = relu(p1 W2 + b2) -- one local round
+  if (TR) {
+    for (int i = tid; i < kPre2 * R; i += NT) {
+      const int n = i / R, q = i - n * R;
+      U0[n * R + q] = a.pre2[(unsigned)(rsel<R>(brow, q) * Td) * ldp2 + n];
+    }
+    if (a.prein && lead && tid < kMel * R) {   // pre-net input frame of step 0 (train stash for the layer-1 weight gradient)
+      const int q = tid / kMel, i = tid - q * kMel;
+      if (rsel<R>(valid, q))
+        a.prein[((int64_t)rsel<R>(brow, q) * Td) * kMel + i] = a.mel[((int64_t)rsel<R>(brow, q) * Td) * R80 + kMel * (RR - 1) + i];
+    }
+  } else {
+    for (int i = tid; i < kPre1 * R; i += NT) P1[i] = fmaxf(w.pre_b1[i / R], 0.f);
+    __syncthreads();
+    X.epoch = 0x7fffffffu;
+    const Lane<R, 64> L;
+    const int n4 = peer * 4 + (L.wave & 3);
+    Acc<R> ap;
+    ap.zero();
+    mv<R, 4, 64>(wp2, P1, L.lane, ap);
+    col_sum_all<R, 64>(ap);
+    if (L.res && L.wave < 4) {
+      const float y = fmaxf(pick<R>(ap, L.rho) + BIAS[D::b_p2 + n4], 0.f);
+      U0[n4 * R + L.rho] = y;
+      put_granule<R>(X, X3_P2, n4, L.rho, y);
+    }
+    gather<R, 1>(X, X3_P2, kPre2, [&](int n) { return (n >> 2) == peer; }, [&](int n, int q, float v) { U0[n * R + q] = v; });
+  }
+  __syncthreads();
+
+  // values parked one step ahead: teacher p2 and the dropout multipliers of the NEXT step's pre-net (result lanes only)
+  float p2n = 0.f, km1n = 1.f, km2n = 1.f;
+  auto park_next = [&](int tn) {
+    p2n = 0.f;
+    km1n = km2n = 1.f;
+    if (TR && tn < Td) {
+      const Lane<R, 64> L;
+      if (L.tid < kPre2 * R) {
+        const int n = L.tid / R, q = L.tid - n * R;
+        p2n = a.pre2[(unsigned)(rsel<R>(brow, q) * Td + tn) * ldp2 + n];
+      }
+      if (L.res) {
+        const unsigned bt = (unsigned)(rsel<R>(brow, L.rho) * Td + tn);
+        if (a.keep1) km1n = a.keep1[bt * kPre1 + peer * 8 + L.wave] ? 2.f : 0.f;
+        if (a.keep2 && L.wave < 4) km2n = a.keep2[bt * kPre2 + peer * 4 + L.wave] ? 2.f : 0.f;
+      }
+    }
+  };
+  static_assert(kPre2 * 4 <= NT, "one parked p2 value per thread");
+  park_next(1);
+
+  for (int t = 0; t < Td; ++t) {
+    X.epoch = (unsigned)(t + 1);
+    if (kProbes3) {
+      X.trace = (a.trace && blockIdx.x == 0 && t == Td / 2) ? a.trace : nullptr;
+      X.tslot = 0;
+      X.polls = 0;
+    }
+    tstamp(X);
+    const bool has_next = t + 1 < Td;
+    // helper.next_inputs: step t+1 of row rho is fed cell_output[t] at inference or when sampled, else mel[t+1]
+    RV from_out;
+    static_for<R>([&](auto Q) {
+      constexpr int q = decltype(Q)::value;
+      from_out.template at<q>() = !TR || (a.sample && a.sample[(unsigned)(t * B + brow.template get<q>())]);
+    });
+    const float p2t = p2n, km1t = km1n, km2t = km2n;   // step t+1's values, landed below in rounds OUT / E
+    park_next(t + 2);
+
+    // ---- round G0: x = [p2 ; out'] Wx + al' VWx + bi ;  gates_1 = sigmoid([p2 ; out' ; h1] Wg0' + al' VWg + bg0') ----
+    {
+      const Lane<R, 64> L;
+      const int n8 = peer * 8 + L.wave;
+      Acc<R> ax;
+      ax.zero();
+      mv<R, D::KPLX, 64>(wx, U0, L.lane, ax);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const XV<R> al = lds_rows<R>(ALS + (L.lane + 64 * j) * R);
+#pragma unroll
+        for (int q = 0; q < R; ++q) ax.v[q] = fmaf(al.v[q], vwx[q][j], ax.v[q]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      col_sum_all<R, 64>(ax);
+      float yx = 0.f;
+      if (L.res) {
+        yx = pick<R>(ax, L.rho) + BIAS[D::b_in + n8];
+        XS[n8 * R + L.rho] = yx;
+        CATA[n8 * R + L.rho] = yx;
+        put_granule<R>(X, X3_X, n8, L.rho, yx);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const Lane<R, 32> M;
+      const int n16 = peer * 16 + M.wave * 2 + (M.lane >> 5);
+      Acc<R> ag;
+      ag.zero();
+      mv<R, D::KPLG0, 32>(wg0, U0, M.lk, ag);
+      {
+        const float* vwg = smem + D::o_vwg + M.tid * R;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const XV<R> al = lds_rows<R>(ALS + (M.lk + 32 * j) * R);
+          const XV<R> vw = lds_rows<R>(vwg + j * NT * R);
+#pragma unroll
+          for (int q = 0; q < R; ++q) ag.v[q] = fmaf(al.v[q], vw.v[q], ag.v[q]);
+          if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      col_sum_all<R, 32>(ag);
+      float gg = 0.f, gv = 0.f;
+      if (M.res) {
+        gg = sigmoid_fast(pick<R>(ag, M.rho) + BIAS[D::b_g + n16]);
+        gv = gg;
+        if (n16 < kDec) {
+          gv = gg * H1[n16 * R + M.rho];
+          CATA[(kDec + n16) * R + M.rho] = gv;
+        } else {
+          US[(n16 - kDec) * R + M.rho] = gg;
+        }
+        put_granule<R>(X, X3_G0, n16, M.rho, gv);
+      }
+      tstamp(X);   // G0: computed + published
+      gather<R, (768 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(
+          X, X3_X, 768,
+          [&](int n) { return n < 256 ? (n >> 3) == peer : ((n - 256) >> 4) == peer; },
+          [&](int n, int q, float v) {
+            // (one store through an integer index into the LDS array: with a store per branch hipcc merges them into a store
+            //  through a pointer selected from a stack table -- generic address space, scratch loads)
+            const int i = n < 512 ? D::o_catc + n * R : D::o_us + (n - 512) * R;   // x -> CATA[n]; r*h of unit n-256 -> CATA[256 + (n-256)]; u
+            smem[i + q] = v;
+            if (n < 256) smem[D::o_xs + n * R + q] = v;
+          });
+      if (TR) {   // stash stores after the polls: they then fly under the next round instead of in front of this round's loads
+        if (L.res && rsel<R>(valid, L.rho)) stash[(unsigned)(rsel<R>(brow, L.rho) * Td + t) * kStRec + kStX + n8] = yx;
+        if (M.res && rsel<R>(valid, M.rho)) {
+          float* st = stash + (unsigned)(rsel<R>(brow, M.rho) * Td + t) * kStRec;
+          if (n16 < kDec) { st[kStR + n16] = gg; st[kStRH + n16] = gv; }
+          else st[kStU + n16 - kDec] = gg;
+        }
+      }
+      tstamp(X);   // G0: gathered
+    }
+    lds_barrier();
+    tstamp(X);     // G0: barrier
+    // ---- GRU stack (ONE ResidualWrapper around it, tacotron.py:54-58) ----
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+      float* const HL = l == 0 ? H1 : (l == 1 ? CAT1 : CAT2) + kDec * R;   // h_l, [256][R]
+      float* const CIN = l == 1 ? CATB : CATA;    // [layer input ; r*h_l] read by this layer's candidate round
+      float* const CNX = l == 1 ? CATA : CATB;    // ... of the next layer (its input part is written by THIS layer's candidate round)
+      if (l > 0) {
+        const Lane<R, 32> M;
+        const int n16 = peer * 16 + M.wave * 2 + (M.lane >> 5);
+        float* const CL = l == 1 ? CAT1 : CAT2;
+        Acc<R> ag;
+        ag.zero();
+        mv<R, 16, 32>(l == 1 ? wg1 : wg2, CL, M.lk, ag);
+        col_sum_all<R, 32>(ag);
+        float gg = 0.f, gv = 0.f;
+        if (M.res) {
+          gg = sigmoid_fast(pick<R>(ag, M.rho) + BIAS[D::b_g + l * 768 + n16]);
+          gv = gg;
+          if (n16 < kDec) {
+            gv = gg * HL[n16 * R + M.rho];
+            CIN[(kDec + n16) * R + M.rho] = gv;
+          } else {
+            US[(n16 - kDec) * R + M.rho] = gg;
+          }
+          put_granule<R>(X, X3_G + (l - 1) * 512, n16, M.rho, gv);
+        }
+        tstamp(X);
+        gather<R, (512 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(
+            X, X3_G + (l - 1) * 512, 512, [&](int n) { return (n >> 4) == peer; },
+            [&](int n, int q, float v) {
+              const int i = n < kDec ? (l == 1 ? D::o_catd : D::o_catc) + (kDec + n) * R : D::o_us + (n - kDec) * R;
+              smem[i + q] = v;
+            });
+        if (TR && M.res && rsel<R>(valid, M.rho)) {
+          float* st = stash + (unsigned)(rsel<R>(brow, M.rho) * Td + t) * kStRec;
+          if (n16 < kDec) { st[kStR + l * kDec + n16] = gg; st[kStRH + l * kDec + n16] = gv; }
+          else st[kStU + l * kDec + n16 - kDec] = gg;
+        }
+        tstamp(X);
+        lds_barrier();
+        tstamp(X);
+      }
+      {
+        const Lane<R, 64> L;
+        const int n8 = peer * 8 + L.wave;
+        Acc<R> ac;
+        ac.zero();
+        mv<R, 8, 64>(l == 0 ? wc0 : (l == 1 ? wc1 : wc2), CIN, L.lane, ac);
+        col_sum_all<R, 64>(ac);
+        auto hput = [&](int n, int q, float hn) {
+          const int o_hl = l == 0 ? D::o_u0 + KA * R : (l == 1 ? D::o_cat1 : D::o_cat2) + kDec * R;
+          smem[o_hl + n * R + q] = hn;
+          if (l < 2) {
+            smem[(l == 0 ? D::o_cat1 : D::o_cat2) + n * R + q] = hn;
+            smem[(l == 1 ? D::o_catc : D::o_catd) + n * R + q] = hn;
+          } else {
+            smem[D::o_ys + n * R + q] = smem[D::o_xs + n * R + q] + hn;
+          }
+        };
+        float cc = 0.f, hn = 0.f, yy = 0.f;
+        if (L.res) {
+          cc = tanh_fast(pick<R>(ac, L.rho) + BIAS[D::b_c + l * 768 + n8]);
+          const float u = US[n8 * R + L.rho];
+          hn = u * HL[n8 * R + L.rho] + (1.f - u) * cc;
+          if (l == 2) yy = XS[n8 * R + L.rho] + hn;
+          put_granule<R>(X, X3_C + l * 256, n8, L.rho, hn);
+          hput(n8, L.rho, hn);
+        }
+        tstamp(X);
+        gather<R, (256 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(X, X3_C + l * 256, 256, [&](int n) { return (n >> 3) == peer; }, hput);
+        if (TR && L.res && rsel<R>(valid, L.rho)) {
+          float* st = stash + (unsigned)(rsel<R>(brow, L.rho) * Td + t) * kStRec;
+          st[kStC + l * kDec + n8] = cc;
+          st[kStH + l * kDec + n8] = hn;
+          if (l == 2) st[kStY + n8] = yy;
+        }
+        tstamp(X);
+      }
+      lds_barrier();
+      tstamp(X);
+    }
+    // ---- round OUT: [q | cell_output | 0] = (x + h3) [Wo Wq | Wo] + [bo Wq | bo]  and pre_net layer 1 of step t+1 ----
+    {
+      const Lane<R, D::LPC_O> O;
+      const int nO = peer * (NO / P3) + O.wave * D::CPW_O + O.lane / D::LPC_O;
+      Acc<R> ao;
+      ao.zero();
+      mv<R, D::KPL_O, D::LPC_O>(wo, YS, O.lk, ao);
+      col_sum_all<R, D::LPC_O>(ao);
+      auto oput = [&](int n, int q, float v) {
+        const int i = n < kAtt ? D::o_qs + q * kAtt + n : D::o_u0 + (kPre2 + n - kAtt) * R + q;
+        if (n < kAtt + R80) smem[i] = v;
+      };
+      float yo = 0.f;
+      if (O.res) {
+        yo = pick<R>(ao, O.rho) + BIAS[D::b_o + nO];
+        put_granule<R>(X, X3_O, nO, O.rho, yo);
+        oput(nO, O.rho, yo);
+      }
+      const Lane<R, 64> L;
+      const int n8 = peer * 8 + L.wave;
+      float yp = 0.f;
+      if (has_next) {
+        __builtin_amdgcn_sched_barrier(0);
+        Acc<R> ap;
+        ap.zero();
+        mv<R, 4, 64>(wp1, YS, L.lane, ap);
+        col_sum_all<R, 64>(ap);
+        if (L.res) {
+          // layer 1 of a step fed by this step's output, straight from (x + h3) with Wo[:, last frame] W1
+          yp = fmaxf(pick<R>(ap, L.rho) + BIAS[D::b_p1o + n8], 0.f) * km1t;
+          P1[n8 * R + L.rho] = yp;
+          put_granule<R>(X, X3_P1, n8, L.rho, yp);
+        }
+      }
+      tstamp(X);
+      gather<R, (NO * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(X, X3_O, NO, [&](int n) { return n / (NO / P3) == peer; }, oput);
+      if (has_next)
+        gather<R, (256 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(X, X3_P1, 256, [&](int n) { return (n >> 3) == peer; },
+                                                             [&](int n, int q, float v) { P1[n * R + q] = v; });
+      if (O.res && rsel<R>(valid, O.rho)) {
+        const unsigned bt = (unsigned)(rsel<R>(brow, O.rho) * Td + t);
+        if (nO < kAtt) {
+          if (TR) stash[bt * kStRec + kStQ + nO] = yo;
+        } else if (nO < kAtt + R80) {
+          const int c = nO - kAtt;
+          a.out[bt * R80 + c] = yo;
+          if (TR && a.prein && has_next && rsel<R>(from_out, O.rho) && c >= kMel * (RR - 1)) a.prein[(bt + 1) * kMel + c - kMel * (RR - 1)] = yo;
+        }
+      }
+      if (TR && has_next && L.res && rsel<R>(valid, L.rho) && rsel<R>(from_out, L.rho))
+        stash[(unsigned)(rsel<R>(brow, L.rho) * Td + t + 1) * kStRec + kStP1 + n8] = yp;   // record of step t+1
+      tstamp(X);
+    }
+    lds_barrier();
+    tstamp(X);
+    // ---- round E: energies e[rho][s] = sum_u v_u tanh(keys[s,u] + q_u)  and pre_net layer 2 of step t+1 ----
+    {
+      const Lane<R, 64> L;
+      const int n4 = peer * 4 + (L.wave & 3);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int g = i * 256 + L.wave * 32 + peer;
+        const int rho = g % R, sidx = g / R;
+        if (sidx < rsel<R>(len, rho)) {
+          const float4 q4 = reinterpret_cast<const float4*>(QS + rho * kAtt)[L.lane];
+          const float4 k4 = kres[i];
+          float e = v4.x * tanh_fast(k4.x + q4.x) + v4.y * tanh_fast(k4.y + q4.y) + v4.z * tanh_fast(k4.z + q4.z) +
+                    v4.w * tanh_fast(k4.w + q4.w);
+          e = wave_sum(e);
+          if (L.lane == 0) {
+            ES[rho * TTP + sidx] = e;
+            put_granule<R>(X, X3_E, sidx, rho, e);
+          }
+        }
+      }
+      float y2 = 0.f;
+      if (has_next) {
+        Acc<R> ap;
+        ap.zero();
+        mv<R, 4, 64>(wp2, P1, L.lane, ap);
+        col_sum_all<R, 64>(ap);
+        if (L.res && L.wave < 4) {
+          y2 = fmaxf(pick<R>(ap, L.rho) + BIAS[D::b_p2 + n4], 0.f) * km2t;
+          put_granule<R>(X, X3_P2, n4, L.rho, y2);
+          if (rsel<R>(from_out, L.rho)) U0[n4 * R + L.rho] = y2;
+        }
+        // rows fed by the teacher take the hoisted pre-net output instead
+        if (TR && L.tid < kPre2 * R) {
+          const int n = L.tid / R, q = L.tid - n * R;
+          if (!rsel<R>(from_out, q)) U0[n * R + q] = p2t;
+        }
+        tstamp(X);
+        gather<R, 1>(X, X3_P2, kPre2, [&](int n) { return (n >> 2) == peer; },
+                     [&](int n, int q, float v) {
+                       if (rsel<R>(from_out, q)) U0[n * R + q] = v;
+                     });
+      }
+      // energies of every slot (the owner's own included: they are one L2 hit away)
+      gather<R, (TTP * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(
+          X, X3_E, TTP, [&](int n) { return false; },
+          [&](int n, int q, float v) { ES[q * TTP + n] = v; },
+          [&](int n, int q) { return n < rsel<R>(len, q); });   // nobody scores (or publishes) positions past text_length
+      if (TR && has_next) {
+        if (L.res && L.wave < 4 && rsel<R>(valid, L.rho) && rsel<R>(from_out, L.rho))
+          stash[(unsigned)(rsel<R>(brow, L.rho) * Td + t + 1) * kStRec + kStP2 + n4] = y2;
+        // teacher frames of step t+1 for the pre-net weight gradient (model.hip reads a.prein for every step)
+        if (a.prein && lead && L.tid < kMel * R) {
+          const int q = L.tid / kMel, i = L.tid - q * kMel;
+          if (!rsel<R>(from_out, q) && rsel<R>(valid, q)) {
+            const unsigned bt1 = (unsigned)(rsel<R>(brow, q) * Td + t + 1);
+            a.prein[bt1 * kMel + i] = a.mel[bt1 * R80 + kMel * (RR - 1) + i];
+          }
+        }
+      }
+      tstamp(X);
+    }
+    lds_barrier();
+    tstamp(X);
+    // ---- masked softmax over s < len (score_mask_value = -inf): wave rho handles row rho ----
+    {
+      const Lane<R, 64> L;
+      if (L.wave < R) {
+        const int q = L.wave;
+        const int ln = rsel<R>(len, q);
+        float ev[4];
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int sx = L.lane + 64 * j;
+          ev[j] = sx < ln ? ES[q * TTP + sx] : -INFINITY;
+          m = fmaxf(m, ev[j]);
+        }
+        m = wave_max(m);
+        float z = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          ev[j] = L.lane + 64 * j < ln ? __expf(ev[j] - m) : 0.f;
+          z += ev[j];
+        }
+        z = wave_sum(z);
+        const float inv = 1.0f / z;
+        const bool wr = lead && rsel<R>(valid, q);
+        float* al = a.align + (unsigned)(rsel<R>(brow, q) * Td + t) * (unsigned)Tt;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int sx = L.lane + 64 * j;
+          const float v = ev[j] * inv;
+          ALS[sx * R + q] = v;
+          if (wr && sx < Tt) al[sx] = v;
+        }
+      }
+    }
+    lds_barrier();
+    tstamp(X);
+    if (kProbes3 && X.trace) {
+      int pm = X.polls;
+      for (int o = 32; o; o >>= 1) pm = max(pm, __shfl_xor(pm, o, 64));
+      if (tid == 0) { X.trace[63] = X.tslot; X.trace[62] = pm; }
+    }
+  }
+}
+
+template <int R, int RR>
+int launch3(DecFwdArgs& a, int ncl, hipStream_t s) {
+  typedef Dims<R, RR> D;
+  void (*kern)(DecFwdArgs) = a.mel ? decoder3_fwd_kernel<R, RR, true> : decoder3_fwd_kernel<R, RR, false>;
+  const size_t smem = (size_t)D::kFloats * sizeof(float);
+  static_assert(D::kFloats * sizeof(float) <= 160 * 1024, "decoder3: LDS budget");
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) {
+      taco_set_error("decoder3_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return TACO_ELAUNCH;
+    }
+  }
+  // every workgroup of the grid must be resident (the all-gathers need all 32 peers of a cluster running); the grid is always
+  // 8 clusters x 32 peers so that a cluster maps onto one XCD
+  int dev = 0, cus = 0, per_cu = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, NT, smem);
+  if (e != hipSuccess || (int64_t)cus * per_cu < (int64_t)8 * P3) return TACO_ENOTFOUND;
+  e = hipMemsetAsync(a.xchg, 0, (size_t)decoder_xchg_bytes(a.B, a.Tt), s);
+  if (e != hipSuccess) {
+    taco_set_error("decoder3_fwd: memset: %s", hipGetErrorString(e));
+    return TACO_ELAUNCH;
+  }
+  (void)ncl;
+  hipLaunchKernelGGL(kern, dim3(8 * P3), dim3(NT), smem, s, a);
+  TACO_LAUNCH_CHECK("decoder3_fwd");
+  return TACO_OK;
+}
+
+}  // namespace
+
+// Returns TACO_ENOTFOUND (nothing enqueued) when the shape is outside this kernel's scope; the caller then takes decoder.hip.
+int launch_decoder3_fwd(DecFwdArgs a, hipStream_t s) {
+  const char* env = getenv("TACO_DEC_V3");
+  if (env && atoi(env) == 0) return TACO_ENOTFOUND;
+  if (a.Tt > TTP || a.B > 32 || a.B < 1 || (a.r != 2 && a.r != 5)) return TACO_ENOTFOUND;
+  if (a.mel && !a.pre2) return TACO_ENOTFOUND;   // training needs the hoisted pre-net
+  if (a.trace && !kProbes3) return TACO_ENOTFOUND;   // (the production build carries no stamps; decoder.hip's trace then)
+  const int R = a.B > 16 ? 4 : (a.B > 8 ? 2 : 1);
+  const int ncl = (a.B + R - 1) / R;
+  if ((int64_t)ncl * R * kX3Row * 8 + 1024 > decoder_xchg_bytes(a.B, a.Tt)) return TACO_ENOTFOUND;
+  a.xcc_table_ofs = (int)(decoder_xchg_bytes(a.B, a.Tt) / 4 - 256);   // last 1 KB of the exchange area
+  a.fast_ok = getenv("TACO_DEC_V3_AGENT") ? 0 : 1;
+  a.P = P3;
+  a.fakew = kProbes3 ? ((getenv("TACO_DEC_FAKEX") ? 2 : 0)) : 0;
+  decoder_note_cluster(0, P3);
+  if (a.r == 2) return R == 4 ? launch3<4, 2>(a, ncl, s) : (R == 2 ? launch3<2, 2>(a, ncl, s) : launch3<1, 2>(a, ncl, s));
+  return R == 4 ? launch3<4, 5>(a, ncl, s) : (R == 2 ? launch3<2, 5>(a, ncl, s) : launch3<1, 5>(a, ncl, s));
+}

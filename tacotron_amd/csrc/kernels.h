@@ -263,10 +263,16 @@ struct DecFwdArgs {
   int P;                 // cluster width (workgroups per row); chosen by launch_decoder_fwd
   int fakew = 0;         // timing probe (TACO_DEC_FAKEW): see Xchg::fake
   int lres0 = 0, lres1 = 0;  // launch-resident weight rows (LDS) of the GRU-2 / GRU-3 gate mat-vecs; chosen by launch_decoder_fwd
+  int xcc_table_ofs = 0;     // decoder3.hip: int offset, inside the exchange area, of the 256-entry placement table
+  int fast_ok = 1;           // decoder3.hip: 0 forces the placement-independent (agent-scope) publish form (TACO_DEC_V3_AGENT=1)
 };
 int64_t decoder_xchg_bytes(int B, int Tt);
 int decoder_last_cluster(int which);   // cluster width (workgroups per row) of the last forward (0) / backward (1) launch
 int launch_decoder_fwd(DecFwdArgs a, hipStream_t s);
+// decoder3.hip: clusters of 32 workgroups x up to 4 rows with register-resident weights.  TACO_ENOTFOUND (nothing enqueued) when
+// the shape is outside its scope (Tt > 256, B > 32, r not in {2, 5}) or TACO_DEC_V3=0: the caller then takes launch_decoder_fwd.
+int launch_decoder3_fwd(DecFwdArgs a, hipStream_t s);
+void decoder_note_cluster(int which, int P);
 
 struct DecBwdArgs {
   DecWeights wT;         // every matrix TRANSPOSED (out,in); biases unused

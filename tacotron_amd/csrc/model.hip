@@ -467,7 +467,9 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
   //  guarded Adam update and to the host's next check, however rarely the host looks)
   {
     const int slot = prof_begin(0, s);
-    TACO_TRY(launch_decoder_fwd(da, s));
+    int rc = launch_decoder3_fwd(da, s);
+    if (rc == TACO_ENOTFOUND) rc = launch_decoder_fwd(da, s);
+    TACO_TRY(rc);
     prof_end(0, slot, s);
   }
   hipStream_t sl = s;

@@ -22,7 +22,7 @@ __device__ __forceinline__ bool get(u64* p, unsigned e) {
   return false;
 }
 
-template <int SCOPE>
+template <int SCOPE, int SSCOPE = SCOPE>
 __global__ void pingpong(u64* buf, int a, int b, int iters, long long* out, int* xcc) {
   if (threadIdx.x == 0) {
     unsigned id;
@@ -38,11 +38,11 @@ __global__ void pingpong(u64* buf, int a, int b, int iters, long long* out, int*
   const long long t0 = wall_clock64();
   for (int i = 1; i <= iters && ok; ++i) {
     if (first) {
-      put<SCOPE>(mine, i, i);
+      put<SSCOPE>(mine, i, i);
       ok = get<SCOPE>(theirs, i);
     } else {
       ok = get<SCOPE>(theirs, i);
-      put<SCOPE>(mine, i, i);
+      put<SSCOPE>(mine, i, i);
     }
   }
   const long long t1 = wall_clock64();
@@ -54,14 +54,17 @@ int main() {
   u64* buf; long long* out; int* xcc;
   hipMalloc(&buf, 4096); hipMalloc(&out, 64); hipMalloc(&xcc, G * sizeof(int));
   int hx[G]; long long ho[2];
-  for (int mode = 0; mode < 2; ++mode) {
+  for (int mode = 0; mode < 3; ++mode) {
     for (int b : {8, 1, 16, 4}) {   // partner of block 0: +8 / +16 = same XCD if round-robin over 8 XCDs; 1 / 4 = other XCD
       hipMemset(buf, 0, 4096); hipMemset(out, 0, 64);
       if (mode == 0) hipLaunchKernelGGL(pingpong<__HIP_MEMORY_SCOPE_AGENT>, dim3(G), dim3(64), 0, 0, buf, 0, b, iters, out, xcc);
-      else hipLaunchKernelGGL(pingpong<__HIP_MEMORY_SCOPE_WORKGROUP>, dim3(G), dim3(64), 0, 0, buf, 0, b, iters, out, xcc);
+      else if (mode == 1) hipLaunchKernelGGL(pingpong<__HIP_MEMORY_SCOPE_WORKGROUP>, dim3(G), dim3(64), 0, 0, buf, 0, b, iters, out, xcc);
+      // mode 2: stores at workgroup scope (the line STAYS in the XCD's L2), loads at agent scope (bypass L1, served by that L2):
+      // coherent only when both blocks share an XCD
+      else hipLaunchKernelGGL((pingpong<__HIP_MEMORY_SCOPE_AGENT, __HIP_MEMORY_SCOPE_WORKGROUP>), dim3(G), dim3(64), 0, 0, buf, 0, b, iters, out, xcc);
       hipDeviceSynchronize();
       hipMemcpy(ho, out, 16, hipMemcpyDeviceToHost); hipMemcpy(hx, xcc, sizeof(hx), hipMemcpyDeviceToHost);
-      printf("mode %d (%s) blocks 0<->%d  xcc %d/%d  ok=%lld  round trip %.3f us\n", mode, mode ? "workgroup scope" : "agent scope", b,
+      printf("mode %d (%s) blocks 0<->%d  xcc %d/%d  ok=%lld  round trip %.3f us\n", mode, mode == 0 ? "agent scope" : mode == 1 ? "workgroup scope" : "wg-scope store + agent-scope load", b,
              hx[0], hx[b], ho[1], ho[0] / 100.0 / iters);
     }
   }
