@@ -896,6 +896,495 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------------------
+// Same cluster geometry.  The BPTT step is re-distributed so that everything a unit needs stays with its owner:
+// workgroup `peer` owns units [8 peer, 8 peer + 8) of every 256-wide vector, wave w unit i = 8 peer + w.  In the gate /
+// candidate rounds (512 output columns) lanes 0-31 of the wave finish column i (the layer-input gradient of unit i) and lanes
+// 32-63 column 256 + i (its recurrent gradient), so the carried dL/dh_l, the forward record (r, u, c, h_prev of the unit) and
+// every elementwise GRU derivative are per-owner data: nothing of the 3,712-float stash record is replicated, and the rounds
+// exchange only what the NEXT mat-vec needs as its K input:
+//   FAN   d alignments[s] = VWxc[s] . dx_{t+1}  (memory rows dealt to waves)        (+ rider: d p2_{t+1})
+//   DQ    softmax / energy backward on the wave's unit over all rows; dq all-gather   (+ rider: d p1_{t+1})
+//   OUT   dy = [d out ; dq ; d p1] . wot + dx_{t+1} . wdx ; owner: dht_3 = dh_3 + dy -> (dcp, dup) of GRU-3, published
+//   C_l   [d inp ; d(r h)] = dcp . Wc^T ; owner: d gates_r, new carry part, published
+//   G_l   [d inp ; d h] += dgp . Wg^T ; owner: dht of the layer below -> its (dcp, dup), published;  G_0 publishes dx_t
+// (decoder.hip computes the elementwise derivatives of all 256 units redundantly in every peer from a replicated record.)
+constexpr int Y3_DAL = 0;        // TTP     d alignments          (backward granule regions, per row)
+constexpr int Y3_DP2 = 256;      // 128
+constexpr int Y3_DQ = 384;       // 256
+constexpr int Y3_DP1 = 640;      // 256
+constexpr int Y3_CG = 896;       // 3 * 512  [dcp ; dup] of GRU l at + l*512  (published by OUT for l = 2, by G_{l+1} otherwise)
+constexpr int Y3_GR = 2432;      // 3 * 256  d gates_r of GRU l
+constexpr int Y3_DX = 3200;      // 256
+static_assert(Y3_DX + 256 <= kX3Row, "backward regions fit the per-row exchange area");
+
+template <int R, int RR>
+struct BDims {
+  static constexpr int R80 = kMel * RR;
+  static constexpr int KO = R80 + 2 * kAtt + kDec;            // [d out ; dq ; d p1 ; dx]
+  static constexpr int KPL_O = (KO + 63) / 64;
+  static constexpr int KOP = KPL_O * 64;
+  // LDS (floats)
+  static constexpr int o_vo = 0;                              // [KOP][R]   (zero padded)
+  static constexpr int o_dcp = o_vo + KOP * R;                // [256][R]
+  static constexpr int o_dgpa = o_dcp + 256 * R;              // [512][R]  [d gates_r ; dup], layers 2 and 0
+  static constexpr int o_dgpb = o_dgpa + 512 * R;             // ... layer 1
+  static constexpr int o_dp2 = o_dgpb + 512 * R;              // [128][R]
+  static constexpr int o_dxr = o_dp2 + 128 * R;               // [R][256]  dx_{t+1} row-major (FAN dots)
+  static constexpr int o_als = o_dxr + 256 * R;               // [R][TTP]
+  static constexpr int o_des = o_als + TTP * R;               // [R][TTP]
+  static constexpr int o_own = o_des + TTP * R;               // per-owner state, [slot][8 units][R]:
+  static constexpr int w_dy = 0, w_dht = 1, w_dinp = 2, w_dhp = 3, w_dh = 4 /* +l */, w_rec = 7 /* + 4*l + {r,u,c,hp} */, w_q = 19,
+                       w_p1 = 20, w_n = 21;                   //   (w_p1: forward pre-net layer-1 activation of step t+1, unit's column)
+  static constexpr int o_p2m = o_own + w_n * 8 * R;           // [4][R] forward pre-net layer-2 activations of step t+1 (this peer's 4 columns)
+  static constexpr int o_zero_end = o_p2m + 4 * R;
+  static constexpr int o_dead = o_zero_end;
+  static constexpr int o_kr = o_dead + 4;                     // [4][NT][R] resident keys of the wave's unit   } private slots
+  static constexpr int o_dkr = o_kr + 4 * NT * R;             // [4][NT][R] their d keys accumulators           }
+  static constexpr int kFloats = o_dkr + 4 * NT * R;
+};
+
+template <int R, int RR>
+__global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
+  typedef BDims<R, RR> D;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NCL = 8;
+  const int cl = blockIdx.x % NCL, peer = blockIdx.x / NCL;
+  const int B = a.B, Tt = a.Tt, Td = a.Td;
+  const int ncl_used = (B + R - 1) / R;
+  constexpr int R80 = D::R80;
+  float* const VO = smem + D::o_vo;
+  float* const DCP = smem + D::o_dcp;
+  float* const DXR = smem + D::o_dxr;
+  float* const ALS = smem + D::o_als;
+  float* const DES = smem + D::o_des;
+  float* const OWN = smem + D::o_own;
+  int* const dead = reinterpret_cast<int*>(smem + D::o_dead);
+  const DecWeights& w = a.wT;
+  Xc X;
+  X.base = (gu64*)(reinterpret_cast<u64*>(a.xchg) + (int64_t)cl * R * kX3Row);
+  {
+    gi32* tab = (gi32*)(reinterpret_cast<int*>(a.xchg) + a.xcc_table_ofs);
+    int* sflag = reinterpret_cast<int*>(smem);
+    if (tid == 0) {
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      __hip_atomic_store(tab + blockIdx.x, (int)(xcc & 15u) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid < P3) {
+      int v = 0;
+      for (unsigned spin = 0; spin < (1u << 22); ++spin) {
+        v = __hip_atomic_load(tab + tid * NCL + cl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v != 0) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+      const int v0 = __shfl(v, 0, 64);
+      const bool same = __all(tid >= P3 || (v != 0 && v == v0));
+      if (tid == 0) sflag[0] = same ? 1 : 0;
+    }
+    __syncthreads();
+    X.fast = sflag[0] != 0 && a.fast_ok;
+    __syncthreads();
+    if (cl >= ncl_used) return;
+  }
+  X.err = a.err;
+  X.dead = dead;
+  X.epoch = 0;
+  X.fake = a.fakew;
+  X.trace = nullptr;
+  X.tslot = 0;
+  X.polls = 0;
+
+  RV brow, len, valid;
+  static_for<R>([&](auto Q) {
+    constexpr int q = decltype(Q)::value;
+    const int b = cl * R + q;
+    valid.template at<q>() = b < B;
+    brow.template at<q>() = b < B ? b : B - 1;
+    const int l = a.text_length[brow.template get<q>()];
+    len.template at<q>() = l < 1 ? 1 : (l > Tt ? Tt : l);
+  });
+
+  for (int i = tid; i < D::o_zero_end; i += NT) smem[i] = 0.f;
+  if (tid == 0) *dead = 0;
+
+  // ---- register-resident (transposed) weights ----
+  const int lk32 = lane & 31;
+  const int unit = peer * 8 + wave;                       // this wave's unit
+  WReg<4> wdp2;                                           // d p2 = dx . Wi_p^T : columns peer*4 + wave (waves 0..3) of wT.in_w (256, 384)
+  WReg<2> wdp1;                                           // d p1 = d p2pre . W2^T : column `unit` of wT.pre_w2 (128, 256)
+  WReg<D::KPL_O> wout;                                    // column `unit` of [wot ; wdx]
+  WReg<8> wc0, wc1, wc2;                                  // wT.cw[l] (256, 512): column unit (lanes 0-31) / 256 + unit (lanes 32-63)
+  WReg<16> wg0, wg1, wg2;                                 // wT.gw[l] (512, 512): likewise
+  float4 vres[4];
+  {
+    load_w<4, 64>(wdp2, w.in_w, kPre2 + kAtt, kDec, peer * 4 + (wave & 3), lane, wave < 4);
+    load_w<2, 64>(wdp1, w.pre_w2, kPre1, kPre2, unit, lane, true);
+#pragma unroll
+    for (int j = 0; j < D::KPL_O; ++j) {
+      const int k = lane + 64 * j;
+      const int kw = R80 + 2 * kAtt;
+      const float v1 = a.wot[(int64_t)(k < kw ? k : 0) * kDec + unit];
+      const float v2 = a.wdx[(int64_t)((k >= kw && k < D::KO) ? k - kw : 0) * kDec + unit];
+      wout.w[j] = k < kw ? v1 : (k < D::KO ? v2 : 0.f);
+    }
+    const int ncg = unit + (lane >> 5) * kDec;
+    load_w<8, 32>(wc0, w.cw[0], 2 * kDec, kDec, ncg, lk32, true);
+    load_w<8, 32>(wc1, w.cw[1], 2 * kDec, kDec, ncg, lk32, true);
+    load_w<8, 32>(wc2, w.cw[2], 2 * kDec, kDec, ncg, lk32, true);
+    load_w<16, 32>(wg0, w.gw[0], 2 * kDec, 2 * kDec, ncg, lk32, true);
+    load_w<16, 32>(wg1, w.gw[1], 2 * kDec, 2 * kDec, ncg, lk32, true);
+    load_w<16, 32>(wg2, w.gw[2], 2 * kDec, 2 * kDec, ncg, lk32, true);
+    // d alignments: slot g = i*256 + wave*32 + peer -> (rho = g % R, s = g / R): the wave keeps its four VWxc rows in registers
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int g = i * 256 + wave * 32 + peer;
+      const int rho = g % R, sidx = g / R;
+      const bool on = sidx < rsel<R>(len, rho);
+      vres[i] = on ? reinterpret_cast<const float4*>(a.vwx + ((int64_t)rsel<R>(brow, rho) * Tt + sidx) * kDec)[lane]
+                   : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // energy backward: the wave's unit over all memory rows: keys[b][lane + 64 i][unit] (LDS private slots), accumulators zero
+    float* const KR = smem + D::o_kr + tid * R;
+    float* const DKR = smem + D::o_dkr + tid * R;
+    static_for<R>([&](auto Q) {
+      constexpr int q = decltype(Q)::value;
+      const float* kb = a.keys + (int64_t)brow.template get<q>() * Tt * kAtt;
+      const int ln = len.template get<q>();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int sx = lane + 64 * i;
+        KR[i * NT * R + q] = sx < ln ? kb[(int64_t)sx * kAtt + unit] : 0.f;
+        DKR[i * NT * R + q] = 0.f;
+      }
+    });
+  }
+  const float vu = a.att_v[unit];
+  Acc<R> dvu;      // d attention_v[unit] per row: this lane's partial over its memory rows, all steps
+  dvu.zero();
+  __syncthreads();
+
+  const float km1c = a.keep1 ? 2.f : 1.f, km2c = a.keep2 ? 2.f : 1.f;
+  const float* const stash = a.stash;
+  float* const gst = a.gstash;
+  auto own = [&](int slot, int wv, int rho) -> float& { return OWN[(slot * 8 + wv) * R + rho]; };
+
+  // ---- prefetch of the next processed step's inputs (registers; landed in LDS at the head of that step) ----
+  // result lanes 16+rho / 48+rho of every wave: the 12 record values of their unit; all threads: d out and alignment rows
+  constexpr int NDO = (R * R80 + NT - 1) / NT, NAL = (R * TTP + NT - 1) / NT;
+  float prec[12], pq = 0.f, pp1 = 0.f, pp2 = 0.f, pdo[NDO], pal[NAL];
+  auto prefetch = [&](int tp) {          // tp = step whose data is fetched (>= 0)
+    const Lane<R, 32> M;
+    if (M.res) {
+      const unsigned bt = (unsigned)(rsel<R>(brow, M.rho) * Td + tp);
+      const float* st = stash + bt * kStRec;
+      const int u = peer * 8 + M.wave;
+#pragma unroll
+      for (int l = 0; l < 3; ++l) {
+        prec[4 * l + 0] = st[kStR + l * kDec + u];
+        prec[4 * l + 1] = st[kStU + l * kDec + u];
+        prec[4 * l + 2] = st[kStC + l * kDec + u];
+        prec[4 * l + 3] = tp > 0 ? (st - kStRec)[kStH + l * kDec + u] : 0.f;
+      }
+      pq = st[kStQ + u];
+      // pre-net activations of step tp + 1 (their backward runs one step late, in step tp's FAN / DQ rounds)
+      pp1 = tp + 1 < Td ? st[kStRec + kStP1 + u] : 0.f;
+      pp2 = (tp + 1 < Td && M.wave < 4) ? st[kStRec + kStP2 + peer * 4 + M.wave] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NDO; ++j) {
+      const int i = M.tid + j * NT;           // (rho, c) of d out: i = rho * R80 + c
+      const int qd = i / R80, cd = i - qd * R80;
+      pdo[j] = (qd < R) ? a.dout[(unsigned)(rsel<R>(brow, qd) * Td + tp) * R80 + cd] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NAL; ++j) {
+      const int i = M.tid + j * NT;           // (rho, s) of the alignments: i = rho * TTP + s
+      const int qa = i / TTP, sa = i - qa * TTP;
+      pal[j] = (qa < R && sa < Tt) ? a.align[(unsigned)(rsel<R>(brow, qa) * Td + tp) * (unsigned)Tt + sa] : 0.f;
+    }
+  };
+  prefetch(Td - 1);
+
+  for (int t = Td - 1; t >= 0; --t) {
+    X.epoch = (unsigned)(Td - t);
+    const bool has_next = t + 1 < Td;
+    RV nfo;   // step t+1 of the row was fed by this step's output (sampled): its pre-net gradient flows back into this step
+    static_for<R>([&](auto Q) {
+      constexpr int q = decltype(Q)::value;
+      nfo.template at<q>() = has_next && a.sample && a.sample[(unsigned)(t * B + brow.template get<q>())];
+    });
+    // ---- 0. land the prefetched inputs ----
+    {
+      const Lane<R, 32> M;
+      if (M.res && M.lane < 32) {   // (lanes 16+rho; the twins 48+rho hold the same values)
+#pragma unroll
+        for (int k = 0; k < 12; ++k) own(D::w_rec + k, M.wave, M.rho) = prec[k];
+        own(D::w_q, M.wave, M.rho) = pq;
+        own(D::w_p1, M.wave, M.rho) = pp1;
+        if (M.wave < 4) smem[D::o_p2m + M.wave * R + M.rho] = pp2;
+      }
+#pragma unroll
+      for (int j = 0; j < NDO; ++j) {
+        const int i = M.tid + j * NT;
+        const int qd = i / R80, cd = i - qd * R80;
+        if (qd < R) VO[cd * R + qd] = pdo[j];
+      }
+#pragma unroll
+      for (int j = 0; j < NAL; ++j) {
+        const int i = M.tid + j * NT;
+        const int qa = i / TTP, sa = i - qa * TTP;
+        if (qa < R) ALS[qa * TTP + sa] = pal[j];
+      }
+    }
+    lds_barrier();
+    // ---- 1. round FAN: d alignments[rho][s] = VWxc[s] . dx_{t+1}   (+ rider: d p2_{t+1} = mask (dx_{t+1} . Wi_p^T)) ----
+    {
+      const Lane<R, 64> L;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int g = i * 256 + L.wave * 32 + peer;
+        const int rho = g % R, sidx = g / R;
+        if (sidx < rsel<R>(len, rho)) {
+          const float4 c4 = reinterpret_cast<const float4*>(DXR + rho * kDec)[L.lane];
+          const float4 x4 = vres[i];
+          float dd = x4.x * c4.x + x4.y * c4.y + x4.z * c4.z + x4.w * c4.w;
+          dd = wave_sum(dd);
+          if (L.lane == 0) put_granule<R>(X, Y3_DAL, sidx, rho, dd);
+        }
+      }
+      if (has_next) {
+        Acc<R> ap;
+        ap.zero();
+        mv<R, 4, 64>(wdp2, VO + (R80 + 2 * kAtt) * R, L.lane, ap);
+        col_sum_all<R, 64>(ap);
+        if (L.res && L.wave < 4) {
+          const int n4 = peer * 4 + L.wave;
+          const float g = smem[D::o_p2m + L.wave * R + L.rho] > 0.f ? km2c * pick<R>(ap, L.rho) : 0.f;
+          smem[D::o_dp2 + n4 * R + L.rho] = g;
+          put_granule<R>(X, Y3_DP2, n4, L.rho, g);
+        }
+        gather<R, 1>(X, Y3_DP2, kPre2, [&](int n) { return (n >> 2) == peer; },
+                     [&](int n, int q, float v) { smem[D::o_dp2 + n * R + q] = v; });
+      }
+      gather<R, (TTP * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(
+          X, Y3_DAL, TTP, [&](int n) { return false; }, [&](int n, int q, float v) { DES[q * TTP + n] = v; },
+          [&](int n, int q) { return n < rsel<R>(len, q); });
+    }
+    lds_barrier();
+    // ---- 2. softmax backward: de = al * (dal - sum al dal)   (wave rho handles row rho) ----
+    {
+      const Lane<R, 64> L;
+      if (L.wave < R) {
+        const int q = L.wave;
+        const int ln = rsel<R>(len, q);
+        float al[4], dl[4], dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int sx = L.lane + 64 * j;
+          al[j] = sx < ln ? ALS[q * TTP + sx] : 0.f;
+          dl[j] = sx < ln ? DES[q * TTP + sx] : 0.f;
+          dot += al[j] * dl[j];
+        }
+        dot = wave_sum(dot);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) DES[q * TTP + L.lane + 64 * j] = al[j] * (dl[j] - dot);
+      }
+    }
+    lds_barrier();
+    // ---- 3. energy backward on the wave's unit over all memory rows:  th = tanh(keys + q); dpre = de v (1 - th^2);
+    //         dq[u] = sum_s dpre ; dkeys[s, u] += dpre ; dv[u] += de th      (+ rider: d p1_{t+1} = mask (d p2 . W2^T)) ----
+    {
+      const Lane<R, 64> L;
+      const int u = peer * 8 + L.wave;
+      Acc<R> dq;
+      dq.zero();
+      {
+        float* const KR = smem + D::o_kr + L.tid * R;
+        float* const DKR = smem + D::o_dkr + L.tid * R;
+        const XV<R> qv = lds_rows<R>(OWN + (D::w_q * 8 + L.wave) * R);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const XV<R> kr = lds_rows<R>(KR + i * NT * R);
+          XV<R> dk = lds_rows<R>(DKR + i * NT * R);
+          const int sx = L.lane + 64 * i;
+#pragma unroll
+          for (int q = 0; q < R; ++q) {
+            const float de = DES[q * TTP + sx];        // (zero past text_length: the softmax backward wrote al = 0 there)
+            const float th = tanh_fast(kr.v[q] + qv.v[q]);
+            const float pre = de * vu * (1.f - th * th);
+            dq.v[q] += pre;
+            dk.v[q] += pre;
+            dvu.v[q] += de * th;
+          }
+          if constexpr (R == 4) *reinterpret_cast<float4*>(DKR + i * NT * R) = make_float4(dk.v[0], dk.v[1], dk.v[2], dk.v[3]);
+          else if constexpr (R == 2) *reinterpret_cast<float2*>(DKR + i * NT * R) = make_float2(dk.v[0], dk.v[1]);
+          else DKR[i * NT * R] = dk.v[0];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < R; ++q) dq.v[q] = wave_sum(dq.v[q]);
+      if (L.lane < R) {
+        const float v = pick<R>(dq, L.lane);
+        VO[(R80 + u) * R + L.lane] = v;
+        put_granule<R>(X, Y3_DQ, u, L.lane, v);
+      }
+      float g1 = 0.f;
+      if (has_next) {
+        Acc<R> ap;
+        ap.zero();
+        mv<R, 2, 64>(wdp1, smem + D::o_dp2, L.lane, ap);
+        col_sum_all<R, 64>(ap);
+        if (L.res) {
+          g1 = own(D::w_p1, L.wave, L.rho) > 0.f ? km1c * pick<R>(ap, L.rho) : 0.f;
+          g1 = rsel<R>(nfo, L.rho) ? g1 : 0.f;    // d p1pre of step t+1 reaches this step's output only where that step was fed by it
+          VO[(R80 + kAtt + u) * R + L.rho] = g1;
+          put_granule<R>(X, Y3_DP1, u, L.rho, g1);
+        }
+        gather<R, (256 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(X, Y3_DP1, 256, [&](int n) { return (n >> 3) == peer; },
+                                                             [&](int n, int q, float v) { VO[(R80 + kAtt + n) * R + q] = v; });
+      }
+      gather<R, (256 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(X, Y3_DQ, 256, [&](int n) { return (n >> 3) == peer; },
+                                                           [&](int n, int q, float v) { VO[(R80 + n) * R + q] = v; });
+      if (L.lane < R && rsel<R>(valid, L.lane)) gst[(unsigned)(rsel<R>(brow, L.lane) * Td + t) * kGsRec + kGsQ + u] = pick<R>(dq, L.lane);
+      if (L.res && rsel<R>(valid, L.rho)) gst[(unsigned)(rsel<R>(brow, L.rho) * Td + t) * kGsRec + kGsP1S + u] = g1;
+    }
+    lds_barrier();
+    // ---- 4. round OUT: dy = [d out ; dq ; d p1] . wot + dx_{t+1} . wdx ; owner: dht_3, (dcp, dup) of GRU-3 ----
+    // elementwise GRU derivative of the unit at layer l given the total dL/dh_l' (shared by OUT and the G rounds)
+    auto gru_elem = [&](int l, int wv, int rho, float dht, int u, unsigned gsb, bool vld) {
+      const float uu = own(D::w_rec + 4 * l + 1, wv, rho), c = own(D::w_rec + 4 * l + 2, wv, rho), hp = own(D::w_rec + 4 * l + 3, wv, rho);
+      const float du = dht * (hp - c);
+      const float dc = dht * (1.f - uu);
+      const float dcp = dc * (1.f - c * c);
+      const float dup = du * uu * (1.f - uu);
+      own(D::w_dht, wv, rho) = dht;
+      smem[D::o_dcp + u * R + rho] = dcp;
+      smem[((l & 1) ? D::o_dgpb : D::o_dgpa) + (kDec + u) * R + rho] = dup;
+      put_granule<R>(X, Y3_CG + l * 512, u, rho, dcp);
+      put_granule<R>(X, Y3_CG + l * 512, kDec + u, rho, dup);
+      if (vld) {
+        gst[gsb + kGsC + l * kDec + u] = dcp;
+        gst[gsb + kGsG + l * 512 + kDec + u] = dup;
+      }
+    };
+    auto cg_put = [&](int l) {
+      return [&, l](int n, int q, float v) {
+        const int i = n < kDec ? D::o_dcp + n * R : ((l & 1) ? D::o_dgpb : D::o_dgpa) + n * R;
+        smem[i + q] = v;
+      };
+    };
+    {
+      const Lane<R, 64> L;
+      const int u = peer * 8 + L.wave;
+      Acc<R> ao;
+      ao.zero();
+      mv<R, D::KPL_O, 64>(wout, VO, L.lane, ao);
+      col_sum_all<R, 64>(ao);
+      if (L.res) {
+        const float dy = pick<R>(ao, L.rho);
+        own(D::w_dy, L.wave, L.rho) = dy;
+        gru_elem(2, L.wave, L.rho, own(D::w_dh + 2, L.wave, L.rho) + dy, u, (unsigned)(rsel<R>(brow, L.rho) * Td + t) * kGsRec,
+                 rsel<R>(valid, L.rho) != 0);
+      }
+      gather<R, (512 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(X, Y3_CG + 2 * 512, 512, [&](int n) { return ((n & 255) >> 3) == peer; }, cg_put(2));
+    }
+    if (t > 0) prefetch(t - 1);   // (mid-step: these loads have six rounds to land)
+    lds_barrier();
+    // ---- 5. GRU layers, top down ----
+#pragma unroll
+    for (int l = 2; l >= 0; --l) {
+      const int o_dgp = (l & 1) ? D::o_dgpb : D::o_dgpa;
+      {   // C_l: [d inp ; d(r h)] = dcp . Wc^T
+        const Lane<R, 32> M;
+        const int u = peer * 8 + M.wave;
+        Acc<R> ac;
+        ac.zero();
+        mv<R, 8, 32>(l == 0 ? wc0 : (l == 1 ? wc1 : wc2), DCP, M.lk, ac);
+        col_sum_all<R, 32>(ac);
+        float gr = 0.f;
+        if (M.res) {
+          const float y = pick<R>(ac, M.rho);
+          if (M.lane < 32) {
+            own(D::w_dinp, M.wave, M.rho) = y;
+          } else {
+            const float rr = own(D::w_rec + 4 * l + 0, M.wave, M.rho), uu = own(D::w_rec + 4 * l + 1, M.wave, M.rho),
+                        hp = own(D::w_rec + 4 * l + 3, M.wave, M.rho);
+            gr = y * hp * rr * (1.f - rr);
+            smem[o_dgp + u * R + M.rho] = gr;
+            put_granule<R>(X, Y3_GR + l * 256, u, M.rho, gr);
+            own(D::w_dhp, M.wave, M.rho) = own(D::w_dht, M.wave, M.rho) * uu + y * rr;   // partial new carry: dht u + d(rh) r
+          }
+        }
+        gather<R, (256 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(X, Y3_GR + l * 256, 256, [&](int n) { return (n >> 3) == peer; },
+                                                             [&](int n, int q, float v) { smem[o_dgp + n * R + q] = v; });
+        if (M.res && M.lane >= 32 && rsel<R>(valid, M.rho)) gst[(unsigned)(rsel<R>(brow, M.rho) * Td + t) * kGsRec + kGsG + l * 512 + u] = gr;
+      }
+      lds_barrier();
+      {   // G_l: [d inp ; d h] += dgp . Wg^T
+        const Lane<R, 32> M;
+        const int u = peer * 8 + M.wave;
+        Acc<R> ag;
+        ag.zero();
+        mv<R, 16, 32>(l == 0 ? wg0 : (l == 1 ? wg1 : wg2), smem + o_dgp, M.lk, ag);
+        col_sum_all<R, 32>(ag);
+        float dxv = 0.f;
+        if (M.res) {
+          const float y = pick<R>(ag, M.rho);
+          const unsigned gsb = (unsigned)(rsel<R>(brow, M.rho) * Td + t) * kGsRec;
+          const bool vld = rsel<R>(valid, M.rho) != 0;
+          if (M.lane < 32) {
+            const float di = own(D::w_dinp, M.wave, M.rho) + y;
+            if (l > 0) {
+              gru_elem(l - 1, M.wave, M.rho, own(D::w_dh + l - 1, M.wave, M.rho) + di, u, gsb, vld);   // next layer down: carried + input path
+            } else {
+              dxv = own(D::w_dy, M.wave, M.rho) + di;                                               // x feeds GRU-1 and the residual
+              VO[(R80 + 2 * kAtt + u) * R + M.rho] = dxv;
+              DXR[M.rho * kDec + u] = dxv;
+              put_granule<R>(X, Y3_DX, u, M.rho, dxv);
+            }
+          } else {
+            own(D::w_dh + l, M.wave, M.rho) = own(D::w_dhp, M.wave, M.rho) + y;                     // new carried dL/dh_l
+          }
+        }
+        if (l > 0) {
+          gather<R, (512 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(X, Y3_CG + (l - 1) * 512, 512, [&](int n) { return ((n & 255) >> 3) == peer; },
+                                                               cg_put(l - 1));
+        } else {
+          gather<R, (256 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(X, Y3_DX, 256, [&](int n) { return (n >> 3) == peer; },
+                                                               [&](int n, int q, float v) {
+                                                                 VO[(R80 + 2 * kAtt + n) * R + q] = v;
+                                                                 DXR[q * kDec + n] = v;
+                                                               });
+          if (M.res && M.lane < 32 && rsel<R>(valid, M.rho)) gst[(unsigned)(rsel<R>(brow, M.rho) * Td + t) * kGsRec + kGsX + u] = dxv;
+        }
+      }
+      lds_barrier();
+    }
+  }
+  // ---- resident d keys accumulators -> memory; attention_v gradient per row ----
+  {
+    const float* const DKR = smem + D::o_dkr + tid * R;
+    static_for<R>([&](auto Q) {
+      constexpr int q = decltype(Q)::value;
+      if (valid.template get<q>()) {
+        float* dk = a.dkeys + (int64_t)brow.template get<q>() * Tt * a.ldk;
+        const int ln = len.template get<q>();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int sx = lane + 64 * i;
+          if (sx < ln) dk[(int64_t)sx * a.ldk + unit] = DKR[i * NT * R + q];
+        }
+        const float dv = wave_sum(dvu.v[q]);
+        if (lane == 0) a.datt_v[(int64_t)brow.template get<q>() * kAtt + unit] = dv;   // per-row partial; rows are summed in order afterwards
+      }
+    });
+  }
+}
+
 template <int R, int RR>
 int launch3(DecFwdArgs& a, int ncl, hipStream_t s) {
   typedef Dims<R, RR> D;
@@ -928,6 +1417,51 @@ int launch3(DecFwdArgs& a, int ncl, hipStream_t s) {
 }
 
 }  // namespace
+
+template <int R, int RR>
+int launch3b(DecBwdArgs& a, hipStream_t s) {
+  typedef BDims<R, RR> D;
+  void (*kern)(DecBwdArgs) = decoder3_bwd_kernel<R, RR>;
+  const size_t smem = (size_t)D::kFloats * sizeof(float);
+  static_assert(D::kFloats * sizeof(float) <= 160 * 1024, "decoder3 backward: LDS budget");
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) {
+      taco_set_error("decoder3_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return TACO_ELAUNCH;
+    }
+  }
+  int dev = 0, cus = 0, per_cu = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, NT, smem);
+  if (e != hipSuccess || (int64_t)cus * per_cu < (int64_t)8 * P3) return TACO_ENOTFOUND;
+  e = hipMemsetAsync(a.xchg, 0, (size_t)decoder_xchg_bytes(a.B, a.Tt), s);
+  if (e != hipSuccess) {
+    taco_set_error("decoder3_bwd: memset: %s", hipGetErrorString(e));
+    return TACO_ELAUNCH;
+  }
+  hipLaunchKernelGGL(kern, dim3(8 * P3), dim3(NT), smem, s, a);
+  TACO_LAUNCH_CHECK("decoder3_bwd");
+  return TACO_OK;
+}
+
+int launch_decoder3_bwd(DecBwdArgs a, hipStream_t s) {
+  const char* env = getenv("TACO_DEC_V3");
+  if (env && (atoi(env) == 0 || atoi(env) == 1)) return TACO_ENOTFOUND;   // TACO_DEC_V3=1: forward only (A/B runs)
+  if (a.Tt > TTP || a.B > 32 || a.B < 1 || (a.r != 2 && a.r != 5)) return TACO_ENOTFOUND;
+  if (!a.hoisted || a.trace) return TACO_ENOTFOUND;
+  const int R = a.B > 16 ? 4 : (a.B > 8 ? 2 : 1);
+  const int ncl = (a.B + R - 1) / R;
+  if ((int64_t)ncl * R * kX3Row * 8 + 1024 > decoder_xchg_bytes(a.B, a.Tt)) return TACO_ENOTFOUND;
+  a.xcc_table_ofs = (int)(decoder_xchg_bytes(a.B, a.Tt) / 4 - 256);
+  a.fast_ok = getenv("TACO_DEC_V3_AGENT") ? 0 : 1;
+  a.fakew = kProbes3 ? ((getenv("TACO_DEC_FAKEX") ? 2 : 0)) : 0;
+  a.P = P3;
+  decoder_note_cluster(1, P3);
+  if (a.r == 2) return R == 4 ? launch3b<4, 2>(a, s) : (R == 2 ? launch3b<2, 2>(a, s) : launch3b<1, 2>(a, s));
+  return R == 4 ? launch3b<4, 5>(a, s) : (R == 2 ? launch3b<2, 5>(a, s) : launch3b<1, 5>(a, s));
+}
 
 // Returns TACO_ENOTFOUND (nothing enqueued) when the shape is outside this kernel's scope; the caller then takes decoder.hip.
 int launch_decoder3_fwd(DecFwdArgs a, hipStream_t s) {

@@ -300,10 +300,12 @@ struct DecBwdArgs {
   int P;
   int fakew = 0;
   int lres0 = 0, lres1 = 0;  // launch-resident weight rows (LDS) of the GRU-3 / GRU-2 gate mat-vecs; chosen by launch_decoder_bwd
+  int xcc_table_ofs = 0, fast_ok = 1;   // decoder3.hip (see DecFwdArgs)
   int hoisted = 0;           // 1: the pre-net gradients of the teacher-forced steps are formed after the launch (model.hip); the kernel
                              //    runs the pre-net backward only where a step was fed by the previous output
 };
 int launch_decoder_bwd(DecBwdArgs a, hipStream_t s);
+int launch_decoder3_bwd(DecBwdArgs a, hipStream_t s);   // decoder3.hip; TACO_ENOTFOUND outside its scope
 
 // ---------------------------------------------------------------- vocoder.hip
 // Griffin-Lim (audio.py:77-97).  mag_t / phase0 (B, 1025, F); wave (B, 300 (F - 1)); work: griffinlim_workspace_floats floats

@@ -992,7 +992,9 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     a.trace = getenv("TACO_DEC_TRACE") ? reinterpret_cast<long long*>(ws + W.err + 16) + 128 : nullptr;
     a.B = B; a.Tt = Tt; a.Td = Td; a.r = r; a.P = 1;
     const int slot = prof_begin(1, s);
-    TACO_TRY(launch_decoder_bwd(a, s));
+    int rc = launch_decoder3_bwd(a, s);
+    if (rc == TACO_ENOTFOUND) rc = launch_decoder_bwd(a, s);
+    TACO_TRY(rc);
     prof_end(1, slot, s);
     if (!defer && !taco_dp().overlap_bptt) TACO_TRY(record_segment(2, s));
     // the scratch buffers the deferred post-net GEMMs read are reused from here on
