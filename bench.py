@@ -223,14 +223,18 @@ def main():
             for _ in range(2):
                 mi.run()
             torch.cuda.synchronize()
-            ti = time.perf_counter()
-            n_it = 5
-            for _ in range(n_it):
+            # median of per-call times: one call in ~100 stalls for 80-90 ms on the HOST (profiles/r03_inference_outlier_probe.txt),
+            # which a mean over a handful of calls turns into a 2-3x "slowdown"
+            calls = []
+            for _ in range(9):
+                ti = time.perf_counter()
                 mi.run()
-            torch.cuda.synchronize()
-            ms = (time.perf_counter() - ti) / n_it * 1e3
+                torch.cuda.synchronize()
+                calls.append((time.perf_counter() - ti) * 1e3)
+            ms = sorted(calls)[len(calls) // 2]
             mi.check()
             infer['B%d' % Bi] = {'ms_per_batch': ms, 'mel_frames_per_s': Bi * Td * ci.r / (ms * 1e-3),
+                                 'ms_per_call': [round(x, 3) for x in calls],
                                  'decoder_cluster_width': lib.last_cluster(0), 'placement_census': mi.placement_census(),
                                  'gflop': model_flops(Bi, 140, Td, ci.r) / 1e9,
                                  'tflops': model_flops(Bi, 140, Td, ci.r) / (ms * 1e-3) / 1e12}
@@ -261,7 +265,7 @@ def main():
         frames = world * B * Td * c.r
         fa = sum(fwd_ms) / max(1, len(fwd_ms))
         ba = sum(bwd_ms) / max(1, len(bwd_ms))
-        dom, dom_ms = ('decoder_bwd_kernel', ba) if ba >= fa else ('decoder_fwd_kernel', fa)
+        dom, dom_ms = ('decoder3_bwd_kernel', ba) if ba >= fa else ('decoder3_fwd_kernel', fa)
         # algorithmic FLOPs of ONE launch: forward = SURVEY 8(d) decoder figure; the backward kernel does the
         # transposed mat-vecs + attention backward = the same count again (weight gradients are separate GEMMs).
         flops = decoder_flops(B, Tt, Td, c.r)
@@ -284,8 +288,9 @@ def main():
              'avg_ms': dom_ms, 'us_per_decoder_step': dom_ms * 1e3 / Td, 'flops_per_launch': flops, 'traffic': traffic,
              'traffic_source': 'profiles/pmc_latest.json (rocprofv3 --pmc passes of tools/profile_round.sh; a committed constant, '
                                'used only when its source hash equals this build -- not measured in this run)' if traffic else None,
-             'note': 'persistent per-row recurrence: %d strictly sequential steps x 8-9 dependent exchange rounds, no MFMA, '
-                     'not HBM bound; the fp32 peak is quoted for scale only (DESIGN.md 5)' % Td},
+             'note': 'persistent recurrence (decoder3.hip: 8 clusters x 32 workgroups x 4 rows, register-resident weights): %d strictly '
+                     'sequential steps x 8-9 dependent exchange rounds, no MFMA, not HBM bound; the fp32 peak is quoted for scale '
+                     'only (DESIGN.md 5)' % Td},
             {'what': 'whole train step', 'bound': 'mfma', 'achieved': step_flops / sec_per_step / 1e12, 'peak': PEAK,
              'unit': 'TFLOP/s', 'frac': step_flops / sec_per_step / 1e12 / PEAK, 'flops_per_step': step_flops,
              'ms_per_step': sec_per_step * 1e3},
@@ -313,7 +318,7 @@ def main():
                                    % (B, c.r, Tt, Td, Td * c.r, args.speakers),
                        'global_batch': world * B, 'parallelism': 'dp%d' % world},
             # dominant kernel (largest share of the step); `rooflines` carries every family
-            'roofline': dict(rooflines[0], kernel=dom, launches_timed=len(bwd_ms if dom.startswith('decoder_bwd') else fwd_ms)),
+            'roofline': dict(rooflines[0], kernel=dom, launches_timed=len(bwd_ms if dom.startswith('decoder3_bwd') else fwd_ms)),
             'rooflines': rooflines,
             'kernels_ms': {'decoder_fwd_kernel': fa, 'decoder_bwd_kernel': ba,
                            'us_per_decoder_step_fwd': fa * 1e3 / Td, 'us_per_decoder_step_bwd': ba * 1e3 / Td,

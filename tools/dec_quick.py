@@ -42,8 +42,10 @@ for Bi in (1, 32):
     mi = Tacotron(ci, synthetic_batch(Bi, 140, 180, 2, 60, seed=77, min_len=40), train=False, seed=0)
     for _ in range(2): mi.run()
     torch.cuda.synchronize(); lib.profile_read(0); lib.profile_enable(1)
-    t0 = time.perf_counter()
-    for _ in range(5): mi.run()
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+    its = []
+    for _ in range(12):
+        t0 = time.perf_counter(); mi.run(); torch.cuda.synchronize(); its.append((time.perf_counter() - t0) * 1e3)
+    dt = np.median(its) / 1e3
     lib.profile_enable(0); f = lib.profile_read(0); mi.check()
-    print('inference B=%d: %.2f ms per batch; decoder %.3f ms (%.2f us/step, cluster %d)' % (Bi, dt * 1e3, np.median(f), np.median(f) * 1e3 / 180, lib.last_cluster(0)))
+    print('inference B=%d: %.2f ms per batch (per run: %s); decoder %.3f ms (%.2f us/step, cluster %d)' %
+          (Bi, dt * 1e3, ' '.join('%.1f' % x for x in its), np.median(f), np.median(f) * 1e3 / 180, lib.last_cluster(0)))

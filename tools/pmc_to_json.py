@@ -19,7 +19,7 @@ def main():
     fetch = per_launch(sys.argv[1], 'FETCH_SIZE')
     write = per_launch(sys.argv[2], 'WRITE_SIZE')
     res = {}
-    for key in ('decoder_fwd_kernel', 'decoder_bwd_kernel'):
+    for key in ('decoder3_fwd_kernel', 'decoder3_bwd_kernel', 'decoder_fwd_kernel', 'decoder_bwd_kernel'):
         f = [v for k, v in fetch.items() if key in k]
         w = [v for k, v in write.items() if key in k]
         if not f or not w:
