@@ -704,3 +704,38 @@ def test_inference_is_graph_capturable(built_lib):
     torch.cuda.synchronize()
     assert torch.equal(m.output, ref_out) and torch.equal(m.alignments, ref_al)
     m.check()
+
+
+@pytest.mark.parametrize('B,mode', [(11, 'default'), (12, 'agent'), (20, 'default'), (5, 'v3_off'), (32, 'agent')])
+def test_decoder3_cluster_geometries(built_lib, B, mode, monkeypatch):
+    """decoder3.hip (clusters of 32 workgroups x R rows, register-resident weights): R = 1 / 2 / 4 rows per cluster incl. a
+    partially filled last cluster (B = 11: six clusters of two rows, the last with one valid row; B = 20: five clusters of
+    four), the placement-independent agent-scope exchange forced (TACO_DEC_V3_AGENT=1: what a cluster that straddles XCDs
+    uses), and the decoder.hip fall-back (TACO_DEC_V3=0) -- forward, backward and inference against the fp64 restatement."""
+    if mode == 'agent':
+        monkeypatch.setenv('TACO_DEC_V3_AGENT', '1')
+    if mode == 'v3_off':
+        monkeypatch.setenv('TACO_DEC_V3', '0')
+    r, V, Tt, Td = 2, 33, 41, 9
+    p = on.init_params(V, r, seed=8, perturb=0.2)
+    inp, masks = small_case(r=r, V=V, B=B, Tt=Tt, Td=Td, seed=40 + B)
+    R = Runner(built_lib, B, Tt, Td, r, V)
+    R.set(p, inp, masks)
+    R.forward()
+    assert built_lib.last_cluster(0) == (32 if mode != 'v3_off' else 8)
+    R.backward()
+    assert built_lib.last_cluster(1) == (32 if mode != 'v3_off' else 8)
+    adj, _ = l1_tie_adjusted(R, p, inp, masks, r, Td)
+    lt, s2, o2, a2, ref = ot.loss_and_grads(p, f64(adj), r, Td, f64(masks))
+    assert report('s2s (B=%d, %s)' % (B, mode), R.s2s.cpu().numpy(), s2)[0] < 1e-5
+    assert report('out', R.out.cpu().numpy(), o2)[0] < 1e-5
+    assert report('align', R.al.cpu().numpy(), a2)[1] < 1e-6
+    assert abs(R.loss[0].item() - lt) <= 1e-5 * lt
+    bad = check_grads(R, ref)
+    assert not bad, bad
+    Ri = Runner(built_lib, B, Tt, Td, r, V, train=False)
+    Ri.set(p, {'text': inp['text'], 'text_length': inp['text_length']})
+    Ri.infer()
+    si, oi, ai = on.forward(p, f64(inp), r, Td, train=False, masks=None)[:3]
+    assert report('infer s2s', Ri.s2s.cpu().numpy(), si)[0] < 1e-5
+    assert report('infer align', Ri.al.cpu().numpy(), ai)[1] < 1e-6
