@@ -157,6 +157,57 @@ __device__ __forceinline__ void gather(Xc& X, int reg, int N, Own own, Put put, 
   }
 }
 
+// The same over two regions in ONE poll loop: columns [0, N1) live in region reg1, columns [N1, N) in region reg2.
+template <int R, int MAXU, class Own, class Put, class Need = NeedAll>
+__device__ __forceinline__ void gather2(Xc& X, int reg1, int N1, int reg2, int N, Own own, Put put, Need need = Need()) {
+  constexpr int G = R >= 2 ? 2 : 1;
+  constexpr int UPC = R / G;
+  if (*X.dead) return;
+  if (kProbes3 && (X.fake & 2)) return;
+  const int tid = opaque_tid();
+  int un[MAXU], uh[MAXU];
+  bool pend[MAXU];
+  bool any = false;
+#pragma unroll
+  for (int i = 0; i < MAXU; ++i) {
+    const int u = tid + i * NT;
+    un[i] = UPC == 2 ? (u >> 1) : u;
+    uh[i] = UPC == 2 ? (u & 1) : 0;
+    pend[i] = un[i] < N && !own(un[i]);
+    any |= pend[i];
+  }
+  unsigned spin = 0;
+  while (any) {
+    if (kProbes3) X.polls++;
+    u64 g[MAXU][G];
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i)
+      if (pend[i]) {
+        const int col = un[i] < N1 ? reg1 + un[i] : reg2 + un[i] - N1;
+        const gu64* p = X.base + (unsigned)(col * R + uh[i] * G);
+#pragma unroll
+        for (int q = 0; q < G; ++q) g[i][q] = __hip_atomic_load(p + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    any = false;
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i)
+      if (pend[i]) {
+        bool ok = true;
+#pragma unroll
+        for (int q = 0; q < G; ++q) ok &= (unsigned)(g[i][q] >> 32) == X.epoch || !need(un[i], uh[i] * G + q);
+        if (ok) {
+#pragma unroll
+          for (int q = 0; q < G; ++q)
+            if (need(un[i], uh[i] * G + q)) put(un[i], uh[i] * G + q, __uint_as_float((unsigned)g[i][q]));
+          pend[i] = false;
+        } else {
+          any = true;
+        }
+      }
+    if (any && spin_fail(spin, X)) return;
+  }
+}
+
 // ---- register-resident mat-vec: column `col` of W (K x N, pitch ldw) split over LPC lanes; lane lk holds rows lk + LPC*j ----
 template <int KPL>
 struct WReg {
@@ -448,7 +499,7 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
 
   // ---- register-resident weights (this workgroup's column slices) ----
   // 64-lane columns: one per wave.  x: n = peer*8 + wave; C rounds: same; p1: same; p2: waves 0..3, n = peer*4 + wave.
-  // 32-lane columns: two per wave.  gates: n = peer*16 + wave*2 + (lane >> 5).
+  // 32-lane columns: two per wave.  gates: r column of the wave's unit (lanes 0-31), u column of the same unit (lanes 32-63).
   const int lk32 = lane & 31;
   WReg<D::KPLX> wx;
   WReg<D::KPLG0> wg0;
@@ -459,7 +510,9 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
   float vwx[R][4];
   float4 kres[4];
   {
-    const int n8 = peer * 8 + wave, n16 = peer * 16 + wave * 2 + (lane >> 5), n4 = peer * 4 + (wave & 3);
+    // gate columns of a wave: r of ITS unit (lanes 0-31) and u of ITS unit (lanes 32-63) -- the unit whose candidate column it
+    // finishes in the C round, so the update gate never leaves the lanes that use it
+    const int n8 = peer * 8 + wave, n16 = n8 + (lane >> 5) * kDec, n4 = peer * 4 + (wave & 3);
     load_w<D::KPLX, 64>(wx, cw.wx, kDec, KA, n8, lane, true);
     load_w<D::KPLG0, 32>(wg0, cw.wg0, 2 * kDec, D::KG, n16, lk32, true);
     load_w<8, 64>(wc0, w.cw[0], kDec, 2 * kDec, n8, lane, true);
@@ -579,11 +632,15 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
     park_next(t + 2);
 
     // ---- round G0: x = [p2 ; out'] Wx + al' VWx + bi ;  gates_1 = sigmoid([p2 ; out' ; h1] Wg0' + al' VWg + bg0') ----
+    float ukeep = 0.f;   // update gate of the wave's unit, in the lanes (48 + rho) that finish its candidate column
     {
       const Lane<R, 64> L;
+      const Lane<R, 32> M;
       const int n8 = peer * 8 + L.wave;
-      Acc<R> ax;
+      const int n16 = n8 + (M.lane >> 5) * kDec;
+      Acc<R> ax, ag;
       ax.zero();
+      ag.zero();
       mv<R, D::KPLX, 64>(wx, U0, L.lane, ax);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -592,19 +649,6 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
         for (int q = 0; q < R; ++q) ax.v[q] = fmaf(al.v[q], vwx[q][j], ax.v[q]);
       }
       __builtin_amdgcn_sched_barrier(0);
-      col_sum_all<R, 64>(ax);
-      float yx = 0.f;
-      if (L.res) {
-        yx = pick<R>(ax, L.rho) + BIAS[D::b_in + n8];
-        XS[n8 * R + L.rho] = yx;
-        CATA[n8 * R + L.rho] = yx;
-        put_granule<R>(X, X3_X, n8, L.rho, yx);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      const Lane<R, 32> M;
-      const int n16 = peer * 16 + M.wave * 2 + (M.lane >> 5);
-      Acc<R> ag;
-      ag.zero();
       mv<R, D::KPLG0, 32>(wg0, U0, M.lk, ag);
       {
         const float* vwg = smem + D::o_vwg + M.tid * R;
@@ -617,36 +661,38 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
           if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
       }
+      col_sum_all<R, 64>(ax);     // (the two reductions are independent chains: issued back to back they overlap)
       col_sum_all<R, 32>(ag);
-      float gg = 0.f, gv = 0.f;
+      float yx = 0.f, gg = 0.f, gv = 0.f;
+      if (L.res) {
+        yx = pick<R>(ax, L.rho) + BIAS[D::b_in + n8];
+        XS[n8 * R + L.rho] = yx;
+        CATA[n8 * R + L.rho] = yx;
+        put_granule<R>(X, X3_X, n8, L.rho, yx);
+      }
       if (M.res) {
         gg = sigmoid_fast(pick<R>(ag, M.rho) + BIAS[D::b_g + n16]);
-        gv = gg;
-        if (n16 < kDec) {
-          gv = gg * H1[n16 * R + M.rho];
-          CATA[(kDec + n16) * R + M.rho] = gv;
+        if (M.lane < 32) {
+          gv = gg * H1[n8 * R + M.rho];
+          CATA[(kDec + n8) * R + M.rho] = gv;
+          put_granule<R>(X, X3_G0, n8, M.rho, gv);
         } else {
-          US[(n16 - kDec) * R + M.rho] = gg;
+          ukeep = gg;
         }
-        put_granule<R>(X, X3_G0, n16, M.rho, gv);
       }
       tstamp(X);   // G0: computed + published
-      gather<R, (768 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(
-          X, X3_X, 768,
-          [&](int n) { return n < 256 ? (n >> 3) == peer : ((n - 256) >> 4) == peer; },
+      gather<R, (512 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(
+          X, X3_X, 512, [&](int n) { return ((n & 255) >> 3) == peer; },
           [&](int n, int q, float v) {
-            // (one store through an integer index into the LDS array: with a store per branch hipcc merges them into a store
-            //  through a pointer selected from a stack table -- generic address space, scratch loads)
-            const int i = n < 512 ? D::o_catc + n * R : D::o_us + (n - 512) * R;   // x -> CATA[n]; r*h of unit n-256 -> CATA[256 + (n-256)]; u
-            smem[i + q] = v;
+            smem[D::o_catc + n * R + q] = v;                 // x -> CATA[n]; r*h of unit n-256 -> CATA[256 + (n-256)]
             if (n < 256) smem[D::o_xs + n * R + q] = v;
           });
       if (TR) {   // stash stores after the polls: they then fly under the next round instead of in front of this round's loads
         if (L.res && rsel<R>(valid, L.rho)) stash[(unsigned)(rsel<R>(brow, L.rho) * Td + t) * kStRec + kStX + n8] = yx;
         if (M.res && rsel<R>(valid, M.rho)) {
           float* st = stash + (unsigned)(rsel<R>(brow, M.rho) * Td + t) * kStRec;
-          if (n16 < kDec) { st[kStR + n16] = gg; st[kStRH + n16] = gv; }
-          else st[kStU + n16 - kDec] = gg;
+          if (M.lane < 32) { st[kStR + n8] = gg; st[kStRH + n8] = gv; }
+          else st[kStU + n8] = gg;
         }
       }
       tstamp(X);   // G0: gathered
@@ -661,7 +707,7 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
       float* const CNX = l == 1 ? CATA : CATB;    // ... of the next layer (its input part is written by THIS layer's candidate round)
       if (l > 0) {
         const Lane<R, 32> M;
-        const int n16 = peer * 16 + M.wave * 2 + (M.lane >> 5);
+        const int n8 = peer * 8 + M.wave;
         float* const CL = l == 1 ? CAT1 : CAT2;
         Acc<R> ag;
         ag.zero();
@@ -669,27 +715,23 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
         col_sum_all<R, 32>(ag);
         float gg = 0.f, gv = 0.f;
         if (M.res) {
-          gg = sigmoid_fast(pick<R>(ag, M.rho) + BIAS[D::b_g + l * 768 + n16]);
-          gv = gg;
-          if (n16 < kDec) {
-            gv = gg * HL[n16 * R + M.rho];
-            CIN[(kDec + n16) * R + M.rho] = gv;
+          gg = sigmoid_fast(pick<R>(ag, M.rho) + BIAS[D::b_g + l * 768 + n8 + (M.lane >> 5) * kDec]);
+          if (M.lane < 32) {
+            gv = gg * HL[n8 * R + M.rho];
+            CIN[(kDec + n8) * R + M.rho] = gv;
+            put_granule<R>(X, X3_G + (l - 1) * 512, n8, M.rho, gv);
           } else {
-            US[(n16 - kDec) * R + M.rho] = gg;
+            ukeep = gg;
           }
-          put_granule<R>(X, X3_G + (l - 1) * 512, n16, M.rho, gv);
         }
         tstamp(X);
-        gather<R, (512 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(
-            X, X3_G + (l - 1) * 512, 512, [&](int n) { return (n >> 4) == peer; },
-            [&](int n, int q, float v) {
-              const int i = n < kDec ? (l == 1 ? D::o_catd : D::o_catc) + (kDec + n) * R : D::o_us + (n - kDec) * R;
-              smem[i + q] = v;
-            });
+        gather<R, (256 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(
+            X, X3_G + (l - 1) * 512, 256, [&](int n) { return (n >> 3) == peer; },
+            [&](int n, int q, float v) { smem[(l == 1 ? D::o_catd : D::o_catc) + (kDec + n) * R + q] = v; });
         if (TR && M.res && rsel<R>(valid, M.rho)) {
           float* st = stash + (unsigned)(rsel<R>(brow, M.rho) * Td + t) * kStRec;
-          if (n16 < kDec) { st[kStR + l * kDec + n16] = gg; st[kStRH + l * kDec + n16] = gv; }
-          else st[kStU + l * kDec + n16 - kDec] = gg;
+          if (M.lane < 32) { st[kStR + l * kDec + n8] = gg; st[kStRH + l * kDec + n8] = gv; }
+          else st[kStU + l * kDec + n8] = gg;
         }
         tstamp(X);
         lds_barrier();
@@ -715,7 +757,7 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
         float cc = 0.f, hn = 0.f, yy = 0.f;
         if (L.res) {
           cc = tanh_fast(pick<R>(ac, L.rho) + BIAS[D::b_c + l * 768 + n8]);
-          const float u = US[n8 * R + L.rho];
+          const float u = ukeep;
           hn = u * HL[n8 * R + L.rho] + (1.f - u) * cc;
           if (l == 2) yy = XS[n8 * R + L.rho] + hn;
           put_granule<R>(X, X3_C + l * 256, n8, L.rho, hn);
@@ -769,10 +811,19 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
         }
       }
       tstamp(X);
-      gather<R, (NO * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(X, X3_O, NO, [&](int n) { return n / (NO / P3) == peer; }, oput);
-      if (has_next)
-        gather<R, (256 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(X, X3_P1, 256, [&](int n) { return (n >> 3) == peer; },
-                                                             [&](int n, int q, float v) { P1[n * R + q] = v; });
+      {
+        // one poll loop for both vectors of the round: columns [0, kAtt + R80) of [q | cell_output] and, behind them in the
+        // unit numbering, pre-net layer 1 (region X3_P1); the pad columns of round OUT are never needed
+        constexpr int NQ = kAtt + R80;
+        const int NG = has_next ? NQ + kPre1 : NQ;
+        gather2<R, ((NQ + kPre1) * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(
+            X, X3_O, NQ, X3_P1, NG,
+            [&](int n) { return n < NQ ? n / (NO / P3) == peer : ((n - NQ) >> 3) == peer; },
+            [&](int n, int q, float v) {
+              if (n < NQ) oput(n, q, v);
+              else smem[D::o_p1 + (n - NQ) * R + q] = v;
+            });
+      }
       if (O.res && rsel<R>(valid, O.rho)) {
         const unsigned bt = (unsigned)(rsel<R>(brow, O.rho) * Td + t);
         if (nO < kAtt) {
@@ -825,17 +876,21 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
           const int n = L.tid / R, q = L.tid - n * R;
           if (!rsel<R>(from_out, q)) U0[n * R + q] = p2t;
         }
-        tstamp(X);
-        gather<R, 1>(X, X3_P2, kPre2, [&](int n) { return (n >> 2) == peer; },
-                     [&](int n, int q, float v) {
-                       if (rsel<R>(from_out, q)) U0[n * R + q] = v;
-                     });
       }
-      // energies of every slot (the owner's own included: they are one L2 hit away)
-      gather<R, (TTP * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(
-          X, X3_E, TTP, [&](int n) { return false; },
-          [&](int n, int q, float v) { ES[q * TTP + n] = v; },
-          [&](int n, int q) { return n < rsel<R>(len, q); });   // nobody scores (or publishes) positions past text_length
+      tstamp(X);
+      // one poll loop: pre-net layer 2 of step t+1 (columns [0, 128)) and the energies of every slot behind them (the owner's
+      // own included: they are one L2 hit away).  Nobody scores -- or publishes -- positions past text_length.
+      gather2<R, ((kPre2 + TTP) * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(
+          X, X3_P2, kPre2, X3_E, kPre2 + TTP,
+          [&](int n) { return n < kPre2 && (!has_next || (n >> 2) == peer); },
+          [&](int n, int q, float v) {
+            if (n < kPre2) {
+              if (rsel<R>(from_out, q)) U0[n * R + q] = v;
+            } else {
+              ES[q * TTP + n - kPre2] = v;
+            }
+          },
+          [&](int n, int q) { return n < kPre2 || n - kPre2 < rsel<R>(len, q); });
       if (TR && has_next) {
         if (L.res && L.wave < 4 && rsel<R>(valid, L.rho) && rsel<R>(from_out, L.rho))
           stash[(unsigned)(rsel<R>(brow, L.rho) * Td + t + 1) * kStRec + kStP2 + n4] = y2;

@@ -94,7 +94,8 @@ struct WsLayout {
   int64_t bc_wxct, bc_wdx, bc_wmx;
   int64_t bc_fa, bc_wot, bc_g, bc_h1, bc_h2, bc_cq, bc_cp;   // decoder backward composites and small weight-gradient factors
   int64_t dattv;      // (B,256) per-row attention_v gradient partials
-  int64_t post_dpj1, post_dz1, post_dpool, post_dx;   // post-net backward operands that outlive cbhg_bwd (deferred weight gradients)
+  int64_t post_dpj1, post_dz1, post_dpool, post_dx;
+  int64_t enc_dpj1, enc_dz1, enc_dpool, enc_dx, pre_dz2, pre_dz1, pre_demb;   // likewise for the encoder CBHG / pre-net (side-stream weight gradients)   // post-net backward operands that outlive cbhg_bwd (deferred weight gradients)
   int64_t gA, gB, gC, gD, gE, gF, gG, scratch;
   int64_t total = 0;  // floats
   std::vector<TacoTensorInfo> rows;

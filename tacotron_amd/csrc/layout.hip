@@ -261,6 +261,15 @@ void build_ws_layout(const TacoShape& s, bool train, const TransLayout& T, WsLay
     W.post_dz1 = a.add("bwd.post.dz1", {M2, P.post.c1});
     W.post_dpool = a.add("bwd.post.dpool", {M2, P.post.K * kCb});
     W.post_dx = a.add("bwd.post.dx", {M2, kMel});
+    // encoder backward operands that outlive their stage: its weight-gradient GEMMs run on the side stream, beside the activation-
+    // gradient chain (model.hip), so the chain may not reuse their operands in place
+    W.enc_dpj1 = a.add("bwd.enc.dpj1", {M1, P.enc.c1});
+    W.enc_dz1 = a.add("bwd.enc.dz1", {M1, P.enc.c1});
+    W.enc_dpool = a.add("bwd.enc.dpool", {M1, P.enc.K * kCb});
+    W.enc_dx = a.add("bwd.enc.dx", {M1, kCb});
+    W.pre_dz2 = a.add("bwd.pre.dz2", {M1, kPre2});
+    W.pre_dz1 = a.add("bwd.pre.dz1", {M1, kPre1});
+    W.pre_demb = a.add("bwd.pre.demb", {M1, kEmbed});
     W.gA = a.add("bwd.gA", {Mx, 16 * kCb});
     W.gB = a.add("bwd.gB", {Mx, 16 * kCb});
     W.gC = a.add("bwd.gC", {Mx, 6 * kCb});
@@ -274,6 +283,7 @@ void build_ws_layout(const TacoShape& s, bool train, const TransLayout& T, WsLay
     W.bc_wxct = W.bc_wdx = W.bc_wmx = -1;
     W.bc_fa = W.bc_wot = W.bc_g = W.bc_h1 = W.bc_h2 = W.bc_cq = W.bc_cp = W.dattv = -1;
     W.post_dpj1 = W.post_dz1 = W.post_dpool = W.post_dx = -1;
+    W.enc_dpj1 = W.enc_dz1 = W.enc_dpool = W.enc_dx = W.pre_dz2 = W.pre_dz1 = W.pre_demb = -1;
     W.gA = W.gB = W.gC = W.gD = W.gE = W.gF = W.gG = W.scratch = -1;
   }
   W.total = (a.off + 63) / 64 * 64;

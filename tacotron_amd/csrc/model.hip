@@ -500,11 +500,37 @@ thread_local GemmTnBatch* g_tnq = nullptr;
 // later on the side stream, so that they run underneath the decoder BPTT kernel (which is latency bound and leaves the matrix
 // pipes and most issue slots of every CU idle; the GEMM workgroups co-reside with it -- tools/coresident_probe.py).
 thread_local std::vector<GemmTnArgs>* g_tn_defer = nullptr;
+// Side routing: while set, every weight-gradient launch issued for stream `s` goes to this stream instead, ordered behind the
+// work enqueued on `s` so far by an event.  The CBHG backward passes use it: their ~27 weight-gradient GEMMs (0.5 / 0.7 ms per
+// step) feed nothing but the gradient buffer, so they run beside the activation-gradient chain -- much of which is small
+// launches that leave most CUs idle -- instead of inside it.  Their operands then must not be reused in place by the chain
+// (BwdScratch::alt_*).  TACO_NO_SIDE_TN=1 keeps them on the main stream (A/B runs).
+thread_local hipStream_t g_tn_side = nullptr;
+thread_local hipEvent_t g_tn_ev = nullptr;
+int tn_route(hipStream_t s, hipStream_t* out) {
+  *out = s;
+  if (!g_tn_side || g_tn_side == s) return TACO_OK;
+  if (!g_tn_ev && hipEventCreateWithFlags(&g_tn_ev, hipEventDisableTiming) != hipSuccess) {
+    taco_set_error("weight-gradient side stream: cannot create an event");
+    return TACO_ELAUNCH;
+  }
+  if (hipEventRecord(g_tn_ev, s) != hipSuccess || hipStreamWaitEvent(g_tn_side, g_tn_ev, 0) != hipSuccess) {
+    taco_set_error("weight-gradient side stream: event record/wait failed");
+    return TACO_ELAUNCH;
+  }
+  *out = g_tn_side;
+  return TACO_OK;
+}
+int tn_launch_batch(GemmTnBatch& b, hipStream_t s) {
+  hipStream_t q;
+  TACO_TRY(tn_route(s, &q));
+  return launch_gemm_tn_batch(b, q);
+}
 struct TnGroup {
   GemmTnBatch batch;
   hipStream_t s;
   explicit TnGroup(hipStream_t stream) : s(stream) { g_tnq = &batch; }
-  int flush() { return batch.n ? launch_gemm_tn_batch(batch, s) : TACO_OK; }
+  int flush() { return batch.n ? tn_launch_batch(batch, s) : TACO_OK; }
   ~TnGroup() { g_tnq = nullptr; }
 };
 
@@ -520,11 +546,13 @@ int tn(const float* A, int lda, int K, const float* Y, int ldy, int N, float* W,
     return TACO_OK;
   }
   if (g_tnq) {
-    if (g_tnq->n == kMaxTnBatch) TACO_TRY(launch_gemm_tn_batch(*g_tnq, s));
+    if (g_tnq->n == kMaxTnBatch) TACO_TRY(tn_launch_batch(*g_tnq, s));
     g_tnq->p[g_tnq->n++] = a;
     return TACO_OK;
   }
-  return launch_gemm_tn(a, false, s);
+  hipStream_t q;
+  TACO_TRY(tn_route(s, &q));
+  return launch_gemm_tn(a, false, q);
 }
 
 // Builds every transposed / flipped weight copy the backward pass needs.
@@ -891,6 +919,7 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
   const int M1 = B * Tt, MD = B * Td, M2 = MD * r, F = Td * r;
   float* PT = ws + W.paramsT;
 
+  g_tn_side = nullptr;
   hipError_t e = hipMemsetAsync(G, 0, (size_t)PL.total * sizeof(float), s);
   if (e == hipSuccess)   // [d keys | E]: one (M1, 512) buffer, one fill
     e = hipMemsetAsync(ws + W.dkeys, 0, (size_t)M1 * 2 * kAtt * sizeof(float), s);
@@ -926,8 +955,15 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     dPostIn = ws + W.post_dx;
     g_tn_defer = &post_tn;
   }
+  const bool side_tn = side != s && !defer && getenv("TACO_NO_SIDE_TN") == nullptr;
+  if (side_tn) {
+    scp.alt_dpj1 = ws + W.post_dpj1; scp.alt_dz1 = ws + W.post_dz1; scp.alt_dpool = ws + W.post_dpool;
+    dPostIn = ws + W.post_dx;
+    g_tn_side = side;
+  }
   const int rc_post = cbhg_bwd(P, PT, G, PL.post, TL.post, seq2seq_output, dPostOut, B, F, pb, scp, dPostIn, s);
   g_tn_defer = nullptr;
+  g_tn_side = nullptr;
   TACO_TRY(rc_post);
   // d seq2seq_output = sign(s2s - mel) + post-net path
   float* dS2S = ws + W.ds2s_tot;
@@ -1111,21 +1147,35 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     eb.spk_e = ws + W.spk_e;
     eb.dspk_e = ws + W.dspk_e;
   }
-  TACO_TRY(cbhg_bwd(P, PT, G, PL.enc, TL.enc, ws + W.p2, dEnc, B, Tt, eb, sc, dP2, s));
+  BwdScratch sce = sc;
+  float *pre_dz2 = sc.gD, *pre_dz1 = sc.gE, *pre_demb = sc.gF;
+  if (side_tn && side_stream().side && !PL.enc.spk) {   // (speaker sites: their adapter gradients reuse ping-pong buffers)
+    // (the side stream is still busy with the decoder weight gradients forked above; the encoder's queue up behind them)
+    sce.alt_dpj1 = ws + W.enc_dpj1; sce.alt_dz1 = ws + W.enc_dz1; sce.alt_dpool = ws + W.enc_dpool;
+    dP2 = ws + W.enc_dx;
+    pre_dz2 = ws + W.pre_dz2; pre_dz1 = ws + W.pre_dz1; pre_demb = ws + W.pre_demb;
+    g_tn_side = side_stream().side;
+  }
+  int rc_enc = cbhg_bwd(P, PT, G, PL.enc, TL.enc, ws + W.p2, dEnc, B, Tt, eb, sce, dP2, s);
+  if (rc_enc != TACO_OK) {
+    g_tn_side = nullptr;
+    return rc_enc;
+  }
   if (PL.enc.spk) TACO_TRY(launch_embedding_bwd(ws + W.dspk_e, speaker, G + PL.spk_embed, B, shape->S, s, 16));
   // ---- encoder pre_net + embedding ----
-  float* dz2 = sc.gD;
+  float* dz2 = pre_dz2;
   TACO_TRY(launch_act_bwd(ws + W.p2, dP2, enc_keep2, dz2, (int64_t)M1 * kPre2, TACO_ACT_RELU, s));
   TACO_TRY(tn(ws + W.p1, kPre1, kPre1, dz2, kPre2, kPre2, G + PL.enc_pre2.w, kPre2, M1, M1, 0, s, 1, G + PL.enc_pre2.b));
-  float* dz1 = sc.gE;
+  float* dz1 = pre_dz1;
   TACO_TRY(launch_conv_gemm(dense_problem(dz2, kPre2, PT + TL.enc_pre2, kPre1, nullptr, dz1, kPre1, M1, kPre1, kPre2,
                                           TACO_ACT_NONE), s));
   TACO_TRY(launch_act_bwd(ws + W.p1, dz1, enc_keep1, dz1, (int64_t)M1 * kPre1, TACO_ACT_RELU, s));
   TACO_TRY(tn(ws + W.emb, kEmbed, kEmbed, dz1, kPre1, kPre1, G + PL.enc_pre1.w, kPre1, M1, M1, 0, s, 1, G + PL.enc_pre1.b));
-  float* dEmb = sc.gF;
+  float* dEmb = pre_demb;
   TACO_TRY(launch_conv_gemm(dense_problem(dz1, kPre1, PT + TL.enc_pre1, kEmbed, nullptr, dEmb, kEmbed, M1, kEmbed, kPre1,
                                           TACO_ACT_NONE), s));
   TACO_TRY(launch_embedding_bwd(dEmb, text, G + PL.emb, M1, shape->V, s));
+  g_tn_side = nullptr;
   TACO_TRY(side_join(s, side));
   return record_segment(0, s);
 }
