@@ -593,12 +593,17 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
   __syncthreads();
 
   // values parked one step ahead: teacher p2 and the dropout multipliers of the NEXT step's pre-net (result lanes only)
-  float p2n = 0.f, km1n = 1.f, km2n = 1.f;
+  float p2n = 0.f, km1n = 1.f, km2n = 1.f, frn = 0.f;
   auto park_next = [&](int tn) {
     p2n = 0.f;
     km1n = km2n = 1.f;
+    frn = 0.f;
     if (TR && tn < Td) {
       const Lane<R, 64> L;
+      if (a.prein && lead && L.tid < kMel * R) {   // teacher frame of step tn (the pre-net weight gradient reads a.prein for every step)
+        const int q = L.tid / kMel, i = L.tid - q * kMel;
+        frn = a.mel[(unsigned)(rsel<R>(brow, q) * Td + tn) * R80 + kMel * (RR - 1) + i];
+      }
       if (L.tid < kPre2 * R) {
         const int n = L.tid / R, q = L.tid - n * R;
         p2n = a.pre2[(unsigned)(rsel<R>(brow, q) * Td + tn) * ldp2 + n];
@@ -628,8 +633,10 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
       constexpr int q = decltype(Q)::value;
       from_out.template at<q>() = !TR || (a.sample && a.sample[(unsigned)(t * B + brow.template get<q>())]);
     });
-    const float p2t = p2n, km1t = km1n, km2t = km2n;   // step t+1's values, landed below in rounds OUT / E
-    park_next(t + 2);
+    // step t+1's parked values land below in rounds OUT / E.  The loads for step t+2 are issued right behind round E's polls:
+    // every poll waits for ALL earlier vector-memory operations of its wave (one in-order counter), and behind round E lie the
+    // softmax, a barrier and round G0's mat-vecs -- the longest poll-free stretch of a step -- for these HBM reads to land in
+    const float p2t = p2n, km1t = km1n, km2t = km2n, frt = frn;
 
     // ---- round G0: x = [p2 ; out'] Wx + al' VWx + bi ;  gates_1 = sigmoid([p2 ; out' ; h1] Wg0' + al' VWg + bg0') ----
     float ukeep = 0.f;   // update gate of the wave's unit, in the lanes (48 + rho) that finish its candidate column
@@ -897,12 +904,10 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
         // teacher frames of step t+1 for the pre-net weight gradient (model.hip reads a.prein for every step)
         if (a.prein && lead && L.tid < kMel * R) {
           const int q = L.tid / kMel, i = L.tid - q * kMel;
-          if (!rsel<R>(from_out, q) && rsel<R>(valid, q)) {
-            const unsigned bt1 = (unsigned)(rsel<R>(brow, q) * Td + t + 1);
-            a.prein[bt1 * kMel + i] = a.mel[bt1 * R80 + kMel * (RR - 1) + i];
-          }
+          if (!rsel<R>(from_out, q) && rsel<R>(valid, q)) a.prein[(unsigned)(rsel<R>(brow, q) * Td + t + 1) * kMel + i] = frt;
         }
       }
+      park_next(t + 2);
       tstamp(X);
     }
     lds_barrier();
@@ -1228,6 +1233,9 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
       gather<R, (TTP * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(
           X, Y3_DAL, TTP, [&](int n) { return false; }, [&](int n, int q, float v) { DES[q * TTP + n] = v; },
           [&](int n, int q) { return n < rsel<R>(len, q); });
+      // next processed step's inputs: issued HERE because every poll waits for all earlier vector-memory operations of its wave
+      // (one in-order counter), and the softmax / energy backward that follow are the longest poll-free stretch of a step
+      if (t > 0) prefetch(t - 1);
     }
     lds_barrier();
     // ---- 2. softmax backward: de = al * (dal - sum al dal)   (wave rho handles row rho) ----
@@ -1347,7 +1355,6 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
       }
       gather<R, (512 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(X, Y3_CG + 2 * 512, 512, [&](int n) { return ((n & 255) >> 3) == peer; }, cg_put(2));
     }
-    if (t > 0) prefetch(t - 1);   // (mid-step: these loads have six rounds to land)
     lds_barrier();
     // ---- 5. GRU layers, top down ----
 #pragma unroll
@@ -1506,6 +1513,10 @@ int launch_decoder3_bwd(DecBwdArgs a, hipStream_t s) {
   if (env && (atoi(env) == 0 || atoi(env) == 1)) return TACO_ENOTFOUND;   // TACO_DEC_V3=1: forward only (A/B runs)
   if (a.Tt > TTP || a.B > 32 || a.B < 1 || (a.r != 2 && a.r != 5)) return TACO_ENOTFOUND;
   if (!a.hoisted || a.trace) return TACO_ENOTFOUND;
+  // Opt-in data-parallel mode "collectives underneath the BPTT" (taco_dp_config overlap_bptt): a communication workgroup must
+  // fit on every CU beside the BPTT workgroup.  This kernel fills the CU (8 waves x ~220 VGPRs, ~110 KB LDS), decoder.hip's BPTT
+  // leaves the configured LDS reserve and half the register file: that mode takes decoder.hip.
+  if (taco_dp().overlap_bptt) return TACO_ENOTFOUND;
   const int R = a.B > 16 ? 4 : (a.B > 8 ? 2 : 1);
   const int ncl = (a.B + R - 1) / R;
   if ((int64_t)ncl * R * kX3Row * 8 + 1024 > decoder_xchg_bytes(a.B, a.Tt)) return TACO_ENOTFOUND;

@@ -130,8 +130,9 @@ def test_comm_standin_coresidency_with_decoder_bptt(built_lib):
     d = res['default: segment 2 announced after the BPTT kernel']
     assert d['bptt_ms'] <= 1.1 * solo
     assert d['spin_start_after_bwd_start_ms'] >= d['bptt_ms']          # its enqueue point lies behind the BPTT kernel
+    solo_ov = res['solo, overlap_bptt mode (decoder.hip BPTT kernel + 64 KB LDS reserve)']['bptt_ms']
     for k in ('overlap_bptt + 64 KB LDS reserve, stand-in behind the segment event',
               'overlap_bptt + 64 KB LDS reserve, stand-in dispatched first'):
         r = res[k]
-        assert r['bptt_ms'] <= 1.3 * solo, (k, r, solo)
+        assert r['bptt_ms'] <= 1.3 * solo_ov, (k, r, solo_ov)
         assert r['spin_ms'] <= 1.25 * r['spin_nominal_ms'], (k, r)

@@ -3,7 +3,9 @@ persistent decoder BPTT launch (256 workgroups x 512 threads, up to 158 KB LDS e
 round?  RCCL cannot run with one GPU, so an RCCL-footprint stand-in is used: 64 workgroups x 256 threads x 64 KB LDS spinning
 for a fixed time (taco_debug_spin).  Measured per mode (taco_dp_config) and per dispatch order:
 
-  bptt_ms      decoder_bwd_kernel launch -> end (HIP events on its stream; includes any wait for CUs)
+  bptt_ms      BPTT kernel launch -> end (HIP events on its stream; includes any wait for CUs).  Default mode: decoder3_bwd_kernel,
+               which fills every CU and therefore never runs beside a collective (segment 2 is announced after it); opt-in
+               overlap mode: decoder.hip's decoder_bwd_kernel, which leaves the LDS reserve and half the register file free
   spin_ms      stand-in enqueue-point -> end on the communication stream (nominal = its spin time; more = it waited for CUs)
   bwd_ms       whole taco_backward on the main stream
   err          decoder error words (exchange time-outs)
@@ -79,6 +81,7 @@ def measure(spin_us=2000, reps=3, verbose=True):
         return v[len(v) // 2] if v else None
 
     cases = [('solo', (0, 0), None, 0),
+             ('solo, overlap_bptt mode (decoder.hip BPTT kernel + 64 KB LDS reserve)', (1, 64), None, 0),
              ('default: segment 2 announced after the BPTT kernel', (0, 0), 'segment', spin_us),
              ('overlap_bptt + 64 KB LDS reserve, stand-in behind the segment event', (1, 64), 'segment', spin_us),
              ('overlap_bptt + 64 KB LDS reserve, stand-in dispatched first', (1, 64), 'first', 2 * spin_us),
