@@ -266,7 +266,11 @@ __device__ __forceinline__ XV<R> lds_rows(const float* xp) {
 // of a mat-vec to its head (KPL x R live registers; with the resident weights that spilled ~500 registers to scratch).
 template <int R, int KPL, int LPC>
 __device__ __forceinline__ void mv(const WReg<KPL>& r, const float* x, int lk, Acc<R>& a) {
+#ifdef TACO_MV_CH
+  constexpr int CH = TACO_MV_CH;
+#else
   constexpr int CH = R == 4 ? 2 : 4;
+#endif
   constexpr int NCH = (KPL + CH - 1) / CH;
   const float* xb = x + lk * R;
   XV<R> cur[CH], nxt[CH];
@@ -297,20 +301,43 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
   return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
-template <int LPC>
-__device__ __forceinline__ float col_sum(float v) {
-  v = dpp_add<0xb1>(v);          // quad_perm [1,0,3,2]
-  v = dpp_add<0x4e>(v);          // quad_perm [2,3,0,1]
-  v = dpp_add<0x124>(v);         // row_ror:4
-  v = dpp_add<0x128>(v);         // row_ror:8
-  if (LPC >= 32) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
-  if (LPC >= 64) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
-  return v;
-}
+// The R row sums of a column are independent chains: every DPP step is applied to all of them before the next step, so the
+// two wait states a DPP read needs behind the VALU write of its source are filled by the other rows instead of s_nops (the
+// cross-row steps are ONE asm statement per step for the same reason).
 template <int R, int LPC>
 __device__ __forceinline__ void col_sum_all(Acc<R>& a) {
 #pragma unroll
-  for (int q = 0; q < R; ++q) a.v[q] = col_sum<LPC>(a.v[q]);
+  for (int q = 0; q < R; ++q) a.v[q] = dpp_add<0xb1>(a.v[q]);    // quad_perm [1,0,3,2]
+#pragma unroll
+  for (int q = 0; q < R; ++q) a.v[q] = dpp_add<0x4e>(a.v[q]);    // quad_perm [2,3,0,1]
+#pragma unroll
+  for (int q = 0; q < R; ++q) a.v[q] = dpp_add<0x124>(a.v[q]);   // row_ror:4
+#pragma unroll
+  for (int q = 0; q < R; ++q) a.v[q] = dpp_add<0x128>(a.v[q]);   // row_ror:8
+  if constexpr (R == 4) {
+    float a0 = a.v[0], a1 = a.v[1], a2 = a.v[2], a3 = a.v[3];
+    if (LPC >= 32)
+      asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+    if (LPC >= 64)
+      asm volatile("s_nop 0\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+    a.v[0] = a0; a.v[1] = a1; a.v[2] = a2; a.v[3] = a3;
+  } else {
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      float v = a.v[q];
+      if (LPC >= 32) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
+      if (LPC >= 64) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
+      a.v[q] = v;
+    }
+  }
 }
 template <int R>
 __device__ __forceinline__ float pick(const Acc<R>& a, int rho) {
@@ -558,6 +585,15 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
 
   float* const H1 = U0 + KA * R;     // h of GRU-1 lives behind [p2 ; out]
   float* const stash = a.stash;
+  // Batch row this lane STORES for when it is the result lane (lane c*LPC + LPC-16 + rho) of a valid row, else -1; one value per
+  // column-group width.  Launch constants: three registers for the whole kernel instead of two select chains per store site.
+  int sb64, sb32, sbO;
+  {
+    const int r64 = lane - 48, r32 = (lane & 31) - 16, rO = (lane & (D::LPC_O - 1)) - (D::LPC_O - 16);
+    sb64 = (r64 >= 0 && r64 < R && rsel<R>(valid, r64)) ? rsel<R>(brow, r64) : -1;
+    sb32 = (r32 >= 0 && r32 < R && rsel<R>(valid, r32)) ? rsel<R>(brow, r32) : -1;
+    sbO = (rO >= 0 && rO < R && rsel<R>(valid, rO)) ? rsel<R>(brow, rO) : -1;
+  }
   const unsigned ldp2 = (unsigned)a.ldpre2;
 
   // ---- step 0 pre-net ----
@@ -695,9 +731,9 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
             if (n < 256) smem[D::o_xs + n * R + q] = v;
           });
       if (TR) {   // stash stores after the polls: they then fly under the next round instead of in front of this round's loads
-        if (L.res && rsel<R>(valid, L.rho)) stash[(unsigned)(rsel<R>(brow, L.rho) * Td + t) * kStRec + kStX + n8] = yx;
-        if (M.res && rsel<R>(valid, M.rho)) {
-          float* st = stash + (unsigned)(rsel<R>(brow, M.rho) * Td + t) * kStRec;
+        if (sb64 >= 0) stash[(unsigned)(sb64 * Td + t) * kStRec + kStX + n8] = yx;
+        if (sb32 >= 0) {
+          float* st = stash + (unsigned)(sb32 * Td + t) * kStRec;
           if (M.lane < 32) { st[kStR + n8] = gg; st[kStRH + n8] = gv; }
           else st[kStU + n8] = gg;
         }
@@ -735,8 +771,8 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
         gather<R, (256 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(
             X, X3_G + (l - 1) * 512, 256, [&](int n) { return (n >> 3) == peer; },
             [&](int n, int q, float v) { smem[(l == 1 ? D::o_catd : D::o_catc) + (kDec + n) * R + q] = v; });
-        if (TR && M.res && rsel<R>(valid, M.rho)) {
-          float* st = stash + (unsigned)(rsel<R>(brow, M.rho) * Td + t) * kStRec;
+        if (TR && sb32 >= 0) {
+          float* st = stash + (unsigned)(sb32 * Td + t) * kStRec;
           if (M.lane < 32) { st[kStR + l * kDec + n8] = gg; st[kStRH + l * kDec + n8] = gv; }
           else st[kStU + l * kDec + n8] = gg;
         }
@@ -772,8 +808,8 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
         }
         tstamp(X);
         gather<R, (256 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(X, X3_C + l * 256, 256, [&](int n) { return (n >> 3) == peer; }, hput);
-        if (TR && L.res && rsel<R>(valid, L.rho)) {
-          float* st = stash + (unsigned)(rsel<R>(brow, L.rho) * Td + t) * kStRec;
+        if (TR && sb64 >= 0) {
+          float* st = stash + (unsigned)(sb64 * Td + t) * kStRec;
           st[kStC + l * kDec + n8] = cc;
           st[kStH + l * kDec + n8] = hn;
           if (l == 2) st[kStY + n8] = yy;
@@ -831,8 +867,8 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
               else smem[D::o_p1 + (n - NQ) * R + q] = v;
             });
       }
-      if (O.res && rsel<R>(valid, O.rho)) {
-        const unsigned bt = (unsigned)(rsel<R>(brow, O.rho) * Td + t);
+      if (sbO >= 0) {
+        const unsigned bt = (unsigned)(sbO * Td + t);
         if (nO < kAtt) {
           if (TR) stash[bt * kStRec + kStQ + nO] = yo;
         } else if (nO < kAtt + R80) {
@@ -841,8 +877,8 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
           if (TR && a.prein && has_next && rsel<R>(from_out, O.rho) && c >= kMel * (RR - 1)) a.prein[(bt + 1) * kMel + c - kMel * (RR - 1)] = yo;
         }
       }
-      if (TR && has_next && L.res && rsel<R>(valid, L.rho) && rsel<R>(from_out, L.rho))
-        stash[(unsigned)(rsel<R>(brow, L.rho) * Td + t + 1) * kStRec + kStP1 + n8] = yp;   // record of step t+1
+      if (TR && has_next && sb64 >= 0 && rsel<R>(from_out, L.rho))
+        stash[(unsigned)(sb64 * Td + t + 1) * kStRec + kStP1 + n8] = yp;   // record of step t+1
       tstamp(X);
     }
     lds_barrier();
@@ -867,6 +903,7 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
           }
         }
       }
+      tstamp(X);   // E: energies computed + published
       float y2 = 0.f;
       if (has_next) {
         Acc<R> ap;
@@ -899,8 +936,8 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
           },
           [&](int n, int q) { return n < kPre2 || n - kPre2 < rsel<R>(len, q); });
       if (TR && has_next) {
-        if (L.res && L.wave < 4 && rsel<R>(valid, L.rho) && rsel<R>(from_out, L.rho))
-          stash[(unsigned)(rsel<R>(brow, L.rho) * Td + t + 1) * kStRec + kStP2 + n4] = y2;
+        if (sb64 >= 0 && L.wave < 4 && rsel<R>(from_out, L.rho))
+          stash[(unsigned)(sb64 * Td + t + 1) * kStRec + kStP2 + n4] = y2;
         // teacher frames of step t+1 for the pre-net weight gradient (model.hip reads a.prein for every step)
         if (a.prein && lead && L.tid < kMel * R) {
           const int q = L.tid / kMel, i = L.tid - q * kMel;
@@ -1129,6 +1166,14 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
 
   const float km1c = a.keep1 ? 2.f : 1.f, km2c = a.keep2 ? 2.f : 1.f;
   const float* const stash = a.stash;
+  // batch row this lane stores for as a result lane of a valid row (see the forward kernel), else -1
+  int sb64, sb32, sbq;
+  {
+    const int r64 = lane - 48, r32 = (lane & 31) - 16;
+    sb64 = (r64 >= 0 && r64 < R && rsel<R>(valid, r64)) ? rsel<R>(brow, r64) : -1;
+    sb32 = (r32 >= 0 && r32 < R && rsel<R>(valid, r32)) ? rsel<R>(brow, r32) : -1;
+    sbq = (lane < R && rsel<R>(valid, lane)) ? rsel<R>(brow, lane) : -1;
+  }
   float* const gst = a.gstash;
   auto own = [&](int slot, int wv, int rho) -> float& { return OWN[(slot * 8 + wv) * R + rho]; };
 
@@ -1312,8 +1357,8 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
       }
       gather<R, (256 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(X, Y3_DQ, 256, [&](int n) { return (n >> 3) == peer; },
                                                            [&](int n, int q, float v) { VO[(R80 + n) * R + q] = v; });
-      if (L.lane < R && rsel<R>(valid, L.lane)) gst[(unsigned)(rsel<R>(brow, L.lane) * Td + t) * kGsRec + kGsQ + u] = pick<R>(dq, L.lane);
-      if (L.res && rsel<R>(valid, L.rho)) gst[(unsigned)(rsel<R>(brow, L.rho) * Td + t) * kGsRec + kGsP1S + u] = g1;
+      if (sbq >= 0) gst[(unsigned)(sbq * Td + t) * kGsRec + kGsQ + u] = pick<R>(dq, L.lane);
+      if (sb64 >= 0) gst[(unsigned)(sb64 * Td + t) * kGsRec + kGsP1S + u] = g1;
     }
     lds_barrier();
     // ---- 4. round OUT: dy = [d out ; dq ; d p1] . wot + dx_{t+1} . wdx ; owner: dht_3, (dcp, dup) of GRU-3 ----
@@ -1350,8 +1395,7 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
       if (L.res) {
         const float dy = pick<R>(ao, L.rho);
         own(D::w_dy, L.wave, L.rho) = dy;
-        gru_elem(2, L.wave, L.rho, own(D::w_dh + 2, L.wave, L.rho) + dy, u, (unsigned)(rsel<R>(brow, L.rho) * Td + t) * kGsRec,
-                 rsel<R>(valid, L.rho) != 0);
+        gru_elem(2, L.wave, L.rho, own(D::w_dh + 2, L.wave, L.rho) + dy, u, (unsigned)(sb64 * Td + t) * kGsRec, sb64 >= 0);
       }
       gather<R, (512 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(X, Y3_CG + 2 * 512, 512, [&](int n) { return ((n & 255) >> 3) == peer; }, cg_put(2));
     }
@@ -1383,7 +1427,7 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
         }
         gather<R, (256 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(X, Y3_GR + l * 256, 256, [&](int n) { return (n >> 3) == peer; },
                                                              [&](int n, int q, float v) { smem[o_dgp + n * R + q] = v; });
-        if (M.res && M.lane >= 32 && rsel<R>(valid, M.rho)) gst[(unsigned)(rsel<R>(brow, M.rho) * Td + t) * kGsRec + kGsG + l * 512 + u] = gr;
+        if (sb32 >= 0 && M.lane >= 32) gst[(unsigned)(sb32 * Td + t) * kGsRec + kGsG + l * 512 + u] = gr;
       }
       lds_barrier();
       {   // G_l: [d inp ; d h] += dgp . Wg^T
@@ -1396,8 +1440,8 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
         float dxv = 0.f;
         if (M.res) {
           const float y = pick<R>(ag, M.rho);
-          const unsigned gsb = (unsigned)(rsel<R>(brow, M.rho) * Td + t) * kGsRec;
-          const bool vld = rsel<R>(valid, M.rho) != 0;
+          const unsigned gsb = (unsigned)(sb32 * Td + t) * kGsRec;
+          const bool vld = sb32 >= 0;
           if (M.lane < 32) {
             const float di = own(D::w_dinp, M.wave, M.rho) + y;
             if (l > 0) {
@@ -1421,7 +1465,7 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
                                                                  VO[(R80 + 2 * kAtt + n) * R + q] = v;
                                                                  DXR[q * kDec + n] = v;
                                                                });
-          if (M.res && M.lane < 32 && rsel<R>(valid, M.rho)) gst[(unsigned)(rsel<R>(brow, M.rho) * Td + t) * kGsRec + kGsX + u] = dxv;
+          if (sb32 >= 0 && M.lane < 32) gst[(unsigned)(sb32 * Td + t) * kGsRec + kGsX + u] = dxv;
         }
       }
       lds_barrier();
