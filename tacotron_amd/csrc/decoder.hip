@@ -1455,7 +1455,7 @@ int launch_decoder_bwd(DecBwdArgs a, hipStream_t s) {
   a.P = pick_cluster(kern, smem, a.B, env_cluster(8));
   g_last_cluster[1] = a.P;
   a.fakew = probe_bits();
-  if (a.P > 1) {
+  if (a.P > 1 && !a.xchg_zeroed) {
     hipError_t e = hipMemsetAsync(a.xchg, 0, (size_t)decoder_xchg_bytes(a.B, a.Tt), s);
     if (e != hipSuccess) {
       taco_set_error("decoder_bwd: memset: %s", hipGetErrorString(e));

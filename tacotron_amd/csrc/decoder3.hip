@@ -491,6 +491,9 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
     X.fast = sflag[0] != 0 && a.fast_ok;
     __syncthreads();
     if (cl >= ncl_used) return;
+    // placement census (diagnostic; Tacotron.placement_census()): workgroups whose cluster exchanges through its XCD's L2 (word 4)
+    // vs. at agent scope because the cluster straddles XCDs or TACO_DEC_V3_AGENT is set (word 5)
+    if (tid == 0) atomicAdd(a.err + 4 + (X.fast ? 0 : 1), 1);
   }
   X.err = a.err;
   X.dead = dead;
@@ -1542,7 +1545,7 @@ int launch3b(DecBwdArgs& a, hipStream_t s) {
   if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, NT, smem);
   if (e != hipSuccess || (int64_t)cus * per_cu < (int64_t)8 * P3) return TACO_ENOTFOUND;
-  e = hipMemsetAsync(a.xchg, 0, (size_t)decoder_xchg_bytes(a.B, a.Tt), s);
+  if (!a.xchg_zeroed) e = hipMemsetAsync(a.xchg, 0, (size_t)decoder_xchg_bytes(a.B, a.Tt), s);
   if (e != hipSuccess) {
     taco_set_error("decoder3_bwd: memset: %s", hipGetErrorString(e));
     return TACO_ELAUNCH;

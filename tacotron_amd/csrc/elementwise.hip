@@ -745,3 +745,44 @@ int launch_spin(int blocks, int threads, int lds_bytes, int usec, hipStream_t s)
   TACO_LAUNCH_CHECK("debug_spin");
   return TACO_OK;
 }
+
+// ---- batched zero-fill / copy (InitBatch, kernels.h) ----
+__global__ __launch_bounds__(256) void init_batch_kernel(InitBatch b) {
+  int ji = 0;
+#pragma unroll 1
+  for (int i = 1; i < b.n; ++i)
+    if ((int)blockIdx.x >= b.j[i].blk0) ji = i;
+  const InitJob& q = b.j[ji];
+  const int nb = (ji + 1 < b.n ? b.j[ji + 1].blk0 : (int)gridDim.x) - q.blk0;
+  const int64_t total = (int64_t)q.rows * q.cols;
+  const bool vec = (q.cols % 4 == 0) && (q.ldd % 4 == 0) && (q.lds % 4 == 0) && ((reinterpret_cast<uintptr_t>(q.dst) & 15) == 0) &&
+                   (q.src == nullptr || (reinterpret_cast<uintptr_t>(q.src) & 15) == 0);
+  if (vec) {
+    const int64_t c4 = q.cols / 4, n4 = total / 4;
+    for (int64_t i = (int64_t)(blockIdx.x - q.blk0) * 256 + threadIdx.x; i < n4; i += (int64_t)nb * 256) {
+      const int64_t r = i / c4, c = (i - r * c4) * 4;
+      const float4 v = q.src ? *reinterpret_cast<const float4*>(q.src + r * q.lds + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(q.dst + r * q.ldd + c) = v;
+    }
+  } else {
+    for (int64_t i = (int64_t)(blockIdx.x - q.blk0) * 256 + threadIdx.x; i < total; i += (int64_t)nb * 256) {
+      const int64_t r = i / q.cols, c = i - r * q.cols;
+      q.dst[r * q.ldd + c] = q.src ? q.src[r * q.lds + c] : 0.f;
+    }
+  }
+}
+int launch_init_batch(InitBatch& b, hipStream_t s) {
+  if (b.n == 0) return TACO_OK;
+  int blocks = 0;
+  for (int i = 0; i < b.n; ++i) {
+    b.j[i].blk0 = blocks;
+    const int64_t total = (int64_t)b.j[i].rows * b.j[i].cols;
+    int64_t nb = (total + 256 * 16 - 1) / (256 * 16);      // 16 floats (4 float4) per thread at most
+    nb = nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
+    blocks += (int)nb;
+  }
+  hipLaunchKernelGGL(init_batch_kernel, dim3(blocks), dim3(256), 0, s, b);
+  TACO_LAUNCH_CHECK("init_batch");
+  b.n = 0;
+  return TACO_OK;
+}

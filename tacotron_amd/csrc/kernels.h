@@ -146,7 +146,34 @@ int launch_sumsq(const float* x, int64_t n, float* out, hipStream_t s);  // out[
 int launch_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float cap, int64_t step,
                      const float* sumsq, float* gnorm_out, const int32_t* err, hipStream_t s);
 int launch_bernoulli(uint8_t* out, int64_t n, float p_one, uint64_t seed, hipStream_t s);
-int launch_spin(int blocks, int threads, int lds_bytes, int usec, hipStream_t s);   // communication-kernel stand-in (tests)
+int launch_spin(int blocks, int threads, int lds_bytes, int usec, hipStream_t s);
+// Batched buffer initialisation: up to kMaxInitJobs zero-fills / (strided) copies of fp32 blocks in ONE launch instead of one
+// runtime memset / memcpy launch each (~5 us apiece, serialised on their stream).  Jobs of a batch must not overlap.
+constexpr int kMaxInitJobs = 16;
+struct InitJob {
+  float* dst = nullptr;
+  const float* src = nullptr;   // null: fill with zeros
+  int rows = 1;
+  int64_t cols = 0;             // floats per row
+  int64_t ldd = 0, lds = 0;     // row pitches (floats)
+  int blk0 = 0;                 // first block of the job (filled by the launcher)
+};
+struct InitBatch {
+  InitJob j[kMaxInitJobs];
+  int n = 0;
+  int fill(float* dst, int64_t floats) { return fill2d(dst, 1, floats, floats); }
+  int fill2d(float* dst, int rows, int64_t cols, int64_t ldd) { return add(dst, nullptr, rows, cols, ldd, 0); }
+  int copy(float* dst, const float* src, int64_t floats) { return add(dst, src, 1, floats, floats, floats); }
+  int copy2d(float* dst, int64_t ldd, const float* src, int64_t lds, int rows, int64_t cols) { return add(dst, src, rows, cols, ldd, lds); }
+  int add(float* dst, const float* src, int rows, int64_t cols, int64_t ldd, int64_t lds) {
+    if (n >= kMaxInitJobs) return TACO_EINVAL;
+    if (rows <= 0 || cols <= 0) return TACO_OK;
+    InitJob& q = j[n++];
+    q.dst = dst; q.src = src; q.rows = rows; q.cols = cols; q.ldd = ldd; q.lds = lds;
+    return TACO_OK;
+  }
+};
+int launch_init_batch(InitBatch& b, hipStream_t s);   // communication-kernel stand-in (tests)
 
 // ---------------------------------------------------------------- data-parallel options (model.hip, taco_dp_config)
 // overlap_bptt: segment 2's all-reduce may start BEFORE the decoder BPTT kernel (else: after it); lds_reserve_bytes: LDS every
@@ -301,6 +328,7 @@ struct DecBwdArgs {
   int fakew = 0;
   int lres0 = 0, lres1 = 0;  // launch-resident weight rows (LDS) of the GRU-3 / GRU-2 gate mat-vecs; chosen by launch_decoder_bwd
   int xcc_table_ofs = 0, fast_ok = 1;   // decoder3.hip (see DecFwdArgs)
+  int xchg_zeroed = 0;       // 1: the caller has zeroed the exchange area on this stream already (taco_backward's batched init launch)
   int hoisted = 0;           // 1: the pre-net gradients of the teacher-forced steps are formed after the launch (model.hip); the kernel
                              //    runs the pre-net backward only where a step was fed by the previous output
 };

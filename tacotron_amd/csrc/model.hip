@@ -302,7 +302,7 @@ int side_join(hipStream_t s, hipStream_t side) {
 // linear maps follow each other (attention layer -> input projection -> GRU-1 gates; output projection -> query layer /
 // next step's pre_net) their product is formed here once per call, so that the persistent kernel needs one exchange
 // round for the pair instead of two (decoder.hip).  ~0.4 GFLOP per call, two batched launches.
-int build_dec_composites(const float* P, const ParamLayout& PL, const WsLayout& W, float* ws, int r, hipStream_t s) {
+int build_dec_composites(const float* P, const ParamLayout& PL, const WsLayout& W, float* ws, int r, InitBatch& ib, hipStream_t s) {
   const int R80 = kMel * r, KX = kPre2 + R80 + kAtt, NO = dec_out_cols(r);
   const float* Wi = P + PL.in_proj.w;    // (128 + 256, 256)
   const float* Wa = P + PL.att_w;        // (80r + 256, 256)
@@ -318,14 +318,16 @@ int build_dec_composites(const float* P, const ParamLayout& PL, const WsLayout& 
     }
     return TACO_OK;
   };
-  const auto D2D = hipMemcpyDeviceToDevice;
-  TACO_TRY(chk(hipMemcpyAsync(wx, Wi, sizeof(float) * kPre2 * kDec, D2D, s)));
   const int KA = kPre2 + R80;   // wg0 rows: [0,KA) p2 and out, [KA,KA+256) h1 (= Wg0_h), [KA+256,KA+512) ctx (only used to form VWg)
-  TACO_TRY(chk(hipMemcpyAsync(wg0 + (int64_t)KA * 2 * kDec, Wg0 + (int64_t)kDec * 2 * kDec, sizeof(float) * kDec * 2 * kDec, D2D, s)));
-  TACO_TRY(chk(hipMemsetAsync(wo, 0, sizeof(float) * kDec * NO, s)));
-  TACO_TRY(chk(hipMemsetAsync(bo, 0, sizeof(float) * NO, s)));
-  TACO_TRY(chk(hipMemcpy2DAsync(wo + kAtt, NO * sizeof(float), Wo, R80 * sizeof(float), R80 * sizeof(float), kDec, D2D, s)));
-  TACO_TRY(chk(hipMemcpyAsync(bo + kAtt, P + PL.out_proj.b, sizeof(float) * R80, D2D, s)));
+  (void)chk;
+  // copies / zero pads of the composites: jobs of the caller's batched init launch (one kernel instead of six runtime launches)
+  TACO_TRY(ib.copy(wx, Wi, (int64_t)kPre2 * kDec));
+  TACO_TRY(ib.copy(wg0 + (int64_t)KA * 2 * kDec, Wg0 + (int64_t)kDec * 2 * kDec, (int64_t)kDec * 2 * kDec));
+  TACO_TRY(ib.fill2d(wo + kAtt + R80, kDec, NO - kAtt - R80, NO));            // pad columns of [Wo Wq | Wo | 0]
+  TACO_TRY(ib.fill(bo + kAtt + R80, NO - kAtt - R80));
+  TACO_TRY(ib.copy2d(wo + kAtt, NO, Wo, R80, kDec, R80));
+  TACO_TRY(ib.copy(bo + kAtt, P + PL.out_proj.b, R80));
+  TACO_TRY(launch_init_batch(ib, s));
   {
     ConvGemmBatch b1;
     b1.n = 5;
@@ -369,17 +371,17 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
   const int M1 = B * Tt, M2 = B * Td * r;
   // decoder composites depend on the parameters only: side stream, concurrent with the encoder
   hipStream_t sd = side_fork(s);
-  {
-    // post/dense (256, 1025) kernel -> pitch 1028 so the W tile loads are 16-byte aligned float4 (pad columns are never
-    // stored); depends on the parameters only, so it rides on the side stream too
-    hipError_t e = hipMemcpy2DAsync(ws + W.wd_pad, 1028 * sizeof(float), P + PL.post_dense.w, kFft * sizeof(float),
-                                    kFft * sizeof(float), 2 * kCb, hipMemcpyDeviceToDevice, sd);
-    if (e != hipSuccess) {
-      taco_set_error("forward: memcpy2D: %s", hipGetErrorString(e));
-      return TACO_ELAUNCH;
-    }
+  // ONE batched init launch for everything that is a plain copy / zero pad of parameters (side stream, first thing on it):
+  //   post/dense (256, 1025) kernel -> pitch 1028 so the W tile loads are 16-byte aligned float4 (pad columns are never stored);
+  //   the copied / zero-padded parts of the decoder composites; the pad rows / columns of two transposed backward operands
+  InitBatch ib;
+  TACO_TRY(ib.copy2d(ws + W.wd_pad, 1028, P + PL.post_dense.w, kFft, 2 * kCb, kFft));
+  if (train) {
+    TACO_TRY(ib.fill(ws + W.paramsT + L.T.post_dense + (int64_t)kFft * 2 * kCb, 3 * 2 * kCb));
+    const int NF = dec_fan_cols(r);
+    TACO_TRY(ib.fill2d(ws + W.bc_fa + R80, kDec, NF - R80, NF));
   }
-  TACO_TRY(build_dec_composites(P, PL, W, ws, r, sd));
+  TACO_TRY(build_dec_composites(P, PL, W, ws, r, ib, sd));
   if (train) {
     // everything the backward pass derives from the parameters alone (transposed / tap-flipped weight copies, transposed
     // composites) is built here, beside the encoder, instead of at the head of taco_backward's critical path
@@ -612,11 +614,7 @@ int prepare_transposes(const float* P, const ParamLayout& L, const TransLayout& 
   TACO_TRY(tr(L.q_w, T.q_w, 1, R80, kAtt));
   TACO_TRY(tr(L.att_w, T.att_w, 1, R80 + kAtt, kAtt));
   TACO_TRY(tr(L.post_dense.w, T.post_dense, 1, 2 * kCb, kFft));
-  hipError_t e = hipMemsetAsync(PT + T.post_dense + (int64_t)kFft * 2 * kCb, 0, (size_t)3 * 2 * kCb * sizeof(float), s);
-  if (e != hipSuccess) {
-    taco_set_error("prepare_transposes: memset: %s", hipGetErrorString(e));
-    return TACO_ELAUNCH;
-  }
+  // (the three zero pad rows behind the transposed post/dense kernel are written by forward_impl's batched init launch)
   return launch_transpose_batch(tb, s);
 }
 
@@ -625,11 +623,7 @@ int prepare_transposes(const float* P, const ParamLayout& L, const TransLayout& 
 int build_dec_composites_bwd(const float* P, const ParamLayout& PL, const WsLayout& W, float* ws, int r, hipStream_t s) {
   const int R80 = kMel * r, NO = dec_fan_cols(r);
   float *fa = ws + W.bc_fa, *wot = ws + W.bc_wot;
-  hipError_t e = hipMemsetAsync(fa, 0, sizeof(float) * kDec * NO, s);
-  if (e != hipSuccess) {
-    taco_set_error("build_dec_composites_bwd: memset: %s", hipGetErrorString(e));
-    return TACO_ELAUNCH;
-  }
+  // (fa's pad columns [80r, NO) are zeroed by forward_impl's batched init launch; columns [0, 80r) are written below)
   TransposeBatch tb;
   auto job = [&](const float* in, int ldi, float* out, int ldo, int K, int N) {
     TransposeJob& j = tb.j[tb.n++];
@@ -652,6 +646,7 @@ struct BwdScratch {
   // When the weight-gradient GEMMs are deferred their operands must outlive the rest of cbhg_bwd: these three buffers then
   // replace the in-place reuse of gD / gC / gA (d pj1, d z1, d pool); null = reuse as before.
   float *alt_dpj1 = nullptr, *alt_dz1 = nullptr, *alt_dpool = nullptr;
+  bool dx_zeroed = false;   // dx_out was zeroed by the caller (taco_backward's batched init launch)
 };
 
 // CBHG backward.  dOut (M,256) -> dX (M,cin) written to `dx_out`; parameter gradients accumulated into G.
@@ -796,10 +791,12 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
   // ---- conv bank: weight/bias grads per width; input grad = residual path + sum over widths, accumulated with fp32
   //      atomics by ONE batched launch (all K transposed convolutions run concurrently instead of as a dependent chain) ----
   {
-    hipError_t e = hipMemsetAsync(dx_out, 0, (size_t)M * c.cin * sizeof(float), s);
-    if (e != hipSuccess) {
-      taco_set_error("cbhg_bwd: memset: %s", hipGetErrorString(e));
-      return TACO_ELAUNCH;
+    if (!sc.dx_zeroed) {
+      hipError_t e = hipMemsetAsync(dx_out, 0, (size_t)M * c.cin * sizeof(float), s);
+      if (e != hipSuccess) {
+        taco_set_error("cbhg_bwd: memset: %s", hipGetErrorString(e));
+        return TACO_ELAUNCH;
+      }
     }
     ConvGemmBatch batch;
     batch.n = c.K;
@@ -920,12 +917,22 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
   float* PT = ws + W.paramsT;
 
   g_tn_side = nullptr;
-  hipError_t e = hipMemsetAsync(G, 0, (size_t)PL.total * sizeof(float), s);
-  if (e == hipSuccess)   // [d keys | E]: one (M1, 512) buffer, one fill
-    e = hipMemsetAsync(ws + W.dkeys, 0, (size_t)M1 * 2 * kAtt * sizeof(float), s);
-  if (e != hipSuccess) {
-    taco_set_error("taco_backward: memset: %s", hipGetErrorString(e));
-    return TACO_ELAUNCH;
+  // ONE batched init launch for every accumulator of the pass: the gradient buffer, [d keys | E] (one (M1, 512) buffer), the small
+  // decoder weight-gradient factors, the two CBHG input-gradient accumulators (when they have buffers of their own) and the
+  // decoder exchange area (the forward kernel is long done with it)
+  const bool own_dx = getenv("TACO_NO_SIDE_TN") == nullptr && getenv("TACO_DEFER_POST_TN") == nullptr && !side_stream().off &&
+                      side_stream().side != nullptr;
+  {
+    InitBatch ib;
+    TACO_TRY(ib.fill(G, PL.total));
+    TACO_TRY(ib.fill(ws + W.dkeys, (int64_t)M1 * 2 * kAtt));
+    TACO_TRY(ib.fill(ws + W.bc_g, W.bc_cp + kPre1 - W.bc_g));
+    TACO_TRY(ib.fill(ws + W.xchg, decoder_xchg_bytes(B, Tt) / 4));
+    if (own_dx) {
+      TACO_TRY(ib.fill(ws + W.post_dx, (int64_t)M2 * kMel));
+      if (!PL.enc.spk) TACO_TRY(ib.fill(ws + W.enc_dx, (int64_t)M1 * kCb));
+    }
+    TACO_TRY(launch_init_batch(ib, s));
   }
   // (the transposed weights PT and the transposed decoder composites were built by taco_forward on this workspace)
   BwdScratch sc{ws + W.gA, ws + W.gB, ws + W.gC, ws + W.gD, ws + W.gE, ws + W.gF, ws + W.gG};
@@ -959,6 +966,7 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
   if (side_tn) {
     scp.alt_dpj1 = ws + W.post_dpj1; scp.alt_dz1 = ws + W.post_dz1; scp.alt_dpool = ws + W.post_dpool;
     dPostIn = ws + W.post_dx;
+    scp.dx_zeroed = own_dx;
     g_tn_side = side;
   }
   const int rc_post = cbhg_bwd(P, PT, G, PL.post, TL.post, seq2seq_output, dPostOut, B, F, pb, scp, dPostIn, s);
@@ -999,13 +1007,6 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
   }
 
   // ---- decoder BPTT ----
-  {
-    hipError_t e2 = hipMemsetAsync(ws + W.bc_g, 0, sizeof(float) * (size_t)(W.bc_cp + kPre1 - W.bc_g), s);
-    if (e2 != hipSuccess) {
-      taco_set_error("taco_backward: memset: %s", hipGetErrorString(e2));
-      return TACO_ELAUNCH;
-    }
-  }
   float* gs = ws + W.gstash;
   const float* st = ws + W.stash;
   {
@@ -1027,6 +1028,7 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     a.xchg = ws + W.xchg; a.err = reinterpret_cast<int*>(ws + W.err) + 1;
     a.trace = getenv("TACO_DEC_TRACE") ? reinterpret_cast<long long*>(ws + W.err + 16) + 128 : nullptr;
     a.B = B; a.Tt = Tt; a.Td = Td; a.r = r; a.P = 1;
+    a.xchg_zeroed = 1;
     const int slot = prof_begin(1, s);
     int rc = launch_decoder3_bwd(a, s);
     if (rc == TACO_ENOTFOUND) rc = launch_decoder_bwd(a, s);
@@ -1153,6 +1155,7 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     // (the side stream is still busy with the decoder weight gradients forked above; the encoder's queue up behind them)
     sce.alt_dpj1 = ws + W.enc_dpj1; sce.alt_dz1 = ws + W.enc_dz1; sce.alt_dpool = ws + W.enc_dpool;
     dP2 = ws + W.enc_dx;
+    sce.dx_zeroed = own_dx;
     pre_dz2 = ws + W.pre_dz2; pre_dz1 = ws + W.pre_dz1; pre_demb = ws + W.pre_demb;
     g_tn_side = side_stream().side;
   }

@@ -163,8 +163,10 @@ class Tacotron(object):
                                 'skipped while the flag was set' % (flags[0], flags[1]))
 
     def placement_census(self):
-        """Diagnostic: histogram of (blockIdx - XCD id) mod 8 over the decoder-forward workgroups launched since the last
-        clear_error().  One non-zero bin = the fast placement (one weight slice per XCD L2); host synchronisation."""
+        """Diagnostic, accumulated over the decoder-forward launches since the last clear_error(); host synchronisation.
+        decoder3.hip (cluster width 32): [workgroups whose cluster exchanges through its XCD's L2, workgroups of clusters that
+        straddle XCDs (or TACO_DEC_V3_AGENT=1) and exchange at agent scope, 0, ...] -- the second number should be 0.
+        decoder.hip (cluster width <= 16): histogram of (blockIdx - XCD id) mod 8; one non-zero bin = the fast placement."""
         return self._census.tolist()
 
     @property
