@@ -587,7 +587,13 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
   __syncthreads();
 
   float* const H1 = U0 + KA * R;     // h of GRU-1 lives behind [p2 ; out]
+#ifdef TACO_P_NOSTASH
   float* const stash = a.stash;
+  const bool kNoStash = true;
+#else
+  float* const stash = a.stash;
+  const bool kNoStash = false;
+#endif
   // Batch row this lane STORES for when it is the result lane (lane c*LPC + LPC-16 + rho) of a valid row, else -1; one value per
   // column-group width.  Launch constants: three registers for the whole kernel instead of two select chains per store site.
   int sb64, sb32, sbO;
@@ -596,6 +602,7 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
     sb64 = (r64 >= 0 && r64 < R && rsel<R>(valid, r64)) ? rsel<R>(brow, r64) : -1;
     sb32 = (r32 >= 0 && r32 < R && rsel<R>(valid, r32)) ? rsel<R>(brow, r32) : -1;
     sbO = (rO >= 0 && rO < R && rsel<R>(valid, rO)) ? rsel<R>(brow, rO) : -1;
+    if (kNoStash) sb64 = sb32 = sbO = -1;   // timing probe: no stash / output stores at all (results are garbage)
   }
   const unsigned ldp2 = (unsigned)a.ldpre2;
 
@@ -1219,6 +1226,12 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
 
   for (int t = Td - 1; t >= 0; --t) {
     X.epoch = (unsigned)(Td - t);
+    if (kProbes3) {
+      X.trace = (a.trace && blockIdx.x == 0 && t == Td / 2) ? a.trace : nullptr;
+      X.tslot = 0;
+      X.polls = 0;
+    }
+    tstamp(X);   // 0: step start
     const bool has_next = t + 1 < Td;
     RV nfo;   // step t+1 of the row was fed by this step's output (sampled): its pre-net gradient flows back into this step
     static_for<R>([&](auto Q) {
@@ -1249,6 +1262,7 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
       }
     }
     lds_barrier();
+    tstamp(X);   // 1: inputs landed
     // ---- 1. round FAN: d alignments[rho][s] = VWxc[s] . dx_{t+1}   (+ rider: d p2_{t+1} = mask (dx_{t+1} . Wi_p^T)) ----
     {
       const Lane<R, 64> L;
@@ -1275,17 +1289,22 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
           smem[D::o_dp2 + n4 * R + L.rho] = g;
           put_granule<R>(X, Y3_DP2, n4, L.rho, g);
         }
-        gather<R, 1>(X, Y3_DP2, kPre2, [&](int n) { return (n >> 2) == peer; },
-                     [&](int n, int q, float v) { smem[D::o_dp2 + n * R + q] = v; });
       }
-      gather<R, (TTP * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(
-          X, Y3_DAL, TTP, [&](int n) { return false; }, [&](int n, int q, float v) { DES[q * TTP + n] = v; },
-          [&](int n, int q) { return n < rsel<R>(len, q); });
+      // one poll loop for the round's two vectors (adjacent regions): d alignments of every slot (nobody scores positions past
+      // text_length) and, behind them, the other peers' d p2 columns
+      gather<R, ((TTP + kPre2) * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(
+          X, Y3_DAL, has_next ? TTP + kPre2 : TTP, [&](int n) { return n >= TTP && ((n - TTP) >> 2) == peer; },
+          [&](int n, int q, float v) {
+            const int i = n < TTP ? D::o_des + n * R : D::o_dp2 + (n - TTP) * R;
+            smem[i + q] = v;
+          },
+          [&](int n, int q) { return n >= TTP || n < rsel<R>(len, q); });
       // next processed step's inputs: issued HERE because every poll waits for all earlier vector-memory operations of its wave
       // (one in-order counter), and the softmax / energy backward that follow are the longest poll-free stretch of a step
       if (t > 0) prefetch(t - 1);
     }
     lds_barrier();
+    tstamp(X);   // 2: FAN done
     // ---- 2. softmax backward: de = al * (dal - sum al dal)   (wave rho handles row rho) ----
     {
       const Lane<R, 64> L;
@@ -1297,15 +1316,16 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
         for (int j = 0; j < 4; ++j) {
           const int sx = L.lane + 64 * j;
           al[j] = sx < ln ? ALS[q * TTP + sx] : 0.f;
-          dl[j] = sx < ln ? DES[q * TTP + sx] : 0.f;
+          dl[j] = sx < ln ? DES[sx * R + q] : 0.f;
           dot += al[j] * dl[j];
         }
         dot = wave_sum(dot);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) DES[q * TTP + L.lane + 64 * j] = al[j] * (dl[j] - dot);
+        for (int j = 0; j < 4; ++j) DES[(L.lane + 64 * j) * R + q] = al[j] * (dl[j] - dot);
       }
     }
     lds_barrier();
+    tstamp(X);   // 3: softmax backward done
     // ---- 3. energy backward on the wave's unit over all memory rows:  th = tanh(keys + q); dpre = de v (1 - th^2);
     //         dq[u] = sum_s dpre ; dkeys[s, u] += dpre ; dv[u] += de th      (+ rider: d p1_{t+1} = mask (d p2 . W2^T)) ----
     {
@@ -1321,10 +1341,10 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
         for (int i = 0; i < 4; ++i) {
           const XV<R> kr = lds_rows<R>(KR + i * NT * R);
           XV<R> dk = lds_rows<R>(DKR + i * NT * R);
-          const int sx = L.lane + 64 * i;
+          const XV<R> dev = lds_rows<R>(DES + (L.lane + 64 * i) * R);   // de of the R rows (zero past text_length: the softmax backward wrote al = 0 there)
 #pragma unroll
           for (int q = 0; q < R; ++q) {
-            const float de = DES[q * TTP + sx];        // (zero past text_length: the softmax backward wrote al = 0 there)
+            const float de = dev.v[q];
             const float th = tanh_fast(kr.v[q] + qv.v[q]);
             const float pre = de * vu * (1.f - th * th);
             dq.v[q] += pre;
@@ -1355,15 +1375,15 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
           VO[(R80 + kAtt + u) * R + L.rho] = g1;
           put_granule<R>(X, Y3_DP1, u, L.rho, g1);
         }
-        gather<R, (256 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(X, Y3_DP1, 256, [&](int n) { return (n >> 3) == peer; },
-                                                             [&](int n, int q, float v) { VO[(R80 + kAtt + n) * R + q] = v; });
       }
-      gather<R, (256 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(X, Y3_DQ, 256, [&](int n) { return (n >> 3) == peer; },
+      // one poll loop: dq (region Y3_DQ) and, behind it, d p1 (Y3_DP1) -- adjacent regions, adjacent segments of the OUT input
+      gather<R, (512 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(X, Y3_DQ, has_next ? 512 : 256, [&](int n) { return ((n & 255) >> 3) == peer; },
                                                            [&](int n, int q, float v) { VO[(R80 + n) * R + q] = v; });
       if (sbq >= 0) gst[(unsigned)(sbq * Td + t) * kGsRec + kGsQ + u] = pick<R>(dq, L.lane);
       if (sb64 >= 0) gst[(unsigned)(sb64 * Td + t) * kGsRec + kGsP1S + u] = g1;
     }
     lds_barrier();
+    tstamp(X);   // 4: DQ done
     // ---- 4. round OUT: dy = [d out ; dq ; d p1] . wot + dx_{t+1} . wdx ; owner: dht_3, (dcp, dup) of GRU-3 ----
     // elementwise GRU derivative of the unit at layer l given the total dL/dh_l' (shared by OUT and the G rounds)
     auto gru_elem = [&](int l, int wv, int rho, float dht, int u, unsigned gsb, bool vld) {
@@ -1403,6 +1423,7 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
       gather<R, (512 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(X, Y3_CG + 2 * 512, 512, [&](int n) { return ((n & 255) >> 3) == peer; }, cg_put(2));
     }
     lds_barrier();
+    tstamp(X);   // 5: OUT done
     // ---- 5. GRU layers, top down ----
 #pragma unroll
     for (int l = 2; l >= 0; --l) {
@@ -1433,6 +1454,7 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
         if (sb32 >= 0 && M.lane >= 32) gst[(unsigned)(sb32 * Td + t) * kGsRec + kGsG + l * 512 + u] = gr;
       }
       lds_barrier();
+      tstamp(X);   // C_l done
       {   // G_l: [d inp ; d h] += dgp . Wg^T
         const Lane<R, 32> M;
         const int u = peer * 8 + M.wave;
@@ -1472,7 +1494,9 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
         }
       }
       lds_barrier();
+      tstamp(X);   // G_l done
     }
+    if (kProbes3 && X.trace && tid == 0) X.trace[63] = X.tslot;
   }
   // ---- resident d keys accumulators -> memory; attention_v gradient per row ----
   {
@@ -1559,7 +1583,7 @@ int launch_decoder3_bwd(DecBwdArgs a, hipStream_t s) {
   const char* env = getenv("TACO_DEC_V3");
   if (env && (atoi(env) == 0 || atoi(env) == 1)) return TACO_ENOTFOUND;   // TACO_DEC_V3=1: forward only (A/B runs)
   if (a.Tt > TTP || a.B > 32 || a.B < 1 || (a.r != 2 && a.r != 5)) return TACO_ENOTFOUND;
-  if (!a.hoisted || a.trace) return TACO_ENOTFOUND;
+  if (!a.hoisted || (a.trace && !kProbes3)) return TACO_ENOTFOUND;
   // Opt-in data-parallel mode "collectives underneath the BPTT" (taco_dp_config overlap_bptt): a communication workgroup must
   // fit on every CU beside the BPTT workgroup.  This kernel fills the CU (8 waves x ~220 VGPRs, ~110 KB LDS), decoder.hip's BPTT
   // leaves the configured LDS reserve and half the register file: that mode takes decoder.hip.

@@ -37,3 +37,15 @@ for nm in names:
 rest = t[i:]
 print('E / softmax stamps since the OUT barrier [energies published, p2 rider done, gathered, barrier, softmax done, barrier]:', ['%.2f' % (x - t[i - 1]) for x in rest])
 print('sum over G0..OUT: compute %.2f gather %.2f barrier %.2f; whole step %.2f us' % (tot[0], tot[1], tot[2], t[n - 1]))
+
+if not infer:
+    m.backward()
+    torch.cuda.synchronize()
+    tb = m.workspace[o + 16 + 256:o + 16 + 256 + 2 * 64].view(torch.int64).cpu().numpy()
+    nb = int(tb[63])
+    tt = [(x - tb[0]) / 2400.0 for x in tb[:nb]]
+    names = ['inputs landed', 'FAN (d alignments + d p2)', 'softmax backward', 'DQ (energy backward + dq + d p1)', 'OUT', 'C2', 'G2', 'C1', 'G1', 'C0', 'G0']
+    print('BACKWARD step (us at 2.4 GHz), section durations:')
+    for i in range(1, nb):
+        print('  %-36s %6.2f' % (names[i - 1] if i - 1 < len(names) else '?', tt[i] - tt[i - 1]))
+    print('  whole step %.2f us' % tt[nb - 1])
