@@ -897,17 +897,25 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
     {
       const Lane<R, 64> L;
       const int n4 = peer * 4 + (L.wave & 3);
+      {
+        // the wave's four slots together: four independent partial sums per lane, ONE interleaved reduction (col_sum_all), and
+        // lane 48 + i publishes slot i -- instead of four dependent {score, wave sum, branch, publish} sequences
+        Acc<4> e4;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int g = i * 256 + L.wave * 32 + peer;
-        const int rho = g % R, sidx = g / R;
-        if (sidx < rsel<R>(len, rho)) {
-          const float4 q4 = reinterpret_cast<const float4*>(QS + rho * kAtt)[L.lane];
+        for (int i = 0; i < 4; ++i) {
+          const int g = i * 256 + L.wave * 32 + peer;
+          const float4 q4 = reinterpret_cast<const float4*>(QS + (g % R) * kAtt)[L.lane];
           const float4 k4 = kres[i];
-          float e = v4.x * tanh_fast(k4.x + q4.x) + v4.y * tanh_fast(k4.y + q4.y) + v4.z * tanh_fast(k4.z + q4.z) +
+          e4.v[i] = v4.x * tanh_fast(k4.x + q4.x) + v4.y * tanh_fast(k4.y + q4.y) + v4.z * tanh_fast(k4.z + q4.z) +
                     v4.w * tanh_fast(k4.w + q4.w);
-          e = wave_sum(e);
-          if (L.lane == 0) {
+        }
+        col_sum_all<4, 64>(e4);
+        const int i = L.lane - 48;
+        if (i >= 0 && i < 4) {
+          const int g = i * 256 + L.wave * 32 + peer;
+          const int rho = g % R, sidx = g / R;
+          if (sidx < rsel<R>(len, rho)) {
+            const float e = pick<4>(e4, i);
             ES[rho * TTP + sidx] = e;
             put_granule<R>(X, X3_E, sidx, rho, e);
           }
