@@ -644,7 +644,11 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
     p2n = 0.f;
     km1n = km2n = 1.f;
     frn = 0.f;
+#ifdef TACO_P_NOPARK
+    if (false) {   // timing probe: no next-step input loads at all (results are garbage)
+#else
     if (TR && tn < Td) {
+#endif
       const Lane<R, 64> L;
       if (a.prein && lead && L.tid < kMel * R) {   // teacher frame of step tn (the pre-net weight gradient reads a.prein for every step)
         const int q = L.tid / kMel, i = L.tid - q * kMel;
@@ -953,6 +957,7 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
             }
           },
           [&](int n, int q) { return n < kPre2 || n - kPre2 < rsel<R>(len, q); });
+      tstamp(X);   // E: gathered (before the deferred stores / next-step prefetch)
       if (TR && has_next) {
         if (sb64 >= 0 && L.wave < 4 && rsel<R>(from_out, L.rho))
           stash[(unsigned)(sb64 * Td + t + 1) * kStRec + kStP2 + n4] = y2;

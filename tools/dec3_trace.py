@@ -22,7 +22,7 @@ torch.cuda.synchronize()
 tab = {n: (o, s) for n, o, s, d in lib.workspace_table(m.shape, not infer)}
 o, s = tab['dec.err']
 tr = m.workspace[o + 16:o + 16 + 2 * 64].view(torch.int64).cpu().numpy()
-n = int(tr[63]); polls = int(tr[62])
+n = int(tr[63]); polls = int(tr[62]); print('poll iterations of the E gather (max over the traced workgroup, summed over launches):', int(tr[61]) & 0xffffffff)
 t = [(x - tr[0]) / 2400.0 for x in tr[:n]]      # shader clock ~2.4 GHz (reported in us at that nominal rate)
 names = ['G0', 'C0', 'G1', 'C1', 'G2', 'C2', 'OUT']
 print('B=%d %s: %d stamps, max poll iterations of a thread in the step: %d' % (B, 'infer' if infer else 'train', n, polls))
