@@ -134,8 +134,12 @@ class Tacotron(object):
                      self.masks, self.grads, self.workspace, self.speaker)
 
     def apply_gradients(self, lr):
-        """Guarded: if a decoder kernel flagged a timed-out exchange (on ANY rank -- the error words are all-reduced with
-        the gradients) the update is skipped on the device and `global_gradient_norm` reads -1; check() raises."""
+        """Guarded: if a decoder kernel flagged a timed-out exchange (on ANY rank -- the error words are MAX-reduced with
+        the gradients) the update is skipped on the device and `global_gradient_norm` reads -1; check() raises.
+        `global_step` counts ATTEMPTED updates (it is advanced on the host before the device decides): after a skipped update
+        the Adam bias-correction step, the annealing cadence and the checkpoint numbering run ahead of the updates actually
+        applied by the number of skipped steps -- which check() reports at the next synchronisation point, where the drivers
+        stop."""
         self.global_step += 1
         lib.clip_adam_step(self.params.flat, self.grads, self.adam_m, self.adam_v, lr, self.config.cap_grads,
                            self.global_step, self._scratch, self._gnorm, self._err)
