@@ -196,7 +196,8 @@ int taco_fill_bernoulli(uint8_t* out, int64_t n, float p_one, uint64_t seed, voi
 /* Launch-level timing with hipEventRecord pairs on the launch stream (rings of 4096 event pairs per category; no
  * synchronisation at record time).  Categories: 0 = persistent decoder forward kernel, 1 = decoder backward kernel,
  * 2 = MFMA GEMM family (conv_gemm / gemm_tn / fused highway stack launches), 3 = bi-GRU recurrences.
- * taco_profile_enable(mask): bit c switches category c on (mask 0 = off).
+ * taco_profile_enable(mask): bit c switches category c on (mask 0 = off); bit 4 (16) additionally keeps ALL work on the caller's
+ * stream (no side stream) while set, so that a category-2 pass times every GEMM launch by itself.
  * taco_profile_read2 synchronises on the recorded events, writes up to `cap` elapsed times (milliseconds) and the
  * algorithmic FLOPs of each launch (2 M N K taps) to the HOST arrays, oldest first, clears the ring, returns the count.
  * Launches that overlap on two streams are each timed by their own events (their times then sum to more than the wall). */

@@ -284,7 +284,9 @@ int record_segment(int seg, hipStream_t on) {
 }
 hipStream_t side_fork(hipStream_t s) {
   SideStream& x = side_stream();
-  if (x.off) return s;
+  // (profile bit 4: everything on the caller's stream, so that the per-launch event timing of the GEMM family measures each
+  //  kernel by itself instead of two streams' kernels sharing the chip)
+  if (x.off || (g_prof_mask & 16)) return s;
   if (hipEventRecord(x.ev_fork, s) != hipSuccess || hipStreamWaitEvent(x.side, x.ev_fork, 0) != hipSuccess) return s;
   return x.side;
 }
@@ -511,7 +513,7 @@ thread_local hipStream_t g_tn_side = nullptr;
 thread_local hipEvent_t g_tn_ev = nullptr;
 int tn_route(hipStream_t s, hipStream_t* out) {
   *out = s;
-  if (!g_tn_side || g_tn_side == s) return TACO_OK;
+  if (!g_tn_side || g_tn_side == s || (g_prof_mask & 16)) return TACO_OK;
   if (!g_tn_ev && hipEventCreateWithFlags(&g_tn_ev, hipEventDisableTiming) != hipSuccess) {
     taco_set_error("weight-gradient side stream: cannot create an event");
     return TACO_ELAUNCH;
@@ -1327,7 +1329,7 @@ extern "C" int taco_debug_spin(int blocks, int threads, int lds_bytes, int usec,
 }
 
 extern "C" int taco_profile_enable(int mask) {
-  g_prof_mask = mask & 15;
+  g_prof_mask = mask & 31;
   return TACO_OK;
 }
 
