@@ -143,6 +143,8 @@ __global__ void bn_maxpool_kernel(const float* __restrict__ x, const float* __re
 
 // blockDim = (64 channel quads, 4 row lanes); grid = (C/256 ceil, row chunks).  A row lane walks a CONTIGUOUS run of rows, so
 // the three pooled neighbours z[row-1], z[row], z[row+1] and dy[row-1] roll through registers: x and dy are read once.
+// x is the ReLU output the affine was applied to (ops.py:64-66: relu -> batch_norm -> max_pool): the ReLU backward (x > 0)
+// is applied to the stored gradient in the same pass.
 __global__ void bn_maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                       const float* __restrict__ beta, const float* __restrict__ dy,
                                       float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
@@ -182,7 +184,7 @@ __global__ void bn_maxpool_bwd_kernel(const float* __restrict__ x, const float* 
         float dz = 0.f;
         if (last || z >= xnv[q] * sc[q] + be[q]) dz = dcv[q];          // y[row] = max(z[row], z[row+1]) takes z[row] on ties
         if (!first && z > xpv[q] * sc[q] + be[q]) dz += dpv[q];        // y[row-1] takes z[row] only when strictly larger
-        o[q] = dz * sc[q];
+        o[q] = xcv[q] > 0.f ? dz * sc[q] : 0.f;
         ag[q] += dz * xcv[q] * rs;
         ab[q] += dz;
       }

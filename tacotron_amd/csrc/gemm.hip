@@ -492,6 +492,11 @@ int launch_conv_gemm_batch(ConvGemmBatch& batch, hipStream_t stream) {
     maxN = p.N > maxN ? p.N : maxN;
     work += (double)cdiv(p.M, 128) * cdiv(p.N, 128);
   }
+  // pooled epilogue (ConvGemmProblem::pool) exists in gemm2.hip only: nothing is launched otherwise and the caller runs the
+  // convolution and bn_maxpool as two passes
+  bool any_pool = false;
+  for (int i = 0; i < batch.n; ++i) any_pool = any_pool || batch.p[i].pool != 0;
+  if (any_pool && !(flags == 3 && conv_gemm2_would_launch(batch))) return TACO_ENOTFOUND;
   double flops = 0;
   for (int i = 0; i < batch.n; ++i) flops += 2.0 * batch.p[i].M * batch.p[i].N * batch.p[i].K * batch.p[i].taps;
   const int pslot = taco_prof_begin(2, stream);
@@ -506,6 +511,7 @@ int launch_conv_gemm_batch(ConvGemmBatch& batch, hipStream_t stream) {
       return TACO_OK;
     }
   }
+  TACO_REQUIRE(!any_pool, "conv_gemm: the pooled epilogue was promised by gemm2.hip and not delivered");
   // Big tiles only when they still fill the chip (256 CUs); otherwise 64x64 tiles for more workgroups.
   if (work >= 384) {
     dispatch_nn<2, 2>(flags, dim3(cdiv(maxM, 128), cdiv(maxN, 128), batch.n), stream, batch);

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
   const int rel = blockIdx.x - G.first[pi];
   const int mtiles = G.mt[pi];
   const int tnn = rel / mtiles, tmm = rel - tnn * mtiles;
-  const int m0 = tmm * TM, n0 = tnn * TN;
+  const int m0 = tmm * (P.pool ? TM - 1 : TM), n0 = tnn * TN;   // pooled epilogue: tiles overlap by their halo row
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = P.T, K = P.K, lda = P.lda, ldw = P.ldw;
@@ -245,6 +245,65 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
   // ---- epilogue.  C/D layout of v_mfma_f32_32x32x2: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5);
   //      sub-tile j holds columns n0 + 4 li + j, so element e of the four accumulators is one float4 of row `row` ----
   const int n = n0 + 4 * li;
+  if (P.pool) {
+    // ---- pooled epilogue (conv bank, ops.py:62-71): bank = act(acc + bias) -> Cpre;  z = bank * scale + shift;
+    //      C[m] = max(z[m], z[m + 1]) inside a sequence.  Row m + 1 of element e lives in the same lane (e & 3 < 3), in the
+    //      lane 32 away (rows 3|4 and 7|8 of an 8-row group straddle the kh halves) or in the next wave (row 31|32, via LDS);
+    //      local row 127 is the halo: it only feeds row 126 unless it ends its sequence (the next tile starts ON it).
+    //      Launcher contract: float4 rows, no keep / residual / per-sequence bias / atomics. ----
+    const bool col_ok = n + 3 < P.N;
+    float b4[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {1.f, 1.f, 1.f, 1.f}, sf[4] = {0.f, 0.f, 0.f, 0.f};
+    if (col_ok) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (P.bias) b4[j] = P.bias[n + j];
+        if (P.scale) sc[j] = P.scale[n + j] * P.scale_mul;
+        if (P.shift) sf[j] = P.shift[n + j];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = m0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = apply_act(acc[j][e] + b4[j], P.act);
+      if (P.Cpre && col_ok && m < P.M)
+        *reinterpret_cast<float4*>(P.Cpre + (int64_t)m * P.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j][e] = v[j] * sc[j] + sf[j];
+    }
+    __syncthreads();   // every wave is done with the ring: its first 2 KB now carry each wave's row 0 to the wave above
+    if (kh == 0) *reinterpret_cast<float4*>(smem + wave * TN + 4 * li) = make_float4(acc[0][0], acc[1][0], acc[2][0], acc[3][0]);
+    __syncthreads();
+    float nx[4][4];   // nx[j][i]: successor of this lane's row (e = 4 i + 3)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float send = kh ? acc[j][4 * i] : acc[j][i < 3 ? 4 * (i + 1) : 12];
+        nx[j][i] = __shfl_xor(send, 32);
+      }
+    if (kh == 1 && wave < 3) {
+      const float4 t = *reinterpret_cast<const float4*>(smem + (wave + 1) * TN + 4 * li);
+      nx[0][3] = t.x; nx[1][3] = t.y; nx[2][3] = t.z; nx[3][3] = t.w;
+    }
+    if (!col_ok) return;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = m0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+      if (m >= P.M) continue;
+      const bool has_next = (m % T) + 1 < T;
+      if (has_next && wave == 3 && kh == 1 && e == 15) continue;   // halo row: written by the tile that starts on it
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float nxt = (e & 3) < 3 ? acc[j][(e + 1) & 15] : nx[j][e >> 2];
+        o[j] = has_next ? fmaxf(acc[j][e], nxt) : acc[j][e];
+      }
+      *reinterpret_cast<float4*>(P.C + (int64_t)m * P.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    return;
+  }
   if (n >= P.N) return;
   const bool vec = (P.flags & 4) != 0 && n + 3 < P.N;
   float bias0[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {1.f, 1.f, 1.f, 1.f}, sf[4] = {0.f, 0.f, 0.f, 0.f};
@@ -513,20 +572,43 @@ extern "C" __attribute__((visibility("default"))) int taco_debug_gemm2_window(in
   return n;   // eligible launches seen since the last call
 }
 
+// m-tiles of a problem: pooled problems advance by TM - 1 rows (the last row of a tile is the next tile's first)
+static inline int m_tiles(const ConvGemmProblem& p) { return p.pool ? cdiv(p.M > 1 ? p.M - 1 : 1, TM - 1) : cdiv(p.M, TM); }
+static bool pool_contract(const ConvGemmProblem& p) {
+  return p.N % 4 == 0 && p.ldc % 4 == 0 && al16(p.C) && (!p.Cpre || al16(p.Cpre)) && !p.keep && !p.residual &&
+         p.bias_stride == 0 && !p.atomic_out && p.it0 == 0 && p.it1 == 0;
+}
+bool conv_gemm2_would_launch(const ConvGemmBatch& batch) {
+  const int min_tiles = gemm2_min_tiles();
+  if (min_tiles <= 0) return false;
+  int tiles = 0;
+  for (int i = 0; i < batch.n; ++i) {
+    const ConvGemmProblem& p = batch.p[i];
+    if ((p.flags & 3) != 3 || (p.pool && !pool_contract(p))) return false;
+    tiles += m_tiles(p) * cdiv(p.N, TN);
+  }
+  return tiles >= min_tiles;
+}
+
 int launch_conv_gemm2(ConvGemmBatch& batch, hipStream_t stream, bool force) {
   const int min_tiles = force ? 1 : gemm2_min_tiles();
   if (gemm2_min_tiles() <= 0) return TACO_ENOTFOUND;
   Gemm2Args g;
   int order[kMaxGemmBatch];
   int tiles = 0;
+  bool any_pool = false;
   for (int i = 0; i < batch.n; ++i) {
     ConvGemmProblem& p = batch.p[i];
     if ((p.flags & 3) != 3) return TACO_ENOTFOUND;   // both operands: 16-byte aligned rows, K / Nld multiples of 4
-    tiles += cdiv(p.M, TM) * cdiv(p.N, TN);
+    if (p.pool) {
+      TACO_REQUIRE(pool_contract(p), "conv_gemm2: pooled epilogue needs float4 rows and no keep / residual / row bias / atomics / k-split");
+      any_pool = true;
+    }
+    tiles += m_tiles(p) * cdiv(p.N, TN);
     order[i] = i;
   }
   if (tiles < min_tiles) return TACO_ENOTFOUND;
-  {
+  if (!any_pool) {   // (pooled batches were promised to their caller by conv_gemm2_would_launch: no debug window for them)
     const int idx = g_win_idx++;
     if (getenv("TACO_GEMM2_TRACE"))
       for (int i = 0; i < batch.n; ++i)
@@ -551,7 +633,7 @@ int launch_conv_gemm2(ConvGemmBatch& batch, hipStream_t stream, bool force) {
     p.flags = (p.flags & 3) | (vec ? 4 : 0);
     g.batch.p[i] = p;
     g.first[i] = first;
-    g.mt[i] = cdiv(p.M, TM);
+    g.mt[i] = m_tiles(p);
     first += g.mt[i] * cdiv(p.N, TN);
   }
   Variant v = env_variant();

@@ -28,6 +28,10 @@ struct ConvGemmProblem {
   int atomic_out = 0;  // C += result with fp32 atomics (C pre-zeroed by the caller); several problems may share C
   float scale_mul = 1.f;   // scale[n] is multiplied by this (BN inference: scale = gamma, scale_mul = 1/sqrt(1+eps))
   int it0 = 0, it1 = 0;    // gemm2.hip only: restrict the (tap, 32-deep k-tile) sequence to [it0, it1) (k-split chunk); it1 = 0: all
+  // gemm2.hip only: max_pool1d(2, stride 1, 'same') along the sequence in the epilogue (ops.py:64-71).  C[m] receives
+  // max(z[m], z[m + 1]) (z[m] alone on the last row of a sequence) of the affine'd activation z; Cpre, if given, the
+  // activation before the affine.  m-tiles overlap by one row (stride 127) so every pooled row has its successor in the tile.
+  int pool = 0;
 };
 struct ConvGemmBatch {
   ConvGemmProblem p[kMaxGemmBatch];
@@ -50,6 +54,9 @@ int launch_conv_gemm_batch(ConvGemmBatch& batch, hipStream_t stream);
 // gemm2.hip: DMA-staged NN kernel for batches that meet the vector contract (flags == 3 on every problem) and have at least
 // TACO_GEMM2_MIN_TILES (default 96) 128 x 128 tiles; returns TACO_ENOTFOUND without launching otherwise.
 int launch_conv_gemm2(ConvGemmBatch& batch, hipStream_t stream, bool force = false);
+// true when launch_conv_gemm2 would take this batch (flags already set): callers that want the pooled epilogue ask first and
+// run conv + bn_maxpool as two launches otherwise
+bool conv_gemm2_would_launch(const ConvGemmBatch& batch);
 int gemm2_min_tiles();   // TACO_GEMM2_MIN_TILES (0 disables gemm2.hip)
 // The CBHG's highway layers as one launch (highway.hip).  Layer l: th[l] = [sigmoid(x Wt+bt) | relu(x Wh+bh)] (M,256),
 // y[l] = H*T + x*(1-T) (M,128) feeds layer l+1.
@@ -99,7 +106,7 @@ int launch_center_rows(const float* x, const int32_t* len, float* out, int B, in
 int launch_embedding_bwd(const float* dout, const int32_t* ids, float* dtable, int64_t rows, int V, hipStream_t s, int width = kEmbed);
 // y = maxpool2_same(x*scale+shift) along T; x,y (B*T, C)
 int launch_bn_maxpool(const float* x, const float* gamma, const float* beta, float* y, int B, int T, int C, hipStream_t s);
-// dx, dgamma, dbeta of the op above (dgamma/dbeta accumulated with atomics)
+// dgamma, dbeta of the op above (atomics) and dx THROUGH the ReLU that produced x: dx = (x > 0) * d(x*scale+shift) * scale
 int launch_bn_maxpool_bwd(const float* x, const float* gamma, const float* beta, const float* dy, float* dx,
                           float* dgamma, float* dbeta, int B, int T, int C, hipStream_t s);
 // highway combine: th (M,256) = [T | H]; y = H*T + x*(1-T)

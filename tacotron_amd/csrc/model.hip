@@ -139,23 +139,44 @@ BiGruWeights bigru_weights(const float* P, const CbhgP& c) {
 int cbhg_fwd(const float* P, const CbhgP& c, const float* x, int B, int T, const CbhgBufs& w, bool keep_ruc,
              hipStream_t s) {
   const int M = B * T, KC = c.K * kCb;
-  // conv bank: K 'same' convs + ReLU, concatenated on channels (ops.py:54-62) -- one batched launch
-  {
-    ConvGemmBatch batch;
-    batch.n = c.K;
-    for (int k = 1; k <= c.K; ++k) {
-      ConvGemmProblem& p = batch.p[c.K - k];   // widest kernel first: its blocks are the longest-running
-      p = ConvGemmProblem();
-      p.A = x; p.lda = c.cin; p.W = P + c.bank_w[k - 1]; p.ldw = kCb; p.bias = P + c.bank_b[k - 1];
-      p.C = w.bank + (k - 1) * kCb; p.ldc = KC; p.M = M; p.N = kCb; p.K = c.cin; p.taps = k; p.T = T;
-      p.pad_l = (k - 1) / 2; p.act = TACO_ACT_RELU;
-    }
-    TACO_TRY(launch_conv_gemm_batch(batch, s));
-  }
-  // BN-affine + max-pool(2,1,same) (ops.py:64-71)
-  TACO_TRY(launch_bn_maxpool(w.bank, P + c.bank_g, P + c.bank_be, w.pool, B, T, KC, s));
-  // conv projections (ops.py:75-87) + residual (ops.py:92)
+  // conv bank: K 'same' convs + ReLU, concatenated on channels (ops.py:54-62), BN-affine + max-pool(2,1,same) (ops.py:64-71):
+  // one batched launch whose epilogue pools along the sequence (gemm2.hip); the un-pooled activations are kept only when a
+  // backward pass will read them.  Shapes the DMA kernel does not take run conv and pool as two passes.
   const float bn_rs = 1.0f / sqrtf(1.0f + kBnEps);   // BN in inference mode: gamma / sqrt(moving_var(=1) + eps), folded in the epilogue
+  {
+    const char* nf = getenv("TACO_NO_POOL_FUSE");   // A/B and test switch: always the two-pass form
+    const bool no_fuse = nf && atoi(nf) != 0;
+    ConvGemmBatch batch;
+    auto fill = [&](bool fused) {
+      batch.n = c.K;
+      for (int k = 1; k <= c.K; ++k) {
+        ConvGemmProblem& p = batch.p[c.K - k];   // widest kernel first: its blocks are the longest-running
+        p = ConvGemmProblem();
+        p.A = x; p.lda = c.cin; p.W = P + c.bank_w[k - 1]; p.ldw = kCb; p.bias = P + c.bank_b[k - 1];
+        p.ldc = KC; p.M = M; p.N = kCb; p.K = c.cin; p.taps = k; p.T = T;
+        p.pad_l = (k - 1) / 2; p.act = TACO_ACT_RELU;
+        if (fused) {
+          p.C = w.pool + (k - 1) * kCb; p.Cpre = keep_ruc ? w.bank + (k - 1) * kCb : nullptr;
+          p.scale = P + c.bank_g + (k - 1) * kCb; p.shift = P + c.bank_be + (k - 1) * kCb; p.scale_mul = bn_rs; p.pool = 1;
+        } else {
+          p.C = w.bank + (k - 1) * kCb;
+        }
+      }
+    };
+    int rc = TACO_ENOTFOUND;
+    if (!no_fuse) {
+      fill(true);
+      rc = launch_conv_gemm_batch(batch, s);
+    }
+    if (rc == TACO_ENOTFOUND) {
+      fill(false);
+      TACO_TRY(launch_conv_gemm_batch(batch, s));
+      TACO_TRY(launch_bn_maxpool(w.bank, P + c.bank_g, P + c.bank_be, w.pool, B, T, KC, s));
+    } else {
+      TACO_TRY(rc);
+    }
+  }
+  // conv projections (ops.py:75-87) + residual (ops.py:92)
   {
     ConvGemmProblem p;
     p.A = w.pool; p.lda = KC; p.W = P + c.p1_w; p.ldw = c.c1; p.bias = P + c.p1_b; p.scale = P + c.p1_g; p.scale_mul = bn_rs; p.shift = P + c.p1_be;
@@ -788,8 +809,8 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
     TACO_TRY(launch_conv_gemm(p, s));
   }
   float* dbank = sc.gB;  // (M,KC)
+  // (d relu included: dbank is the gradient of the bank's pre-activation)
   TACO_TRY(launch_bn_maxpool_bwd(w.bank, P + c.bank_g, P + c.bank_be, dpool, dbank, G + c.bank_g, G + c.bank_be, B, T, KC, s));
-  TACO_TRY(launch_act_bwd(w.bank, dbank, nullptr, dbank, (int64_t)M * KC, TACO_ACT_RELU, s));
   // ---- conv bank: weight/bias grads per width; input grad = residual path + sum over widths, accumulated with fp32
   //      atomics by ONE batched launch (all K transposed convolutions run concurrently instead of as a dependent chain) ----
   {

@@ -388,6 +388,46 @@ def test_medium_shape_with_gemm2_forced(built_lib, variant, monkeypatch):
     test_backward_without_masks_and_ragged_lengths(built_lib)
 
 
+@pytest.mark.parametrize('B,Tt,Td', [(3, 127, 64), (2, 128, 9), (1, 255, 12), (4, 200, 100), (5, 9, 5), (2, 254, 127)])
+def test_pooled_bank_epilogue_tile_edges(built_lib, B, Tt, Td, monkeypatch):
+    """Conv bank + BN-affine + max-pool as ONE launch (gemm2.hip pooled epilogue, ops.py:54-71): sequence lengths chosen so that
+    sequence ends fall on every special row of the overlapping 128-row tiles (last row of a tile = halo, first row of the next,
+    rows 3|4 / 7|8 / 31|32 of the MFMA layout), for both CBHGs (T = Tt and T = Td * r).  Checked against the CPU restatement
+    and -- bitwise -- against the two-pass form (TACO_NO_POOL_FUSE=1) on the same inputs."""
+    r, V = 2, 40
+    monkeypatch.setenv('TACO_GEMM2_MIN_TILES', '1')
+    p = on.init_params(V, r, seed=11, perturb=0.3)
+    inp, masks = _full_case(B, Tt, Td, r, V)
+    R = Runner(built_lib, B, Tt, Td, r, V)
+    R.set(p, inp, masks)
+    got = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('TACO_NO_POOL_FUSE', mode)
+        R.forward()
+        got[mode] = {k: R.wsget(k).copy() for k in ('enc.bank', 'enc.pool', 'post.bank', 'post.pool', 'enc.p2')}
+        got[mode]['s2s'] = R.s2s.cpu().numpy().copy()
+    for k in ('enc.bank', 'enc.pool', 'post.bank', 'post.pool'):
+        assert np.array_equal(got['0'][k], got['1'][k]), k
+    for pf, xin, T, K in (('encoder/cbhg/', got['0']['enc.p2'].reshape(B, Tt, -1).astype(np.float64), Tt, 16),
+                          ('post/cbhg/', got['0']['s2s'].reshape(B, Td * r, 80).astype(np.float64), Td * r, 8)):
+        bank = np.concatenate([on.relu(on.conv1d_same(xin, p[pf + 'bank_%d/kernel' % k], p[pf + 'bank_%d/bias' % k]))
+                               for k in range(1, K + 1)], -1)
+        pool = on.maxpool2_same(on.bn_affine(bank, p[pf + 'bank_bn/gamma'], p[pf + 'bank_bn/beta']))
+        tag = 'enc' if K == 16 else 'post'
+        assert report(tag + '.bank', got['0'][tag + '.bank'], bank.reshape(B * T, -1))[0] < 1e-5
+        assert report(tag + '.pool', got['0'][tag + '.pool'], pool.reshape(B * T, -1))[0] < 1e-5
+    # inference keeps no un-pooled activations: same pooled tensor
+    Ri = Runner(built_lib, B, Tt, Td, r, V, train=False)
+    Ri.set(p, inp)
+    Ri.infer()
+    xin = Ri.wsget('enc.p2').reshape(B, Tt, -1).astype(np.float64)       # (no dropout at inference: its own pre_net output)
+    pf = 'encoder/cbhg/'
+    bank = np.concatenate([on.relu(on.conv1d_same(xin, p[pf + 'bank_%d/kernel' % k], p[pf + 'bank_%d/bias' % k]))
+                           for k in range(1, 17)], -1)
+    pool = on.maxpool2_same(on.bn_affine(bank, p[pf + 'bank_bn/gamma'], p[pf + 'bank_bn/beta']))
+    assert report('enc.pool (inference)', Ri.wsget('enc.pool'), pool.reshape(B * Tt, -1))[0] < 1e-5
+
+
 @pytest.mark.parametrize('knob', ['TACO_DEFER_POST_TN', 'TACO_DEC_NO_LRES'])
 def test_medium_shape_with_optional_paths(built_lib, knob, monkeypatch):
     """The opt-in / A-B switches of the train step keep parity: post-net weight gradients deferred under the BPTT kernel
