@@ -112,8 +112,7 @@ template <int R, int MAXU, class Own, class Put, class Need = NeedAll>
 __device__ __forceinline__ void gather(Xc& X, int reg, int N, Own own, Put put, Need need = Need()) {
   constexpr int G = R >= 2 ? 2 : 1;
   constexpr int UPC = R / G;   // units per column
-  if (*X.dead) return;
-  if (kProbes3 && (X.fake & 2)) return;
+  const bool skip = *X.dead || (kProbes3 && (X.fake & 2));
   const int tid = opaque_tid();
   int un[MAXU], uh[MAXU];
   bool pend[MAXU];
@@ -123,7 +122,7 @@ __device__ __forceinline__ void gather(Xc& X, int reg, int N, Own own, Put put, 
     const int u = tid + i * NT;
     un[i] = UPC == 2 ? (u >> 1) : u;
     uh[i] = UPC == 2 ? (u & 1) : 0;
-    pend[i] = un[i] < N && !own(un[i]);
+    pend[i] = !skip && un[i] < N && !own(un[i]);
     any |= pend[i];
   }
   unsigned spin = 0;
@@ -153,8 +152,12 @@ __device__ __forceinline__ void gather(Xc& X, int reg, int N, Own own, Put put, 
           any = true;
         }
       }
-    if (any && spin_fail(spin, X)) return;
+    if (any && spin_fail(spin, X)) break;   // (fatal: the error word is set; every exit passes the wait below)
   }
+  // Tell the compiler's wait-count pass that nothing of this loop is in flight any more (true: the last pass waited for its
+  // loads).  Poll destinations that some path skipped would otherwise count as pending, and the next write of such a register --
+  // anywhere, e.g. behind the next-step prefetch -- would get a full `s_waitcnt vmcnt(0)`.
+  __builtin_amdgcn_s_waitcnt(0x0F70);
 }
 
 // The same over two regions in ONE poll loop: columns [0, N1) live in region reg1, columns [N1, N) in region reg2.
@@ -162,8 +165,7 @@ template <int R, int MAXU, class Own, class Put, class Need = NeedAll>
 __device__ __forceinline__ void gather2(Xc& X, int reg1, int N1, int reg2, int N, Own own, Put put, Need need = Need()) {
   constexpr int G = R >= 2 ? 2 : 1;
   constexpr int UPC = R / G;
-  if (*X.dead) return;
-  if (kProbes3 && (X.fake & 2)) return;
+  const bool skip = *X.dead || (kProbes3 && (X.fake & 2));
   const int tid = opaque_tid();
   int un[MAXU], uh[MAXU];
   bool pend[MAXU];
@@ -173,7 +175,7 @@ __device__ __forceinline__ void gather2(Xc& X, int reg1, int N1, int reg2, int N
     const int u = tid + i * NT;
     un[i] = UPC == 2 ? (u >> 1) : u;
     uh[i] = UPC == 2 ? (u & 1) : 0;
-    pend[i] = un[i] < N && !own(un[i]);
+    pend[i] = !skip && un[i] < N && !own(un[i]);
     any |= pend[i];
   }
   unsigned spin = 0;
@@ -204,8 +206,12 @@ __device__ __forceinline__ void gather2(Xc& X, int reg1, int N1, int reg2, int N
           any = true;
         }
       }
-    if (any && spin_fail(spin, X)) return;
+    if (any && spin_fail(spin, X)) break;   // (fatal: the error word is set; every exit passes the wait below)
   }
+  // Tell the compiler's wait-count pass that nothing of this loop is in flight any more (true: the last pass waited for its
+  // loads).  Poll destinations that some path skipped would otherwise count as pending, and the next write of such a register --
+  // anywhere, e.g. behind the next-step prefetch -- would get a full `s_waitcnt vmcnt(0)`.
+  __builtin_amdgcn_s_waitcnt(0x0F70);
 }
 
 // ---- register-resident mat-vec: column `col` of W (K x N, pitch ldw) split over LPC lanes; lane lk holds rows lk + LPC*j ----
@@ -638,18 +644,33 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
   }
   __syncthreads();
 
-  // values parked one step ahead: teacher p2 and the dropout multipliers of the NEXT step's pre-net (result lanes only)
-  float p2n = 0.f, km1n = 1.f, km2n = 1.f, frn = 0.f;
+  // values parked one step ahead: teacher p2, the dropout keep bytes of the NEXT step's pre-net (result lanes only) and its
+  // sampling flags.  They are parked RAW: any arithmetic on a loaded value (byte -> multiplier, byte -> bool, a register copy)
+  // makes the compiler wait for the load on the spot -- with the in-order counter that is a wait for every parked load, i.e. a
+  // full HBM round trip exposed once per step.  Conversions happen at the use sites (rounds OUT / E of the next step).
+  float p2n = 0.f, frn = 0.f;
+  unsigned k1n = 1, k2n = 1;
+  unsigned fon[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q) fon[q] = 0;
   auto park_next = [&](int tn) {
     p2n = 0.f;
-    km1n = km2n = 1.f;
+    k1n = k2n = 1;
     frn = 0.f;
+#pragma unroll
+    for (int q = 0; q < R; ++q) fon[q] = 0;
 #ifdef TACO_P_NOPARK
     if (false) {   // timing probe: no next-step input loads at all (results are garbage)
 #else
     if (TR && tn < Td) {
 #endif
       const Lane<R, 64> L;
+      if (a.sample) {   // step tn - 1's flags: row q of step tn is fed by that step's output
+        static_for<R>([&](auto Q) {
+          constexpr int q = decltype(Q)::value;
+          fon[q] = a.sample[(unsigned)((tn - 1) * B + brow.template get<q>())];
+        });
+      }
       if (a.prein && lead && L.tid < kMel * R) {   // teacher frame of step tn (the pre-net weight gradient reads a.prein for every step)
         const int q = L.tid / kMel, i = L.tid - q * kMel;
         frn = a.mel[(unsigned)(rsel<R>(brow, q) * Td + tn) * R80 + kMel * (RR - 1) + i];
@@ -660,12 +681,15 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
       }
       if (L.res) {
         const unsigned bt = (unsigned)(rsel<R>(brow, L.rho) * Td + tn);
-        if (a.keep1) km1n = a.keep1[bt * kPre1 + peer * 8 + L.wave] ? 2.f : 0.f;
-        if (a.keep2 && L.wave < 4) km2n = a.keep2[bt * kPre2 + peer * 4 + L.wave] ? 2.f : 0.f;
+        if (a.keep1) k1n = a.keep1[bt * kPre1 + peer * 8 + L.wave];
+        if (a.keep2 && L.wave < 4) k2n = a.keep2[bt * kPre2 + peer * 4 + L.wave];
       }
     }
   };
   static_assert(kPre2 * 4 <= NT, "one parked p2 value per thread");
+  // every load of the prologue is complete before the loop: otherwise the first loop use of a prologue register carries an
+  // `s_waitcnt vmcnt(0)` that, in steady state, waits for the parked loads instead (the waitcnt pass cannot tell iterations apart)
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), other counters untouched
   park_next(1);
 
   for (int t = 0; t < Td; ++t) {
@@ -678,15 +702,11 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
     tstamp(X);
     const bool has_next = t + 1 < Td;
     // helper.next_inputs: step t+1 of row rho is fed cell_output[t] at inference or when sampled, else mel[t+1]
-    RV from_out;
-    static_for<R>([&](auto Q) {
-      constexpr int q = decltype(Q)::value;
-      from_out.template at<q>() = !TR || (a.sample && a.sample[(unsigned)(t * B + brow.template get<q>())]);
-    });
     // step t+1's parked values land below in rounds OUT / E.  The loads for step t+2 are issued right behind round E's polls:
     // every poll waits for ALL earlier vector-memory operations of its wave (one in-order counter), and behind round E lie the
     // softmax, a barrier and round G0's mat-vecs -- the longest poll-free stretch of a step -- for these HBM reads to land in
-    const float p2t = p2n, km1t = km1n, km2t = km2n, frt = frn;
+    // (the parked registers are read in place below: park_next(t + 2) runs after their last use)
+    RV from_out;   // set in round OUT from the parked flags
 
     // ---- round G0: x = [p2 ; out'] Wx + al' VWx + bi ;  gates_1 = sigmoid([p2 ; out' ; h1] Wg0' + al' VWg + bg0') ----
     float ukeep = 0.f;   // update gate of the wave's unit, in the lanes (48 + rho) that finish its candidate column
@@ -862,7 +882,7 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
         col_sum_all<R, 64>(ap);
         if (L.res) {
           // layer 1 of a step fed by this step's output, straight from (x + h3) with Wo[:, last frame] W1
-          yp = fmaxf(pick<R>(ap, L.rho) + BIAS[D::b_p1o + n8], 0.f) * km1t;
+          yp = fmaxf(pick<R>(ap, L.rho) + BIAS[D::b_p1o + n8], 0.f) * (a.keep1 ? (k1n ? 2.f : 0.f) : 1.f);
           P1[n8 * R + L.rho] = yp;
           put_granule<R>(X, X3_P1, n8, L.rho, yp);
         }
@@ -881,6 +901,10 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
               else smem[D::o_p1 + (n - NQ) * R + q] = v;
             });
       }
+      static_for<R>([&](auto Q) {
+        constexpr int q = decltype(Q)::value;
+        from_out.template at<q>() = !TR || fon[q] != 0;
+      });
       if (sbO >= 0) {
         const unsigned bt = (unsigned)(sbO * Td + t);
         if (nO < kAtt) {
@@ -933,14 +957,14 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
         mv<R, 4, 64>(wp2, P1, L.lane, ap);
         col_sum_all<R, 64>(ap);
         if (L.res && L.wave < 4) {
-          y2 = fmaxf(pick<R>(ap, L.rho) + BIAS[D::b_p2 + n4], 0.f) * km2t;
+          y2 = fmaxf(pick<R>(ap, L.rho) + BIAS[D::b_p2 + n4], 0.f) * (a.keep2 ? (k2n ? 2.f : 0.f) : 1.f);
           put_granule<R>(X, X3_P2, n4, L.rho, y2);
           if (rsel<R>(from_out, L.rho)) U0[n4 * R + L.rho] = y2;
         }
         // rows fed by the teacher take the hoisted pre-net output instead
         if (TR && L.tid < kPre2 * R) {
           const int n = L.tid / R, q = L.tid - n * R;
-          if (!rsel<R>(from_out, q)) U0[n * R + q] = p2t;
+          if (!rsel<R>(from_out, q)) U0[n * R + q] = p2n;
         }
       }
       tstamp(X);
@@ -964,7 +988,7 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
         // teacher frames of step t+1 for the pre-net weight gradient (model.hip reads a.prein for every step)
         if (a.prein && lead && L.tid < kMel * R) {
           const int q = L.tid / kMel, i = L.tid - q * kMel;
-          if (!rsel<R>(from_out, q) && rsel<R>(valid, q)) a.prein[(unsigned)(rsel<R>(brow, q) * Td + t + 1) * kMel + i] = frt;
+          if (!rsel<R>(from_out, q) && rsel<R>(valid, q)) a.prein[(unsigned)(rsel<R>(brow, q) * Td + t + 1) * kMel + i] = frn;
         }
       }
       park_next(t + 2);
@@ -1204,8 +1228,17 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
   // result lanes 16+rho / 48+rho of every wave: the 12 record values of their unit; all threads: d out and alignment rows
   constexpr int NDO = (R * R80 + NT - 1) / NT, NAL = (R * TTP + NT - 1) / NT;
   float prec[12], pq = 0.f, pp1 = 0.f, pp2 = 0.f, pdo[NDO], pal[NAL];
+  unsigned nfn[R];   // raw sampling flags of step tp (parked like the rest: no arithmetic on them until they are used)
+#pragma unroll
+  for (int q = 0; q < R; ++q) nfn[q] = 0;
   auto prefetch = [&](int tp) {          // tp = step whose data is fetched (>= 0)
     const Lane<R, 32> M;
+    if (a.sample) {
+      static_for<R>([&](auto Q) {
+        constexpr int q = decltype(Q)::value;
+        nfn[q] = a.sample[(unsigned)(tp * B + brow.template get<q>())];
+      });
+    }
     if (M.res) {
       const unsigned bt = (unsigned)(rsel<R>(brow, M.rho) * Td + tp);
       const float* st = stash + bt * kStRec;
@@ -1235,6 +1268,7 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
       pal[j] = (qa < R && sa < Tt) ? a.align[(unsigned)(rsel<R>(brow, qa) * Td + tp) * (unsigned)Tt + sa] : 0.f;
     }
   };
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // prologue loads complete (see the forward kernel): no stray vmcnt(0) inside the loop
   prefetch(Td - 1);
 
   for (int t = Td - 1; t >= 0; --t) {
@@ -1249,7 +1283,7 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
     RV nfo;   // step t+1 of the row was fed by this step's output (sampled): its pre-net gradient flows back into this step
     static_for<R>([&](auto Q) {
       constexpr int q = decltype(Q)::value;
-      nfo.template at<q>() = has_next && a.sample && a.sample[(unsigned)(t * B + brow.template get<q>())];
+      nfo.template at<q>() = has_next && nfn[q] != 0;
     });
     // ---- 0. land the prefetched inputs ----
     {
