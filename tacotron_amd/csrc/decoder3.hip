@@ -108,18 +108,22 @@ __device__ __forceinline__ int opaque_tid() {
 struct NeedAll {
   __device__ __forceinline__ bool operator()(int, int) const { return true; }
 };
-template <int R, int MAXU, class Own, class Put, class Need = NeedAll>
+// NP: number of polling threads (the first NP of the workgroup, whole waves).  The others pass through WITHOUT touching the
+// vector-memory counter, so loads they have in flight (the backward kernel's next-step prefetch) keep flying across this round.
+template <int R, int MAXU, int NP = NT, class Own, class Put, class Need = NeedAll>
 __device__ __forceinline__ void gather(Xc& X, int reg, int N, Own own, Put put, Need need = Need()) {
   constexpr int G = R >= 2 ? 2 : 1;
   constexpr int UPC = R / G;   // units per column
-  const bool skip = *X.dead || (kProbes3 && (X.fake & 2));
+  static_assert(NP % 64 == 0 && NP <= NT, "pollers are whole waves");
   const int tid = opaque_tid();
+  if (NP < NT && tid >= NP) return;
+  const bool skip = *X.dead || (kProbes3 && (X.fake & 2));
   int un[MAXU], uh[MAXU];
   bool pend[MAXU];
   bool any = false;
 #pragma unroll
   for (int i = 0; i < MAXU; ++i) {
-    const int u = tid + i * NT;
+    const int u = tid + i * NP;
     un[i] = UPC == 2 ? (u >> 1) : u;
     uh[i] = UPC == 2 ? (u & 1) : 0;
     pend[i] = !skip && un[i] < N && !own(un[i]);
@@ -1083,7 +1087,8 @@ struct BDims {
   static constexpr int w_dy = 0, w_dht = 1, w_dinp = 2, w_dhp = 3, w_dh = 4 /* +l */, w_rec = 7 /* + 4*l + {r,u,c,hp} */, w_q = 19,
                        w_p1 = 20, w_n = 21;                   //   (w_p1: forward pre-net layer-1 activation of step t+1, unit's column)
   static constexpr int o_p2m = o_own + w_n * 8 * R;           // [4][R] forward pre-net layer-2 activations of step t+1 (this peer's 4 columns)
-  static constexpr int o_zero_end = o_p2m + 4 * R;
+  static constexpr int o_nf = o_p2m + 4 * R;                  // [4] sampling flags of the step (as floats: 0 = teacher forced)
+  static constexpr int o_zero_end = o_nf + 4;
   static constexpr int o_dead = o_zero_end;
   static constexpr int o_kr = o_dead + 4;                     // [4][NT][R] resident keys of the wave's unit   } private slots
   static constexpr int o_dkr = o_kr + 4 * NT * R;             // [4][NT][R] their d keys accumulators           }
@@ -1225,51 +1230,104 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
   auto own = [&](int slot, int wv, int rho) -> float& { return OWN[(slot * 8 + wv) * R + rho]; };
 
   // ---- prefetch of the next processed step's inputs (registers; landed in LDS at the head of that step) ----
-  // result lanes 16+rho / 48+rho of every wave: the 12 record values of their unit; all threads: d out and alignment rows
-  constexpr int NDO = (R * R80 + NT - 1) / NT, NAL = (R * TTP + NT - 1) / NT;
-  float prec[12], pq = 0.f, pp1 = 0.f, pp2 = 0.f, pdo[NDO], pal[NAL];
-  unsigned nfn[R];   // raw sampling flags of step tp (parked like the rest: no arithmetic on them until they are used)
+  // LOADER WAVES.  Vector-memory loads return in order, so a poll issued behind a prefetch load cannot return before it: with every
+  // thread prefetching, the first exchange round after the prefetch paid the whole HBM round trip of the stash reads (1.2 us of
+  // the 13.2 us step; probe build TACO_P_NOPREF).  Waves 4-7 are therefore the only ones that prefetch -- during the softmax
+  // backward, which occupies waves < R only -- and they sit out the polling of the NEXT round (DQ: waves 0-3 poll for everybody),
+  // so their loads have the softmax, the DQ round and round OUT's mat-vec to land before they poll again.
+  // A loader thread owns a fixed job list (source = base + tp * stride, LDS destination), set up once:
+  //   J1  the 15 record scalars of each (unit, row): r,u,c,h' of three layers, q, and pre-net p1 / p2 of step tp + 1
+  //   J2  d out rows, J3 alignment rows, J4 the sampling flags
+  constexpr int NLD = NT / 2;
+  const bool loader = wave >= 4;
+  const int ltid = tid - NLD;
+  constexpr int NJ1 = (8 * R * 15 + NLD - 1) / NLD, NJ2 = (R * R80 + NLD - 1) / NLD, NJ3 = (R * TTP) / NLD;
+  static_assert(TTP == NLD, "one alignment position per loader thread and row");
+  int j1_base[NJ1], j1_dst[NJ1];   // dst: LDS index | condition << 20  (0 always, 1 tp > 0, 2 tp + 1 < Td, 3 never)
+  int j2_base[NJ2], j2_dst[NJ2];   // dst < 0: no job
+  int j3_base[NJ3];
+  int j4_row = 0;
+  if (loader) {
 #pragma unroll
-  for (int q = 0; q < R; ++q) nfn[q] = 0;
-  auto prefetch = [&](int tp) {          // tp = step whose data is fetched (>= 0)
-    const Lane<R, 32> M;
-    if (a.sample) {
-      static_for<R>([&](auto Q) {
-        constexpr int q = decltype(Q)::value;
-        nfn[q] = a.sample[(unsigned)(tp * B + brow.template get<q>())];
-      });
-    }
-    if (M.res) {
-      const unsigned bt = (unsigned)(rsel<R>(brow, M.rho) * Td + tp);
-      const float* st = stash + bt * kStRec;
-      const int u = peer * 8 + M.wave;
-#pragma unroll
-      for (int l = 0; l < 3; ++l) {
-        prec[4 * l + 0] = st[kStR + l * kDec + u];
-        prec[4 * l + 1] = st[kStU + l * kDec + u];
-        prec[4 * l + 2] = st[kStC + l * kDec + u];
-        prec[4 * l + 3] = tp > 0 ? (st - kStRec)[kStH + l * kDec + u] : 0.f;
+    for (int j = 0; j < NJ1; ++j) {
+      const int id = ltid + j * NLD;
+      const int wv = id / (R * 15), rem = id - wv * (R * 15), rho = rem / 15, k = rem - rho * 15;
+      const int u = peer * 8 + wv, row = rsel<R>(brow, rho);
+      int off, cond = 0, slot;
+      if (k < 12) {
+        const int l = k >> 2, kind = k & 3;
+        off = (kind == 0 ? kStR : kind == 1 ? kStU : kind == 2 ? kStC : kStH - kStRec) + l * kDec + u;
+        cond = kind == 3 ? 1 : 0;
+        slot = D::o_own + ((D::w_rec + k) * 8 + wv) * R + rho;
+      } else if (k == 12) {
+        off = kStQ + u;
+        slot = D::o_own + (D::w_q * 8 + wv) * R + rho;
+      } else if (k == 13) {
+        off = kStRec + kStP1 + u;
+        cond = 2;
+        slot = D::o_own + (D::w_p1 * 8 + wv) * R + rho;
+      } else {
+        off = kStRec + kStP2 + peer * 4 + (wv & 3);
+        cond = wv < 4 ? 2 : 3;
+        slot = D::o_p2m + (wv & 3) * R + rho;
       }
-      pq = st[kStQ + u];
-      // pre-net activations of step tp + 1 (their backward runs one step late, in step tp's FAN / DQ rounds)
-      pp1 = tp + 1 < Td ? st[kStRec + kStP1 + u] : 0.f;
-      pp2 = (tp + 1 < Td && M.wave < 4) ? st[kStRec + kStP2 + peer * 4 + M.wave] : 0.f;
+      if (id >= 8 * R * 15) cond = 3;
+      j1_base[j] = row * Td * kStRec + off;
+      j1_dst[j] = slot | (cond << 20);
     }
 #pragma unroll
-    for (int j = 0; j < NDO; ++j) {
-      const int i = M.tid + j * NT;           // (rho, c) of d out: i = rho * R80 + c
+    for (int j = 0; j < NJ2; ++j) {
+      const int i = ltid + j * NLD;           // (rho, c) of d out: i = rho * R80 + c
       const int qd = i / R80, cd = i - qd * R80;
-      pdo[j] = (qd < R) ? a.dout[(unsigned)(rsel<R>(brow, qd) * Td + tp) * R80 + cd] : 0.f;
+      j2_base[j] = rsel<R>(brow, qd < R ? qd : 0) * Td * R80 + cd;
+      j2_dst[j] = qd < R ? D::o_vo + cd * R + qd : -1;
     }
 #pragma unroll
-    for (int j = 0; j < NAL; ++j) {
-      const int i = M.tid + j * NT;           // (rho, s) of the alignments: i = rho * TTP + s
-      const int qa = i / TTP, sa = i - qa * TTP;
-      pal[j] = (qa < R && sa < Tt) ? a.align[(unsigned)(rsel<R>(brow, qa) * Td + tp) * (unsigned)Tt + sa] : 0.f;
+    for (int j = 0; j < NJ3; ++j) j3_base[j] = rsel<R>(brow, j) * Td * Tt + ltid;   // row j, position ltid
+    j4_row = rsel<R>(brow, ltid < R ? ltid : 0);
+  } else {
+#pragma unroll
+    for (int j = 0; j < NJ1; ++j) j1_base[j] = 0, j1_dst[j] = 3 << 20;
+#pragma unroll
+    for (int j = 0; j < NJ2; ++j) j2_base[j] = 0, j2_dst[j] = -1;
+#pragma unroll
+    for (int j = 0; j < NJ3; ++j) j3_base[j] = 0;
+  }
+  float p1v[NJ1], p2v[NJ2], p3v[NJ3];
+  unsigned p4v = 0;
+  auto prefetch = [&](int tp) {          // loader waves only; tp = step whose data is fetched (>= 0)
+#pragma unroll
+    for (int j = 0; j < NJ1; ++j) {
+      const int cond = j1_dst[j] >> 20;
+      p1v[j] = 0.f;
+      if (cond == 0 || (cond == 1 && tp > 0) || (cond == 2 && tp + 1 < Td)) p1v[j] = stash[(unsigned)(j1_base[j] + tp * kStRec)];
     }
+#pragma unroll
+    for (int j = 0; j < NJ2; ++j) {
+      p2v[j] = 0.f;
+      if (j2_dst[j] >= 0) p2v[j] = a.dout[(unsigned)(j2_base[j] + tp * R80)];
+    }
+#pragma unroll
+    for (int j = 0; j < NJ3; ++j) {
+      p3v[j] = 0.f;
+      if (ltid < Tt) p3v[j] = a.align[(unsigned)(j3_base[j] + tp * Tt)];
+    }
+    p4v = 0;
+    if (a.sample && ltid < R) p4v = a.sample[(unsigned)(tp * B + j4_row)];
+  };
+  auto land = [&]() {                    // loader waves: the prefetched values become this step's LDS inputs
+#pragma unroll
+    for (int j = 0; j < NJ1; ++j)
+      if ((j1_dst[j] >> 20) != 3) smem[j1_dst[j] & 0xfffff] = p1v[j];
+#pragma unroll
+    for (int j = 0; j < NJ2; ++j)
+      if (j2_dst[j] >= 0) smem[j2_dst[j]] = p2v[j];
+#pragma unroll
+    for (int j = 0; j < NJ3; ++j) ALS[j * TTP + ltid] = p3v[j];
+    if (ltid < R) smem[D::o_nf + ltid] = p4v ? 1.f : 0.f;
   };
   __builtin_amdgcn_s_waitcnt(0x0F70);   // prologue loads complete (see the forward kernel): no stray vmcnt(0) inside the loop
-  prefetch(Td - 1);
+  if (loader) prefetch(Td - 1);
 
   for (int t = Td - 1; t >= 0; --t) {
     X.epoch = (unsigned)(Td - t);
@@ -1280,34 +1338,8 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
     }
     tstamp(X);   // 0: step start
     const bool has_next = t + 1 < Td;
-    RV nfo;   // step t+1 of the row was fed by this step's output (sampled): its pre-net gradient flows back into this step
-    static_for<R>([&](auto Q) {
-      constexpr int q = decltype(Q)::value;
-      nfo.template at<q>() = has_next && nfn[q] != 0;
-    });
     // ---- 0. land the prefetched inputs ----
-    {
-      const Lane<R, 32> M;
-      if (M.res && M.lane < 32) {   // (lanes 16+rho; the twins 48+rho hold the same values)
-#pragma unroll
-        for (int k = 0; k < 12; ++k) own(D::w_rec + k, M.wave, M.rho) = prec[k];
-        own(D::w_q, M.wave, M.rho) = pq;
-        own(D::w_p1, M.wave, M.rho) = pp1;
-        if (M.wave < 4) smem[D::o_p2m + M.wave * R + M.rho] = pp2;
-      }
-#pragma unroll
-      for (int j = 0; j < NDO; ++j) {
-        const int i = M.tid + j * NT;
-        const int qd = i / R80, cd = i - qd * R80;
-        if (qd < R) VO[cd * R + qd] = pdo[j];
-      }
-#pragma unroll
-      for (int j = 0; j < NAL; ++j) {
-        const int i = M.tid + j * NT;
-        const int qa = i / TTP, sa = i - qa * TTP;
-        if (qa < R) ALS[qa * TTP + sa] = pal[j];
-      }
-    }
+    if (loader) land();
     lds_barrier();
     tstamp(X);   // 1: inputs landed
     // ---- 1. round FAN: d alignments[rho][s] = VWxc[s] . dx_{t+1}   (+ rider: d p2_{t+1} = mask (dx_{t+1} . Wi_p^T)) ----
@@ -1346,12 +1378,13 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
             smem[i + q] = v;
           },
           [&](int n, int q) { return n >= TTP || n < rsel<R>(len, q); });
-      // next processed step's inputs: issued HERE because every poll waits for all earlier vector-memory operations of its wave
-      // (one in-order counter), and the softmax / energy backward that follow are the longest poll-free stretch of a step
-      if (t > 0) prefetch(t - 1);
     }
     lds_barrier();
     tstamp(X);   // 2: FAN done
+    // next processed step's inputs: the loader waves issue them while waves < R run the softmax backward
+#ifndef TACO_P_NOPREF   // (timing probe: no next-step input loads at all -- results are garbage)
+    if (loader && t > 0) prefetch(t - 1);
+#endif
     // ---- 2. softmax backward: de = al * (dal - sum al dal)   (wave rho handles row rho) ----
     {
       const Lane<R, 64> L;
@@ -1418,14 +1451,16 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
         col_sum_all<R, 64>(ap);
         if (L.res) {
           g1 = own(D::w_p1, L.wave, L.rho) > 0.f ? km1c * pick<R>(ap, L.rho) : 0.f;
-          g1 = rsel<R>(nfo, L.rho) ? g1 : 0.f;    // d p1pre of step t+1 reaches this step's output only where that step was fed by it
+          g1 = smem[D::o_nf + L.rho] != 0.f ? g1 : 0.f;    // d p1pre of step t+1 reaches this step's output only where that step was fed by it (sampled)
           VO[(R80 + kAtt + u) * R + L.rho] = g1;
           put_granule<R>(X, Y3_DP1, u, L.rho, g1);
         }
       }
       // one poll loop: dq (region Y3_DQ) and, behind it, d p1 (Y3_DP1) -- adjacent regions, adjacent segments of the OUT input
-      gather<R, (512 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(X, Y3_DQ, has_next ? 512 : 256, [&](int n) { return ((n & 255) >> 3) == peer; },
-                                                           [&](int n, int q, float v) { VO[(R80 + n) * R + q] = v; });
+      // (polled by waves 0-3 for the whole workgroup: the loader waves' prefetch stays in flight across this round)
+      gather<R, (512 * (R >= 2 ? R / 2 : 1) + NT / 2 - 1) / (NT / 2), NT / 2>(
+          X, Y3_DQ, has_next ? 512 : 256, [&](int n) { return ((n & 255) >> 3) == peer; },
+          [&](int n, int q, float v) { VO[(R80 + n) * R + q] = v; });
       if (sbq >= 0) gst[(unsigned)(sbq * Td + t) * kGsRec + kGsQ + u] = pick<R>(dq, L.lane);
       if (sb64 >= 0) gst[(unsigned)(sb64 * Td + t) * kGsRec + kGsP1S + u] = g1;
     }
