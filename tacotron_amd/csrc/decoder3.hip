@@ -1225,6 +1225,9 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
     sb64 = (r64 >= 0 && r64 < R && rsel<R>(valid, r64)) ? rsel<R>(brow, r64) : -1;
     sb32 = (r32 >= 0 && r32 < R && rsel<R>(valid, r32)) ? rsel<R>(brow, r32) : -1;
     sbq = (lane < R && rsel<R>(valid, lane)) ? rsel<R>(brow, lane) : -1;
+#ifdef TACO_P_NOSTASH
+    sb64 = sb32 = sbq = -1;   // timing probe: no gradient-stash stores at all (results are garbage)
+#endif
   }
   float* const gst = a.gstash;
   auto own = [&](int slot, int wv, int rho) -> float& { return OWN[(slot * 8 + wv) * R + rho]; };
