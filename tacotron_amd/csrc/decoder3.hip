@@ -657,6 +657,24 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
   unsigned fon[R];
 #pragma unroll
   for (int q = 0; q < R; ++q) fon[q] = 0;
+  // Their addresses are `base + tn * stride` with launch-constant bases (-1: this lane has no such load): four registers, set
+  // up once, instead of ~100 address instructions per step in the instruction stream behind round E.
+  int pk_fr = -1, pk_p2 = -1, pk_k1 = -1, pk_k2 = -1;
+  if (TR) {
+    if (a.prein && lead && tid < kMel * R) {   // teacher frame of step tn (the pre-net weight gradient reads a.prein for every step)
+      const int q = tid / kMel, i = tid - q * kMel;
+      pk_fr = rsel<R>(brow, q) * Td * R80 + kMel * (RR - 1) + i;
+    }
+    if (tid < kPre2 * R) {
+      const int n = tid / R, q = tid - n * R;
+      pk_p2 = rsel<R>(brow, q) * Td * (int)ldp2 + n;
+    }
+    const int r64 = lane - 48;
+    if (r64 >= 0 && r64 < R) {
+      if (a.keep1) pk_k1 = rsel<R>(brow, r64) * Td * kPre1 + peer * 8 + wave;
+      if (a.keep2 && wave < 4) pk_k2 = rsel<R>(brow, r64) * Td * kPre2 + peer * 4 + wave;
+    }
+  }
   auto park_next = [&](int tn) {
     p2n = 0.f;
     k1n = k2n = 1;
@@ -668,26 +686,16 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
 #else
     if (TR && tn < Td) {
 #endif
-      const Lane<R, 64> L;
       if (a.sample) {   // step tn - 1's flags: row q of step tn is fed by that step's output
         static_for<R>([&](auto Q) {
           constexpr int q = decltype(Q)::value;
           fon[q] = a.sample[(unsigned)((tn - 1) * B + brow.template get<q>())];
         });
       }
-      if (a.prein && lead && L.tid < kMel * R) {   // teacher frame of step tn (the pre-net weight gradient reads a.prein for every step)
-        const int q = L.tid / kMel, i = L.tid - q * kMel;
-        frn = a.mel[(unsigned)(rsel<R>(brow, q) * Td + tn) * R80 + kMel * (RR - 1) + i];
-      }
-      if (L.tid < kPre2 * R) {
-        const int n = L.tid / R, q = L.tid - n * R;
-        p2n = a.pre2[(unsigned)(rsel<R>(brow, q) * Td + tn) * ldp2 + n];
-      }
-      if (L.res) {
-        const unsigned bt = (unsigned)(rsel<R>(brow, L.rho) * Td + tn);
-        if (a.keep1) k1n = a.keep1[bt * kPre1 + peer * 8 + L.wave];
-        if (a.keep2 && L.wave < 4) k2n = a.keep2[bt * kPre2 + peer * 4 + L.wave];
-      }
+      if (pk_fr >= 0) frn = a.mel[(unsigned)(pk_fr + tn * R80)];
+      if (pk_p2 >= 0) p2n = a.pre2[(unsigned)(pk_p2 + tn * (int)ldp2)];
+      if (pk_k1 >= 0) k1n = a.keep1[(unsigned)(pk_k1 + tn * kPre1)];
+      if (pk_k2 >= 0) k2n = a.keep2[(unsigned)(pk_k2 + tn * kPre2)];
     }
   };
   static_assert(kPre2 * 4 <= NT, "one parked p2 value per thread");

@@ -35,7 +35,7 @@ for nm in names:
     tot = [tot[0] + a, tot[1] + b, tot[2] + c_]
     i += 3
 rest = t[i:]
-print('E / softmax stamps since the OUT barrier [energies published, p2 rider done, gathered, barrier, softmax done, barrier]:', ['%.2f' % (x - t[i - 1]) for x in rest])
+print('E / softmax stamps since the OUT barrier [energies published, p2 rider done, gathered, deferred stores + next-step loads issued, barrier, softmax + barrier]:', ['%.2f' % (x - t[i - 1]) for x in rest])
 print('sum over G0..OUT: compute %.2f gather %.2f barrier %.2f; whole step %.2f us' % (tot[0], tot[1], tot[2], t[n - 1]))
 
 if not infer:
