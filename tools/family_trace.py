@@ -16,7 +16,7 @@ for _ in range(10): m.step()
 e1.record(); torch.cuda.synchronize()
 print('step %.3f ms' % (e0.elapsed_time(e1) / 10))
 lib.profile_read(2); lib.profile_read(3)
-lib.profile_enable(0b1100)
+lib.profile_enable(0b11100)   # bit 4: side stream off, every launch timed by itself
 N = 4
 for _ in range(N): m.step()
 torch.cuda.synchronize()
