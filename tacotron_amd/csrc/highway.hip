@@ -2,11 +2,19 @@
 //
 // The layers are row-wise: y = relu(x Wh + bh) * sigmoid(x Wt + bt) + x * (1 - sigmoid(x Wt + bt)), y feeds the next layer.
 // Run as separate GEMMs each layer is a 0.4-0.75 GFLOP launch with K = 128 that cannot fill the chip (16-26 TF measured)
-// plus an elementwise blend; here a workgroup keeps a 32-row tile resident in LDS and walks all layers, streaming the
-// (128 x 256) [Wt | Wh] of each layer through LDS in k-tiles.  MFMA tiling: 4 waves, wave w owns the 32 gate columns
-// [32w, 32w+32) AND the same 32 candidate columns (two 32x32 accumulators), so T and H of an element meet in one lane and
-// the blend is the epilogue.  The backward kernel does the same for the activation-gradient chain; the weight gradients
+// plus an elementwise blend; here a workgroup keeps a 32-row tile resident in LDS and walks all layers.  MFMA tiling: 4 waves,
+// wave w owns the 32 gate columns [32w, 32w+32) AND the same 32 candidate columns, so T and H of an element meet in one lane
+// and the blend is the epilogue.  The backward kernel does the same for the activation-gradient chain; the weight gradients
 // stay grouped TN GEMMs over the stashed d[T|H] (model.hip).
+//
+// Round 3: the weights no longer pass through LDS.  The B operand of v_mfma_f32_32x32x2_f32 is one float per lane --
+// W[k = 2j + (lane >> 5)][n = 32 wave + (lane & 31)] -- i.e. a coalesced global_load_dword straight into the register the MFMA
+// reads; every workgroup reads the same 128 KB per layer, so these are L2 hits.  They are fetched in chunks of 32 k-values
+// (16 or 32 registers per operand), one chunk ahead of the MFMAs that use them, across layer boundaries too: no W staging, no
+// barrier inside a layer's k-loop (round 2: one per 16 MFMAs, three ds_read_b32 in front of every MFMA pair, 12-15 % of the
+// matrix pipe).  Only the activations live in LDS (feature-major, pitch 33); two barriers per layer guard their update.
+// Barriers are LDS-only (`s_waitcnt lgkmcnt(0); s_barrier`): a __syncthreads() would drain the weight prefetch.
+// Accumulators are split in two independent chains so that back-to-back MFMAs never wait for each other's result.
 #include "common.h"
 #include "kernels.h"
 
@@ -14,17 +22,17 @@ namespace {
 
 constexpr int HB = 32;         // rows per workgroup
 constexpr int HC = 128;        // highway width
-constexpr int HK = 16;         // k-tile
-constexpr int HPAD = HB + 1;   // hT row pitch (conflict-free column reads)
-constexpr int WPITCH = 2 * HC + 8;
+constexpr int HPAD = HB + 1;   // activation row pitch, feature-major (conflict-free column reads)
+constexpr int FCK = 16;        // forward: k-pairs per chunk (32 k-values): 4 chunks per layer
+constexpr int BCK = 32;        // backward: k-pairs per chunk (64 of the 256 k-values): 4 chunks per layer
 
 // forward: grid = ceil(M / 32), block = 256
-__global__ __launch_bounds__(256) void highway_stack_fwd_kernel(HighwayStackArgs a) {
+__global__ __launch_bounds__(256, 2) void highway_stack_fwd_kernel(HighwayStackArgs a) {
   __shared__ __attribute__((aligned(16))) float hT[HC][HPAD];          // current layer input, feature-major
-  __shared__ __attribute__((aligned(16))) float Ws[2][HK][WPITCH];     // k-tile of [Wt | Wh]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lk = lane >> 5, li = lane & 31;
   const int m0 = blockIdx.x * HB;
+  const int n = 32 * wave + li;
 
   // input tile -> hT (transposed)
   {
@@ -41,75 +49,62 @@ __global__ __launch_bounds__(256) void highway_stack_fwd_kernel(HighwayStackArgs
       hT[k + 3][row] = v.w;
     }
   }
-  // W loader: 16 rows x 64 float4 per k-tile = 4 float4 per thread
-  const int w_c4 = tid & 63, w_r = tid >> 6;   // rows w_r + 4*i
-  // two register sets: a k-tile is fetched TWO iterations before it is written to LDS (one iteration of 16 MFMAs is shorter
-  // than an L2 round trip)
-  float4 rw[2][4];
-  auto load_w = [&](float4 (&r)[4], const float* wt, const float* wh, int k0) {
+  // B fragments of chunk (l, c): this lane's [Wt | Wh] values for k = 2 (16 c + j) + lk, column n
+  float wt_r[2][FCK], wh_r[2][FCK];
+  auto load_chunk = [&](float (&t)[FCK], float (&h)[FCK], int l, int c) {
+    const float* wt = a.wt[l] + (2 * c * FCK + lk) * HC + n;
+    const float* wh = a.wh[l] + (2 * c * FCK + lk) * HC + n;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = k0 + w_r + 4 * i;
-      const float* src = w_c4 < 32 ? wt + (int64_t)k * HC + w_c4 * 4 : wh + (int64_t)k * HC + (w_c4 - 32) * 4;
-      r[i] = *reinterpret_cast<const float4*>(src);
+    for (int j = 0; j < FCK; ++j) {
+      t[j] = wt[2 * j * HC];
+      h[j] = wh[2 * j * HC];
     }
   };
-  auto store_w = [&](const float4 (&r)[4], int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&Ws[buf][w_r + 4 * i][w_c4 * 4]) = r[i];
-  };
+  load_chunk(wt_r[0], wh_r[0], 0, 0);
 
+  f32x16 accT[2], accH[2];
 #pragma unroll
-  for (int l = 0; l < 4; ++l) {   // (unrolled: the per-layer pointer arrays of the argument struct stay in registers)
+  for (int i = 0; i < 16; ++i) {   // chunk i = (layer i >> 2, k-chunk i & 3); fully unrolled: register sets by parity
+    const int l = i >> 2, c = i & 3;
     if (l >= a.nl) break;
-    const float* wt = a.wt[l];
-    const float* wh = a.wh[l];
-    f32x16 accT, accH;
+    if (i + 1 < 16 && ((i + 1) >> 2) < a.nl) load_chunk(wt_r[(i + 1) & 1], wh_r[(i + 1) & 1], (i + 1) >> 2, (i + 1) & 3);
+    __builtin_amdgcn_sched_barrier(0);   // the prefetch stays HERE: the scheduler would sink each load to just in front of its MFMA
+    if (c == 0) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) accT[e] = accH[e] = 0.f;
-    constexpr int NKT = HC / HK;
-    load_w(rw[0], wt, wh, 0);
-    store_w(rw[0], 0);
-    load_w(rw[1], wt, wh, HK);        // tile 1 -> set 1
-    load_w(rw[0], wt, wh, 2 * HK);    // tile 2 -> set 0
-    __syncthreads();   // also publishes hT (first layer: the input tile; later layers: the previous layer's output)
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      const int buf = kt & 1;
-#pragma unroll
-      for (int kk = 0; kk < HK; kk += 2) {
-        const float av = hT[kt * HK + kk + lk][li];
-        const float bt = Ws[buf][kk + lk][32 * wave + li];
-        const float bh = Ws[buf][kk + lk][HC + 32 * wave + li];
-        accT = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bt, accT, 0, 0, 0);
-        accH = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bh, accH, 0, 0, 0);
-      }
-      if (kt + 1 < NKT) store_w(rw[(kt + 1) & 1], buf ^ 1);                       // tile kt+1 (fetched two iterations ago)
-      if (kt + 3 < NKT) load_w(rw[(kt + 1) & 1], wt, wh, (kt + 3) * HK);          // tile kt+3 into the freed set
-      __syncthreads();
+      for (int e = 0; e < 16; ++e) accT[0][e] = accT[1][e] = accH[0][e] = accH[1][e] = 0.f;
+      lds_barrier();   // hT holds this layer's input (first layer: the input tile; later: the previous layer's output)
     }
-    // epilogue: C layout col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
-    const int n = 32 * wave + li;
-    const float bT = a.bt[l][n], bH = a.bh[l][n];
-    float y[16];
+    float av[FCK];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int r = (e & 3) + 8 * (e >> 2) + 4 * lk;
-      const int m = m0 + r;
-      const float T = sigmoid_f(accT[e] + bT);
-      const float H = fmaxf(accH[e] + bH, 0.f);
-      const float h = hT[n][r];
-      y[e] = H * T + h * (1.f - T);
-      if (m < a.M) {
-        a.th[l][(int64_t)m * 2 * HC + n] = T;
-        a.th[l][(int64_t)m * 2 * HC + HC + n] = H;
-        a.y[l][(int64_t)m * HC + n] = y[e];
-      }
+    for (int j = 0; j < FCK; ++j) av[j] = hT[2 * (c * FCK + j) + lk][li];
+#pragma unroll
+    for (int j = 0; j < FCK; ++j) {
+      accT[j & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], wt_r[i & 1][j], accT[j & 1], 0, 0, 0);
+      accH[j & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], wh_r[i & 1][j], accH[j & 1], 0, 0, 0);
     }
-    __syncthreads();   // every lane has read its inputs from hT
+    if (c == 3) {
+      // epilogue: C layout col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+      const float bT = a.bt[l][n], bH = a.bh[l][n];
+      float y[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) hT[n][(e & 3) + 8 * (e >> 2) + 4 * lk] = y[e];
-    // (the barrier at the top of the next layer's k-loop publishes them)
+      for (int e = 0; e < 16; ++e) {
+        const int r = (e & 3) + 8 * (e >> 2) + 4 * lk;
+        const int m = m0 + r;
+        const float T = sigmoid_f(accT[0][e] + accT[1][e] + bT);
+        const float H = fmaxf(accH[0][e] + accH[1][e] + bH, 0.f);
+        const float h = hT[n][r];
+        y[e] = H * T + h * (1.f - T);
+        if (m < a.M) {
+          a.th[l][(int64_t)m * 2 * HC + n] = T;
+          a.th[l][(int64_t)m * 2 * HC + HC + n] = H;
+          a.y[l][(int64_t)m * HC + n] = y[e];
+        }
+      }
+      lds_barrier();   // every lane has read its inputs from hT
+#pragma unroll
+      for (int e = 0; e < 16; ++e) hT[n][(e & 3) + 8 * (e >> 2) + 4 * lk] = y[e];
+      // (the barrier at the head of the next layer publishes them)
+    }
   }
 }
 
@@ -117,16 +112,15 @@ __global__ __launch_bounds__(256) void highway_stack_fwd_kernel(HighwayStackArgs
 //   dT = g (H - x) T (1 - T);  dH = g T [H > 0];  g' = [dT | dH] . [Wt ; Wh]^T + g (1 - T)
 // wT[l] is the (256, 128) transposed pair [Wt^T ; Wh^T] built by prepare_transposes.  grid = ceil(M / 32), block = 256,
 // dynamic LDS (kHwBwdSmem bytes).
-constexpr int WBP = HC + 4;   // pitch of the (16 x 128) k-tile of wT
-constexpr size_t kHwBwdSmem = sizeof(float) * ((size_t)2 * HC * HPAD + (size_t)HC * HPAD + (size_t)2 * HK * WBP);
-__global__ __launch_bounds__(256) void highway_stack_bwd_kernel(HighwayStackBwdArgs a) {
+constexpr size_t kHwBwdSmem = sizeof(float) * ((size_t)2 * HC * HPAD + (size_t)HC * HPAD);
+__global__ __launch_bounds__(256, 2) void highway_stack_bwd_kernel(HighwayStackBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float hw_smem[];
   float (*dT)[HPAD] = reinterpret_cast<float (*)[HPAD]>(hw_smem);                                  // [256][33] d[T|H], k-major
   float (*gT)[HPAD] = reinterpret_cast<float (*)[HPAD]>(hw_smem + 2 * HC * HPAD);                  // [128][33] dL/dy of the layer
-  float (*Ws)[HK][WBP] = reinterpret_cast<float (*)[HK][WBP]>(hw_smem + 3 * HC * HPAD);            // [2][16][132]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lk = lane >> 5, li = lane & 31;
   const int m0 = blockIdx.x * HB;
+  const int n = 32 * wave + li;
   // element mapping of the pre-processing pass: thread -> (row pr + 8*i, 4 columns at pc4*4)
   const int pr = tid >> 5, pc4 = tid & 31;
   // incoming gradient tile -> gT
@@ -140,88 +134,84 @@ __global__ __launch_bounds__(256) void highway_stack_bwd_kernel(HighwayStackBwdA
     gT[pc4 * 4 + 2][r] = v.z;
     gT[pc4 * 4 + 3][r] = v.w;
   }
-  const int w_c4 = tid & 31, w_r = tid >> 5;   // k-tile loader: 16 rows x 32 float4 = 2 float4 per thread
-  float4 rw[2][2];   // two register sets, tiles fetched two iterations ahead (see the forward kernel)
-  auto load_w = [&](float4 (&r)[2], const float* w, int k0) {
+  // B fragments of chunk (l, c): wT[l][k = 2 (32 c + j) + lk][n]
+  float w_r[2][BCK];
+  auto load_chunk = [&](float (&w)[BCK], int l, int c) {
+    const float* src = a.wT[l] + (2 * c * BCK + lk) * HC + n;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) r[i] = *reinterpret_cast<const float4*>(w + (int64_t)(k0 + w_r + 8 * i) * HC + w_c4 * 4);
+    for (int j = 0; j < BCK; ++j) w[j] = src[2 * j * HC];
   };
-  auto store_w = [&](const float4 (&r)[2], int buf) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&Ws[buf][w_r + 8 * i][w_c4 * 4]) = r[i];
-  };
-  __syncthreads();
+  const int nl = a.nl;
+  load_chunk(w_r[0], nl - 1, 0);
+  lds_barrier();
 
+  f32x16 acc[2];
 #pragma unroll
-  for (int l = 3; l >= 0; --l) {
-    if (l >= a.nl) continue;
-    const float* w = a.wT[l];
-    load_w(rw[0], w, 0);
-    // ---- pre-processing: d[T|H] of this layer from g, the stashed gates and the layer input ----
+  for (int i = 0; i < 16; ++i) {   // chunk i = (layer 3 - (i >> 2), k-chunk i & 3); layers above nl - 1 do not exist
+    const int l = 3 - (i >> 2), c = i & 3;
+    if (l >= nl) continue;
+    if (c == 0) {
+      // ---- pre-processing: d[T|H] of this layer from g, the stashed gates and the layer input ----
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = pr + 8 * i, m = m0 + r;
-      float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f), h4 = t4, x4 = t4;
-      if (m < a.M) {
-        t4 = *reinterpret_cast<const float4*>(a.th[l] + (int64_t)m * 2 * HC + pc4 * 4);
-        h4 = *reinterpret_cast<const float4*>(a.th[l] + (int64_t)m * 2 * HC + HC + pc4 * 4);
-        x4 = *reinterpret_cast<const float4*>(a.x[l] + (int64_t)m * HC + pc4 * 4);
-      }
-      const float tt[4] = {t4.x, t4.y, t4.z, t4.w}, hh[4] = {h4.x, h4.y, h4.z, h4.w}, xx[4] = {x4.x, x4.y, x4.z, x4.w};
-      float dt[4], dh[4];
+      for (int q = 0; q < 4; ++q) {
+        const int r = pr + 8 * q, m = m0 + r;
+        float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f), h4 = t4, x4 = t4;
+        if (m < a.M) {
+          t4 = *reinterpret_cast<const float4*>(a.th[l] + (int64_t)m * 2 * HC + pc4 * 4);
+          h4 = *reinterpret_cast<const float4*>(a.th[l] + (int64_t)m * 2 * HC + HC + pc4 * 4);
+          x4 = *reinterpret_cast<const float4*>(a.x[l] + (int64_t)m * HC + pc4 * 4);
+        }
+        const float tt[4] = {t4.x, t4.y, t4.z, t4.w}, hh[4] = {h4.x, h4.y, h4.z, h4.w}, xx[4] = {x4.x, x4.y, x4.z, x4.w};
+        float dt[4], dh[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float g = gT[pc4 * 4 + j][r];
-        dt[j] = g * (hh[j] - xx[j]) * tt[j] * (1.f - tt[j]);
-        dh[j] = hh[j] > 0.f ? g * tt[j] : 0.f;
-        dT[pc4 * 4 + j][r] = dt[j];
-        dT[HC + pc4 * 4 + j][r] = dh[j];
+        for (int j = 0; j < 4; ++j) {
+          const float g = gT[pc4 * 4 + j][r];
+          dt[j] = g * (hh[j] - xx[j]) * tt[j] * (1.f - tt[j]);
+          dh[j] = hh[j] > 0.f ? g * tt[j] : 0.f;
+          dT[pc4 * 4 + j][r] = dt[j];
+          dT[HC + pc4 * 4 + j][r] = dh[j];
+        }
+        if (m < a.M) {
+          *reinterpret_cast<float4*>(a.dth[l] + (int64_t)m * 2 * HC + pc4 * 4) = make_float4(dt[0], dt[1], dt[2], dt[3]);
+          *reinterpret_cast<float4*>(a.dth[l] + (int64_t)m * 2 * HC + HC + pc4 * 4) = make_float4(dh[0], dh[1], dh[2], dh[3]);
+        }
       }
-      if (m < a.M) {
-        *reinterpret_cast<float4*>(a.dth[l] + (int64_t)m * 2 * HC + pc4 * 4) = make_float4(dt[0], dt[1], dt[2], dt[3]);
-        *reinterpret_cast<float4*>(a.dth[l] + (int64_t)m * 2 * HC + HC + pc4 * 4) = make_float4(dh[0], dh[1], dh[2], dh[3]);
-      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[0][e] = acc[1][e] = 0.f;
+      lds_barrier();
     }
-    store_w(rw[0], 0);
-    load_w(rw[1], w, HK);
-    load_w(rw[0], w, 2 * HK);
-    __syncthreads();
+    // the next chunk's weights fly under this chunk's MFMAs (the last chunk of a layer fetches the first of the layer below)
+    if (i + 1 < 16) load_chunk(w_r[(i + 1) & 1], 3 - ((i + 1) >> 2), (i + 1) & 3);
+    __builtin_amdgcn_sched_barrier(0);   // the prefetch stays HERE (see the forward kernel)
     // ---- g' = d[T|H] . wT  (K = 256) ----
-    f32x16 acc;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    constexpr int NKT = 2 * HC / HK;
+    for (int hhalf = 0; hhalf < 2; ++hhalf) {
+      float av[BCK / 2];
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      const int buf = kt & 1;
+      for (int j = 0; j < BCK / 2; ++j) av[j] = dT[2 * (c * BCK + hhalf * (BCK / 2) + j) + lk][li];
 #pragma unroll
-      for (int kk = 0; kk < HK; kk += 2) {
-        const float av = dT[kt * HK + kk + lk][li];
-        const float bv = Ws[buf][kk + lk][32 * wave + li];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+      for (int j = 0; j < BCK / 2; ++j)
+        acc[j & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], w_r[i & 1][hhalf * (BCK / 2) + j], acc[j & 1], 0, 0, 0);
+    }
+    if (c == 3) {
+      // ---- epilogue: + g (1 - T); the result is the next (lower) layer's g ----
+      float gn[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int r = (e & 3) + 8 * (e >> 2) + 4 * lk;
+        const int m = m0 + r;
+        const float t = m < a.M ? a.th[l][(int64_t)m * 2 * HC + n] : 0.f;
+        gn[e] = acc[0][e] + acc[1][e] + gT[n][r] * (1.f - t);
       }
-      if (kt + 1 < NKT) store_w(rw[(kt + 1) & 1], buf ^ 1);
-      if (kt + 3 < NKT) load_w(rw[(kt + 1) & 1], w, (kt + 3) * HK);
-      __syncthreads();
-    }
-    // ---- epilogue: + g (1 - T); the result is the next (lower) layer's g ----
-    const int n = 32 * wave + li;
-    float gn[16];
+      lds_barrier();   // every lane has read the old g (and every wave is done with dT)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int r = (e & 3) + 8 * (e >> 2) + 4 * lk;
-      const int m = m0 + r;
-      const float t = m < a.M ? a.th[l][(int64_t)m * 2 * HC + n] : 0.f;
-      gn[e] = acc[e] + gT[n][r] * (1.f - t);
+      for (int e = 0; e < 16; ++e) {
+        const int r = (e & 3) + 8 * (e >> 2) + 4 * lk;
+        gT[n][r] = gn[e];
+        if (l == 0 && m0 + r < a.M) a.gout[(int64_t)(m0 + r) * HC + n] = gn[e];
+      }
+      lds_barrier();
     }
-    __syncthreads();   // every lane has read the old g
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int r = (e & 3) + 8 * (e >> 2) + 4 * lk;
-      gT[n][r] = gn[e];
-      if (l == 0 && m0 + r < a.M) a.gout[(int64_t)(m0 + r) * HC + n] = gn[e];
-    }
-    __syncthreads();
   }
 }
 
