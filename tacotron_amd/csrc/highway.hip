@@ -14,6 +14,9 @@
 // barrier inside a layer's k-loop (round 2: one per 16 MFMAs, three ds_read_b32 in front of every MFMA pair, 12-15 % of the
 // matrix pipe).  Only the activations live in LDS (feature-major, pitch 33); two barriers per layer guard their update.
 // Barriers are LDS-only (`s_waitcnt lgkmcnt(0); s_barrier`): a __syncthreads() would drain the weight prefetch.
+// Measured around it (same box): the stash stores of [T | H] and y are 10 of the forward kernel's 39 us at M = 6400 (39 MB per
+// launch; issuing them in three batches behind the next layer's prefetches changed nothing -- it is write bandwidth, not the
+// in-order counter); reading all A fragments of a layer in one burst changed nothing either.
 // Accumulators are split in two independent chains so that back-to-back MFMAs never wait for each other's result.
 #include "common.h"
 #include "kernels.h"
@@ -90,13 +93,15 @@ __global__ __launch_bounds__(256, 2) void highway_stack_fwd_kernel(HighwayStackA
       for (int e = 0; e < 16; ++e) {
         const int r = (e & 3) + 8 * (e >> 2) + 4 * lk;
         const int m = m0 + r;
-        const float T = sigmoid_f(accT[0][e] + accT[1][e] + bT);
+        const float T = sigmoid_fast(accT[0][e] + accT[1][e] + bT);   // v_exp + v_rcp, as in the decoder kernels
         const float H = fmaxf(accH[0][e] + accH[1][e] + bH, 0.f);
         const float h = hT[n][r];
         y[e] = H * T + h * (1.f - T);
         if (m < a.M) {
-          a.th[l][(int64_t)m * 2 * HC + n] = T;
-          a.th[l][(int64_t)m * 2 * HC + HC + n] = H;
+          if (a.th[l]) {   // gate / candidate stash for the backward pass (null at inference)
+            a.th[l][(int64_t)m * 2 * HC + n] = T;
+            a.th[l][(int64_t)m * 2 * HC + HC + n] = H;
+          }
           a.y[l][(int64_t)m * HC + n] = y[e];
         }
       }

@@ -63,7 +63,7 @@ int gemm2_min_tiles();   // TACO_GEMM2_MIN_TILES (0 disables gemm2.hip)
 struct HighwayStackArgs {
   const float* x = nullptr;    // (M,128) input of the first layer
   const float* wt[4]; const float* bt[4]; const float* wh[4]; const float* bh[4];
-  float* th[4];
+  float* th[4];               // (M,256) [T | H] stash per layer, or null (inference: no backward pass will read it)
   float* y[4];
   int M = 0, nl = 0;
 };

@@ -202,7 +202,7 @@ int cbhg_fwd(const float* P, const CbhgP& c, const float* x, int B, int T, const
     ha.x = w.hx[0]; ha.M = M; ha.nl = 4;
     for (int l = 0; l < 4; ++l) {
       ha.wt[l] = P + c.hwT[l].w; ha.bt[l] = P + c.hwT[l].b; ha.wh[l] = P + c.hwH[l].w; ha.bh[l] = P + c.hwH[l].b;
-      ha.th[l] = w.th[l]; ha.y[l] = w.h[l + 1];
+      ha.th[l] = keep_ruc ? w.th[l] : nullptr; ha.y[l] = w.h[l + 1];
     }
     TACO_TRY(launch_highway_stack_fwd(ha, s));
   }
