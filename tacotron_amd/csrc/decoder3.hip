@@ -1631,7 +1631,7 @@ int launch3(DecFwdArgs& a, int ncl, hipStream_t s) {
   if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, NT, smem);
   if (e != hipSuccess || (int64_t)cus * per_cu < (int64_t)8 * P3) return TACO_ENOTFOUND;
-  e = hipMemsetAsync(a.xchg, 0, (size_t)decoder_xchg_bytes(a.B, a.Tt), s);
+  if (!a.xchg_zeroed) e = hipMemsetAsync(a.xchg, 0, (size_t)decoder_xchg_bytes(a.B, a.Tt), s);
   if (e != hipSuccess) {
     taco_set_error("decoder3_fwd: memset: %s", hipGetErrorString(e));
     return TACO_ELAUNCH;

@@ -297,6 +297,7 @@ struct DecFwdArgs {
   int P;                 // cluster width (workgroups per row); chosen by launch_decoder_fwd
   int fakew = 0;         // timing probe (TACO_DEC_FAKEW): see Xchg::fake
   int lres0 = 0, lres1 = 0;  // launch-resident weight rows (LDS) of the GRU-2 / GRU-3 gate mat-vecs; chosen by launch_decoder_fwd
+  int xchg_zeroed = 0;       // 1: the caller's batched init launch has zeroed the exchange area already (decoder3.hip only)
   int xcc_table_ofs = 0;     // decoder3.hip: int offset, inside the exchange area, of the 256-entry placement table
   int fast_ok = 1;           // decoder3.hip: 0 forces the placement-independent (agent-scope) publish form (TACO_DEC_V3_AGENT=1)
 };

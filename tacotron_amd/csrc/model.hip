@@ -404,6 +404,9 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
     const int NF = dec_fan_cols(r);
     TACO_TRY(ib.fill2d(ws + W.bc_fa + R80, kDec, NF - R80, NF));
   }
+  // the decoder's exchange area (granule epochs of the previous launch): zeroed by the same launch; decoder3.hip then issues no
+  // memset in front of the forward decoder (decoder.hip, the fallback, still zeroes for itself)
+  TACO_TRY(ib.fill(ws + W.xchg, decoder_xchg_bytes(B, Tt) / 4));
   TACO_TRY(build_dec_composites(P, PL, W, ws, r, ib, sd));
   if (train) {
     // everything the backward pass derives from the parameters alone (transposed / tap-flipped weight copies, transposed
@@ -492,6 +495,7 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
   //  guarded Adam update and to the host's next check, however rarely the host looks)
   {
     const int slot = prof_begin(0, s);
+    da.xchg_zeroed = 1;
     int rc = launch_decoder3_fwd(da, s);
     if (rc == TACO_ENOTFOUND) rc = launch_decoder_fwd(da, s);
     TACO_TRY(rc);
