@@ -746,17 +746,20 @@ def test_inference_is_graph_capturable(built_lib):
     m.check()
 
 
-@pytest.mark.parametrize('B,mode', [(11, 'default'), (12, 'agent'), (20, 'default'), (5, 'v3_off'), (32, 'agent')])
-def test_decoder3_cluster_geometries(built_lib, B, mode, monkeypatch):
+@pytest.mark.parametrize('B,mode,r', [(11, 'default', 2), (12, 'agent', 2), (20, 'default', 2), (5, 'v3_off', 2), (32, 'agent', 2),
+                                      (20, 'default', 5), (9, 'default', 5)])
+def test_decoder3_cluster_geometries(built_lib, B, mode, r, monkeypatch):
     """decoder3.hip (clusters of 32 workgroups x R rows, register-resident weights): R = 1 / 2 / 4 rows per cluster incl. a
     partially filled last cluster (B = 11: six clusters of two rows, the last with one valid row; B = 20: five clusters of
     four), the placement-independent agent-scope exchange forced (TACO_DEC_V3_AGENT=1: what a cluster that straddles XCDs
-    uses), and the decoder.hip fall-back (TACO_DEC_V3=0) -- forward, backward and inference against the fp64 restatement."""
+    uses), and the decoder.hip fall-back (TACO_DEC_V3=0) -- forward, backward and inference against the fp64 restatement.
+    r = 5 (BASELINE configs[0]'s reduction factor) at four and two rows per cluster: the widest instantiations of both kernels
+    (400 output columns per step; 7 d-out prefetch jobs per loader thread, 252 VGPRs in the backward kernel)."""
     if mode == 'agent':
         monkeypatch.setenv('TACO_DEC_V3_AGENT', '1')
     if mode == 'v3_off':
         monkeypatch.setenv('TACO_DEC_V3', '0')
-    r, V, Tt, Td = 2, 33, 41, 9
+    V, Tt, Td = 33, 41, 9
     p = on.init_params(V, r, seed=8, perturb=0.2)
     inp, masks = small_case(r=r, V=V, B=B, Tt=Tt, Td=Td, seed=40 + B)
     R = Runner(built_lib, B, Tt, Td, r, V)
