@@ -956,7 +956,11 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     TACO_TRY(ib.fill(ws + W.bc_g, W.bc_cp + kPre1 - W.bc_g));
     TACO_TRY(ib.fill(ws + W.xchg, decoder_xchg_bytes(B, Tt) / 4));
     if (own_dx) {
-      TACO_TRY(ib.fill(ws + W.post_dx, (int64_t)M2 * kMel));
+      // the post-net's input-gradient accumulator starts from the direct L1 term sign(s2s - mel) (left by the forward pass)
+      // instead of from zero: d seq2seq_output is complete when the K-way bank backward has added its part -- no add pass.
+      // (Deterministic mode overwrites the accumulator with a fixed-order chain and keeps the explicit add.)
+      if (!taco_deterministic()) TACO_TRY(ib.copy(ws + W.post_dx, ws + W.ds2s, (int64_t)M2 * kMel));
+      else TACO_TRY(ib.fill(ws + W.post_dx, (int64_t)M2 * kMel));
       if (!PL.enc.spk) TACO_TRY(ib.fill(ws + W.enc_dx, (int64_t)M1 * kCb));
     }
     TACO_TRY(launch_init_batch(ib, s));
@@ -1002,7 +1006,8 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
   TACO_TRY(rc_post);
   // d seq2seq_output = sign(s2s - mel) + post-net path
   float* dS2S = ws + W.ds2s_tot;
-  TACO_TRY(launch_add(ws + W.ds2s, dPostIn, dS2S, (int64_t)MD * R80, s));
+  if (side_tn && own_dx && !taco_deterministic()) dS2S = dPostIn;   // (accumulated on top of the L1 term, see the init launch)
+  else TACO_TRY(launch_add(ws + W.ds2s, dPostIn, dS2S, (int64_t)MD * R80, s));
   SideStream& ssx = side_stream();
   if (defer) {
     // side: wait for the producers of the deferred operands (everything enqueued on `s` so far), then the grouped launches
@@ -1096,7 +1101,7 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
       ConvGemmProblem p = dense_problem(gs + kGsX, kGsRec, ws + W.bc_fa, dec_fan_cols(r), nullptr, gs + kGsO, kGsRec, MD, R80, kDec,
                                         TACO_ACT_NONE);
       p.T = Td; p.pad_l = -1;
-      p.residual = ws + W.ds2s_tot; p.ldr = R80;
+      p.residual = dS2S; p.ldr = R80;
       TACO_TRY(launch_conv_gemm(p, s));
     }
     // d attention_v = sum over batch rows of the kernel's per-row partials, in row order (no atomics)
