@@ -157,15 +157,23 @@ __global__ __launch_bounds__(256, 2) void highway_stack_bwd_kernel(HighwayStackB
     if (l >= nl) continue;
     if (c == 0) {
       // ---- pre-processing: d[T|H] of this layer from g, the stashed gates and the layer input ----
+      // (all twelve loads first: issued between the stores of the previous rows they would have to queue behind them -- the
+      //  compiler cannot prove that dth does not alias th / x, and vector-memory operations complete in order)
+      float4 t4v[4], h4v[4], x4v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = m0 + pr + 8 * q;
+        t4v[q] = h4v[q] = x4v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < a.M) {
+          t4v[q] = *reinterpret_cast<const float4*>(a.th[l] + (int64_t)m * 2 * HC + pc4 * 4);
+          h4v[q] = *reinterpret_cast<const float4*>(a.th[l] + (int64_t)m * 2 * HC + HC + pc4 * 4);
+          x4v[q] = *reinterpret_cast<const float4*>(a.x[l] + (int64_t)m * HC + pc4 * 4);
+        }
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int r = pr + 8 * q, m = m0 + r;
-        float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f), h4 = t4, x4 = t4;
-        if (m < a.M) {
-          t4 = *reinterpret_cast<const float4*>(a.th[l] + (int64_t)m * 2 * HC + pc4 * 4);
-          h4 = *reinterpret_cast<const float4*>(a.th[l] + (int64_t)m * 2 * HC + HC + pc4 * 4);
-          x4 = *reinterpret_cast<const float4*>(a.x[l] + (int64_t)m * HC + pc4 * 4);
-        }
+        const float4 t4 = t4v[q], h4 = h4v[q], x4 = x4v[q];
         const float tt[4] = {t4.x, t4.y, t4.z, t4.w}, hh[4] = {h4.x, h4.y, h4.z, h4.w}, xx[4] = {x4.x, x4.y, x4.z, x4.w};
         float dt[4], dh[4];
 #pragma unroll

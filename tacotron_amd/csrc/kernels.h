@@ -68,6 +68,23 @@ struct HighwayStackArgs {
   int M = 0, nl = 0;
 };
 int launch_highway_stack_fwd(const HighwayStackArgs& a, hipStream_t s);
+// prenet.hip: the encoder pre_net (two dense + ReLU + dropout layers) and its activation-gradient chain as one launch each.
+//   forward : x (M,256) -> y1 = drop1(relu(x w1 + b1)) (M,256) -> y2 = drop2(relu(y1 w2 + b2)) (M,128)
+//   backward: x = d p2 (M,128), y2_in = p2, y1_in = p1, w1 = W2^T (128,256), w2 = W1^T (256,256):
+//             x_out = dz2 (M,128), y1 = dz1 (M,256), y2 = d input (M,256); keep1 / keep2 are the masks of layer 1 / layer 2
+struct PrenetArgs {
+  const float* x = nullptr;
+  const float* w1 = nullptr; const float* b1 = nullptr;
+  const float* w2 = nullptr; const float* b2 = nullptr;
+  const uint8_t* keep1 = nullptr; const uint8_t* keep2 = nullptr;   // (M, width of layer 1 / layer 2) or null: no dropout
+  const float* y1_in = nullptr; const float* y2_in = nullptr;       // backward only: the forward activations (ReLU masks)
+  float* x_out = nullptr;                                            // backward only
+  float* y1 = nullptr; float* y2 = nullptr;
+  int M = 0;
+  long long* trace = nullptr;   // probe builds (-DTACO_PN_TRACE) only
+};
+int launch_prenet_fwd(const PrenetArgs& a, hipStream_t s);
+int launch_prenet_bwd(const PrenetArgs& a, hipStream_t s);
 struct HighwayStackBwdArgs {
   const float* g = nullptr;    // (M,128) dL/d output of the last layer
   const float* wT[4];          // (256,128) [Wt^T ; Wh^T] per layer

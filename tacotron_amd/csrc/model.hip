@@ -431,7 +431,14 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
   }
   // embedding + encoder pre_net (tacotron.py:111-114, 128)
   TACO_TRY(launch_embedding(P + PL.emb, text, ws + W.emb, M1, sh.V, s));
-  {
+  if (!getenv("TACO_NO_PRENET_FUSE")) {   // both layers in one launch (prenet.hip)
+    PrenetArgs pa;
+    pa.x = ws + W.emb; pa.w1 = P + PL.enc_pre1.w; pa.b1 = P + PL.enc_pre1.b; pa.w2 = P + PL.enc_pre2.w; pa.b2 = P + PL.enc_pre2.b;
+    pa.keep1 = train ? ek1 : nullptr; pa.keep2 = train ? ek2 : nullptr;
+    pa.y1 = ws + W.p1; pa.y2 = ws + W.p2; pa.M = M1;
+    pa.trace = getenv("TACO_PN_TRACE") ? reinterpret_cast<long long*>(ws + W.err + 400) : nullptr;
+    TACO_TRY(launch_prenet_fwd(pa, s));
+  } else {
     ConvGemmProblem p = dense_problem(ws + W.emb, kEmbed, P + PL.enc_pre1.w, kPre1, P + PL.enc_pre1.b, ws + W.p1, kPre1, M1,
                                       kPre1, kEmbed, TACO_ACT_RELU);
     p.keep = train ? ek1 : nullptr;
@@ -1199,16 +1206,26 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
   if (PL.enc.spk) TACO_TRY(launch_embedding_bwd(ws + W.dspk_e, speaker, G + PL.spk_embed, B, shape->S, s, 16));
   // ---- encoder pre_net + embedding ----
   float* dz2 = pre_dz2;
-  TACO_TRY(launch_act_bwd(ws + W.p2, dP2, enc_keep2, dz2, (int64_t)M1 * kPre2, TACO_ACT_RELU, s));
-  TACO_TRY(tn(ws + W.p1, kPre1, kPre1, dz2, kPre2, kPre2, G + PL.enc_pre2.w, kPre2, M1, M1, 0, s, 1, G + PL.enc_pre2.b));
   float* dz1 = pre_dz1;
-  TACO_TRY(launch_conv_gemm(dense_problem(dz2, kPre2, PT + TL.enc_pre2, kPre1, nullptr, dz1, kPre1, M1, kPre1, kPre2,
-                                          TACO_ACT_NONE), s));
-  TACO_TRY(launch_act_bwd(ws + W.p1, dz1, enc_keep1, dz1, (int64_t)M1 * kPre1, TACO_ACT_RELU, s));
-  TACO_TRY(tn(ws + W.emb, kEmbed, kEmbed, dz1, kPre1, kPre1, G + PL.enc_pre1.w, kPre1, M1, M1, 0, s, 1, G + PL.enc_pre1.b));
   float* dEmb = pre_demb;
-  TACO_TRY(launch_conv_gemm(dense_problem(dz1, kPre1, PT + TL.enc_pre1, kEmbed, nullptr, dEmb, kEmbed, M1, kEmbed, kPre1,
-                                          TACO_ACT_NONE), s));
+  if (!getenv("TACO_NO_PRENET_FUSE")) {
+    // the activation-gradient chain d p2 -> dz2 -> dz1 -> d embedding in one launch (prenet.hip); the two weight gradients follow
+    PrenetArgs pa;
+    pa.x = dP2; pa.x_out = dz2; pa.y2_in = ws + W.p2; pa.y1_in = ws + W.p1; pa.keep2 = enc_keep2; pa.keep1 = enc_keep1;
+    pa.w1 = PT + TL.enc_pre2; pa.w2 = PT + TL.enc_pre1; pa.y1 = dz1; pa.y2 = dEmb; pa.M = M1;
+    TACO_TRY(launch_prenet_bwd(pa, s));
+    TACO_TRY(tn(ws + W.p1, kPre1, kPre1, dz2, kPre2, kPre2, G + PL.enc_pre2.w, kPre2, M1, M1, 0, s, 1, G + PL.enc_pre2.b));
+    TACO_TRY(tn(ws + W.emb, kEmbed, kEmbed, dz1, kPre1, kPre1, G + PL.enc_pre1.w, kPre1, M1, M1, 0, s, 1, G + PL.enc_pre1.b));
+  } else {
+    TACO_TRY(launch_act_bwd(ws + W.p2, dP2, enc_keep2, dz2, (int64_t)M1 * kPre2, TACO_ACT_RELU, s));
+    TACO_TRY(tn(ws + W.p1, kPre1, kPre1, dz2, kPre2, kPre2, G + PL.enc_pre2.w, kPre2, M1, M1, 0, s, 1, G + PL.enc_pre2.b));
+    TACO_TRY(launch_conv_gemm(dense_problem(dz2, kPre2, PT + TL.enc_pre2, kPre1, nullptr, dz1, kPre1, M1, kPre1, kPre2,
+                                            TACO_ACT_NONE), s));
+    TACO_TRY(launch_act_bwd(ws + W.p1, dz1, enc_keep1, dz1, (int64_t)M1 * kPre1, TACO_ACT_RELU, s));
+    TACO_TRY(tn(ws + W.emb, kEmbed, kEmbed, dz1, kPre1, kPre1, G + PL.enc_pre1.w, kPre1, M1, M1, 0, s, 1, G + PL.enc_pre1.b));
+    TACO_TRY(launch_conv_gemm(dense_problem(dz1, kPre1, PT + TL.enc_pre1, kEmbed, nullptr, dEmb, kEmbed, M1, kEmbed, kPre1,
+                                            TACO_ACT_NONE), s));
+  }
   TACO_TRY(launch_embedding_bwd(dEmb, text, G + PL.emb, M1, shape->V, s));
   g_tn_side = nullptr;
   TACO_TRY(side_join(s, side));
