@@ -272,6 +272,7 @@ __global__ void affine_act_bwd_kernel(const float* __restrict__ pre, const float
   float ag = 0.f, ab = 0.f;
   if (c < N) {
     const float s = gamma[c] * rs;
+#pragma unroll 4
     for (int64_t row = r0 + threadIdx.y; row < r1; row += 4) {
       const float g = dy[row * N + c];
       const float p = pre[row * N + c];
@@ -403,15 +404,32 @@ __global__ __launch_bounds__(1024) void l1_kernel(const float* __restrict__ a, c
     const float* ar = a + m * N;
     const float* br = b + m * N;
     float* gr = grad ? grad + m * ldg : nullptr;
-#pragma unroll 4
-    for (int n = lane; n < ldg; n += 64) {
-      float g = 0.f;
-      if (n < N) {
-        const float d = ar[n] - br[n];
-        acc += fabsf(d);
-        g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    // four 64-wide pieces at a time: all eight loads (clamped addresses instead of a branch around them), then the arithmetic,
+    // then the stores -- a load issued behind a store would have to wait for that store's acknowledgement before its use
+    for (int n0 = 0; n0 < ldg; n0 += 256) {
+      float av[4], bv[4], g[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int n = n0 + 64 * u + lane;
+        const int nn = n < N ? n : N - 1;
+        av[u] = ar[nn];
+        bv[u] = br[nn];
       }
-      if (gr) gr[n] = g;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int n = n0 + 64 * u + lane;
+        const float d = av[u] - bv[u];
+        const bool in = n < N;
+        acc += in ? fabsf(d) : 0.f;
+        g[u] = in ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : 0.f;
+      }
+      if (gr) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int n = n0 + 64 * u + lane;
+          if (n < ldg) gr[n] = g[u];
+        }
+      }
     }
   }
   const float t = block_sum(acc, red);
