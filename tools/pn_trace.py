@@ -1,4 +1,5 @@
-"""Stage stamps of the fused pre_net kernel (probe build -DTACO_PN_TRACE): python tools/pn_trace.py"""
+"""Stage stamps of the fused pre_net kernel.  Needs the probe build: `bash tools/ab_build.sh pntrace "-DTACO_PN_TRACE" prenet`, then
+  TACO_LIB=$PWD/tacotron_amd/libtaco_pntrace.so python tools/pn_trace.py   (GPU box)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ['TACO_PN_TRACE'] = '1'
