@@ -245,6 +245,114 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
   // ---- epilogue.  C/D layout of v_mfma_f32_32x32x2: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5);
   //      sub-tile j holds columns n0 + 4 li + j, so element e of the four accumulators is one float4 of row `row` ----
   const int n = n0 + 4 * li;
+  if (P.pool == 2) {
+    // ---- backward pooled epilogue (kernels.h: ConvGemmProblem::pool == 2).  The accumulators hold dy = d(pooled) of rows
+    //      m0 .. m0+127; row m needs dy[m-1] (same lane, the lane 32 away, or the wave below via LDS -- the mirror image of the
+    //      forward epilogue) and the stored activations x[m-1], x[m], x[m+1].  Three passes per half of the tile's rows: all
+    //      loads, all arithmetic, all stores. ----
+    const bool col_ok = n + 3 < P.N;
+    float sc[4] = {0.f, 0.f, 0.f, 0.f}, be[4] = {0.f, 0.f, 0.f, 0.f};
+    if (col_ok) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sc[j] = P.scale[n + j] * P.scale_mul;
+        be[j] = P.shift[n + j];
+      }
+    }
+    // dy of the previous row for the first row of every 4-row group
+    __syncthreads();   // the ring is free: its first 2 KB carry each wave's row 31 to the wave above
+    if (kh == 1) *reinterpret_cast<float4*>(smem + wave * TN + 4 * li) = make_float4(acc[0][15], acc[1][15], acc[2][15], acc[3][15]);
+    __syncthreads();
+    float pv[4][4];   // pv[j][i]: dy of the row in front of this lane's row e = 4 i
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float got = __shfl_xor(acc[j][4 * i + 3], 32);   // rows 8i+3 (from kh = 0) / 8i+7 (from kh = 1)
+        if (kh == 1) pv[j][i] = got;                            // row 8i+4 follows row 8i+3
+        else if (i < 3) pv[j][i + 1] = got;                     // row 8(i+1) follows row 8i+7
+      }
+    if (kh == 0) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (wave > 0) t = *reinterpret_cast<const float4*>(smem + (wave - 1) * TN + 4 * li);
+      pv[0][0] = t.x; pv[1][0] = t.y; pv[2][0] = t.z; pv[3][0] = t.w;
+    }
+    float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+    const float rs = P.scale_mul;
+    const float* X = P.pool_x + n;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      // pass 1: x rows r0-1 .. r0+4 of the two 4-row groups of this half (clamped addresses; masked by the predicates below)
+      f32x4 xr[2][6];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int r0 = m0 + wave * 32 + 8 * (2 * hf + g) + 4 * kh;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          int m = r0 - 1 + q;
+          m = m < 0 ? 0 : (m >= P.M ? P.M - 1 : m);
+          xr[g][q] = col_ok ? *reinterpret_cast<const f32x4*>(X + (int64_t)m * P.ldc) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      // pass 2
+      f32x4 outv[2][4];
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = 2 * hf + g, e = 4 * i + q;
+          const int lr = wave * 32 + 8 * i + 4 * kh + q;   // local row
+          const int m = m0 + lr;
+          const int t = m % T;
+          const bool own = (lr >= 1 || tmm == 0) && m < P.M;
+          const bool first = t == 0, last = t == T - 1;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float xc = xr[g][q + 1][j], xp = xr[g][q][j], xn = xr[g][q + 2][j];
+            const float z = xc * sc[j] + be[j];
+            const float dyc = acc[j][e];
+            const float dyp = q > 0 ? acc[j][e - 1] : pv[j][i];
+            float dz = 0.f;
+            if (last || z >= xn * sc[j] + be[j]) dz = dyc;
+            if (!first && z > xp * sc[j] + be[j]) dz += dyp;
+            if (!own) dz = 0.f;
+            outv[g][q][j] = xc > 0.f ? dz * sc[j] : 0.f;
+            ag[j] += dz * xc * rs;
+            ab[j] += dz;
+          }
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      // pass 3
+      if (col_ok) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int lr = wave * 32 + 8 * (2 * hf + g) + 4 * kh + q;
+            const int m = m0 + lr;
+            if ((lr >= 1 || tmm == 0) && m < P.M) *reinterpret_cast<f32x4*>(P.C + (int64_t)m * P.ldc + n) = outv[g][q];
+          }
+      }
+    }
+    // column sums: the two row halves of a wave, then the four waves (fixed order inside the workgroup), one atomic per column
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ag[j] += __shfl_xor(ag[j], 32);
+      ab[j] += __shfl_xor(ab[j], 32);
+    }
+    __syncthreads();
+    if (kh == 0) {
+      *reinterpret_cast<float4*>(smem + (2 * wave) * TN + 4 * li) = make_float4(ag[0], ag[1], ag[2], ag[3]);
+      *reinterpret_cast<float4*>(smem + (2 * wave + 1) * TN + 4 * li) = make_float4(ab[0], ab[1], ab[2], ab[3]);
+    }
+    __syncthreads();
+    if (tid < 2 * TN) {
+      const int which = tid / TN, c = tid - which * TN;
+      const float v = smem[(0 + which) * TN + c] + smem[(2 + which) * TN + c] + smem[(4 + which) * TN + c] + smem[(6 + which) * TN + c];
+      if (n0 + c < P.N) atomicAdd((which ? P.pool_dbeta : P.pool_dgamma) + n0 + c, v);
+    }
+    return;
+  }
   if (P.pool) {
     // ---- pooled epilogue (conv bank, ops.py:62-71): bank = act(acc + bias) -> Cpre;  z = bank * scale + shift;
     //      C[m] = max(z[m], z[m + 1]) inside a sequence.  Row m + 1 of element e lives in the same lane (e & 3 < 3), in the
@@ -575,8 +683,12 @@ extern "C" __attribute__((visibility("default"))) int taco_debug_gemm2_window(in
 // m-tiles of a problem: pooled problems advance by TM - 1 rows (the last row of a tile is the next tile's first)
 static inline int m_tiles(const ConvGemmProblem& p) { return p.pool ? cdiv(p.M > 1 ? p.M - 1 : 1, TM - 1) : cdiv(p.M, TM); }
 static bool pool_contract(const ConvGemmProblem& p) {
-  return p.N % 4 == 0 && p.ldc % 4 == 0 && al16(p.C) && (!p.Cpre || al16(p.Cpre)) && !p.keep && !p.residual &&
-         p.bias_stride == 0 && !p.atomic_out && p.it0 == 0 && p.it1 == 0;
+  const bool common = p.N % 4 == 0 && p.ldc % 4 == 0 && al16(p.C) && (!p.Cpre || al16(p.Cpre)) && !p.keep && !p.residual &&
+                      p.bias_stride == 0 && !p.atomic_out && p.it0 == 0 && p.it1 == 0;
+  if (p.pool == 2)
+    return common && p.pool_x && al16(p.pool_x) && p.pool_dgamma && p.pool_dbeta && p.scale && p.shift && !p.Cpre && !p.bias &&
+           p.act == TACO_ACT_NONE;
+  return common;
 }
 bool conv_gemm2_would_launch(const ConvGemmBatch& batch) {
   const int min_tiles = gemm2_min_tiles();

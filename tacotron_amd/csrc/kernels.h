@@ -32,6 +32,14 @@ struct ConvGemmProblem {
   // max(z[m], z[m + 1]) (z[m] alone on the last row of a sequence) of the affine'd activation z; Cpre, if given, the
   // activation before the affine.  m-tiles overlap by one row (stride 127) so every pooled row has its successor in the tile.
   int pool = 0;
+  // pool == 2: the BACKWARD of that op in the epilogue of the GEMM that produces d(pooled) (the proj1 input gradient): the
+  // accumulator row m is dy[m]; with z = x scale + shift (x = pool_x, the stored activations, row pitch ldc),
+  //   dz[m] = [last row of its sequence or z[m] >= z[m+1]] dy[m] + [not first and z[m] > z[m-1]] dy[m-1],
+  //   C[m] = (x[m] > 0) dz[m] scale   (through the ReLU that produced x),  pool_dgamma += sum_m dz x / sqrt(1+eps),  pool_dbeta += sum_m dz.
+  // Tiles overlap by one row at the TOP (stride 127): a tile owns its rows 1..127 (tile 0 also row 0).
+  const float* pool_x = nullptr;
+  float* pool_dgamma = nullptr;
+  float* pool_dbeta = nullptr;
 };
 struct ConvGemmBatch {
   ConvGemmProblem p[kMaxGemmBatch];

@@ -813,15 +813,29 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
   TACO_TRY(launch_affine_act_bwd(w.pj1pre, P + c.p1_g, dpj1, dz1, G + c.p1_g, G + c.p1_be, M, c.c1, TACO_ACT_RELU, s));
   TACO_TRY(tn(w.pool, KC, KC, dz1, c.c1, c.c1, G + c.p1_w, c.c1, M, T, 1, s, 3, G + c.p1_b));
   float* dpool = sc.alt_dpool ? sc.alt_dpool : sc.gA;  // (M,KC)
+  float* dbank = sc.gB;  // (M,KC)
   {
+    // d pool = dz1 (*) W_p1^T, then back through max-pool, BN-affine and the bank's ReLU.  Where the DMA kernel takes the GEMM
+    // (and no fixed summation order is asked for) all of it is the GEMM's epilogue: d pool is never written (gemm2.hip, pool == 2)
     ConvGemmProblem p;
     p.A = dz1; p.lda = c.c1; p.W = PT + t.p1; p.ldw = KC; p.C = dpool; p.ldc = KC; p.M = M; p.N = KC; p.K = c.c1;
     p.taps = 3; p.T = T; p.pad_l = 1; p.act = TACO_ACT_NONE;
-    TACO_TRY(launch_conv_gemm(p, s));
+    int rc = TACO_ENOTFOUND;
+    const char* nf = getenv("TACO_NO_POOL_FUSE");
+    if (!taco_deterministic() && !(nf && atoi(nf) != 0)) {
+      ConvGemmProblem q = p;
+      q.C = dbank; q.pool = 2; q.pool_x = w.bank; q.scale = P + c.bank_g; q.shift = P + c.bank_be;
+      q.scale_mul = 1.0f / sqrtf(1.0f + kBnEps); q.pool_dgamma = G + c.bank_g; q.pool_dbeta = G + c.bank_be;
+      rc = launch_conv_gemm(q, s);
+    }
+    if (rc == TACO_ENOTFOUND) {
+      TACO_TRY(launch_conv_gemm(p, s));
+      // (d relu included: dbank is the gradient of the bank's pre-activation)
+      TACO_TRY(launch_bn_maxpool_bwd(w.bank, P + c.bank_g, P + c.bank_be, dpool, dbank, G + c.bank_g, G + c.bank_be, B, T, KC, s));
+    } else {
+      TACO_TRY(rc);
+    }
   }
-  float* dbank = sc.gB;  // (M,KC)
-  // (d relu included: dbank is the gradient of the bank's pre-activation)
-  TACO_TRY(launch_bn_maxpool_bwd(w.bank, P + c.bank_g, P + c.bank_be, dpool, dbank, G + c.bank_g, G + c.bank_be, B, T, KC, s));
   // ---- conv bank: weight/bias grads per width; input grad = residual path + sum over widths, accumulated with fp32
   //      atomics by ONE batched launch (all K transposed convolutions run concurrently instead of as a dependent chain) ----
   {

@@ -406,6 +406,18 @@ def test_pooled_bank_epilogue_tile_edges(built_lib, B, Tt, Td, monkeypatch):
         R.forward()
         got[mode] = {k: R.wsget(k).copy() for k in ('enc.bank', 'enc.pool', 'post.bank', 'post.pool', 'enc.p2')}
         got[mode]['s2s'] = R.s2s.cpu().numpy().copy()
+        # ... and the backward twin (the max-pool / BN / ReLU backward as the epilogue of the d pool GEMM, gemm2.hip pool == 2)
+        R.backward()
+        got[mode]['grads'] = R.grads.cpu().numpy().copy()
+    ga, gb = got['0']['grads'].astype(np.float64), got['1']['grads'].astype(np.float64)
+    rel = np.linalg.norm(ga - gb) / np.linalg.norm(gb)
+    print('  gradients, fused vs two-pass bank backward: rel-L2 %.2e, max|d| %.2e (|g|max %.2e)' % (rel, np.abs(ga - gb).max(), np.abs(gb).max()))
+    assert rel < 2e-6          # same arithmetic; only the order of the atomic accumulations differs
+    for name in ('encoder/cbhg/bank_bn/gamma', 'encoder/cbhg/bank_bn/beta', 'post/cbhg/bank_bn/gamma', 'post/cbhg/bank_bn/beta',
+                 'encoder/cbhg/bank_16/kernel', 'post/cbhg/bank_1/kernel', 'embedding'):
+        o, n_ = R.pb.index[name][0], R.pb.index[name][1]
+        d = np.linalg.norm(ga[o:o + n_] - gb[o:o + n_]) / max(1e-30, np.linalg.norm(gb[o:o + n_]))
+        assert d < 1e-5, (name, d)
     for k in ('enc.bank', 'enc.pool', 'post.bank', 'post.pool'):
         assert np.array_equal(got['0'][k], got['1'][k]), k
     for pf, xin, T, K in (('encoder/cbhg/', got['0']['enc.p2'].reshape(B, Tt, -1).astype(np.float64), Tt, 16),
