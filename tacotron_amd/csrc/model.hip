@@ -1228,8 +1228,10 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     pa.x = dP2; pa.x_out = dz2; pa.y2_in = ws + W.p2; pa.y1_in = ws + W.p1; pa.keep2 = enc_keep2; pa.keep1 = enc_keep1;
     pa.w1 = PT + TL.enc_pre2; pa.w2 = PT + TL.enc_pre1; pa.y1 = dz1; pa.y2 = dEmb; pa.M = M1;
     TACO_TRY(launch_prenet_bwd(pa, s));
+    TnGroup pre_group(s);   // the two weight gradients as one grouped launch: they are the tail of the step
     TACO_TRY(tn(ws + W.p1, kPre1, kPre1, dz2, kPre2, kPre2, G + PL.enc_pre2.w, kPre2, M1, M1, 0, s, 1, G + PL.enc_pre2.b));
     TACO_TRY(tn(ws + W.emb, kEmbed, kEmbed, dz1, kPre1, kPre1, G + PL.enc_pre1.w, kPre1, M1, M1, 0, s, 1, G + PL.enc_pre1.b));
+    TACO_TRY(pre_group.flush());
   } else {
     TACO_TRY(launch_act_bwd(ws + W.p2, dP2, enc_keep2, dz2, (int64_t)M1 * kPre2, TACO_ACT_RELU, s));
     TACO_TRY(tn(ws + W.p1, kPre1, kPre1, dz2, kPre2, kPre2, G + PL.enc_pre2.w, kPre2, M1, M1, 0, s, 1, G + PL.enc_pre2.b));
