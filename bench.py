@@ -152,6 +152,11 @@ def main():
     ap.add_argument('--no-extras', action='store_true', help='skip the S2 (Td=500) and VCTK (109 speakers) legs and the family profile')
     ap.add_argument('--speakers', type=int, default=1, help='>1: VCTK-shaped multi-speaker model (BASELINE configs[4])')
     args = ap.parse_args()
+    # The contract is ONE JSON line on stdout.  Libraries underneath write to file descriptor 1 on their own (RCCL prints a five-line
+    # version banner at communicator creation): everything up to the result line goes to stderr, then stdout is put back.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     from tacotron_amd import lib
     from tacotron_amd.config import Config
@@ -339,7 +344,10 @@ def main():
             res['inference'] = infer
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(B, Tt, Td, c.r, c.vocab_size)
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps(res), flush=True)
+        os.dup2(2, 1)   # (whatever is printed at teardown stays off stdout too)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
