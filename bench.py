@@ -202,10 +202,10 @@ def main():
         seg_us = reducer.segment_times_us()
         reducer.timing = False
         allreduce = {'backend': torch.distributed.get_backend(), 'world': world, 'bucket_floats': reducer.bucket,
-                     'overlap_bptt': reducer.overlap_bptt, 'lds_reserve_kb': reducer.lds_reserve_kb,
+                     'comm_stream_priority': reducer.comm_priority,
                      'segments': [dict(d, us=seg_us[d['segment']]) for d in reducer.describe(model)],
-                     'note': 'completion order post-net, decoder, encoder; us = first collective enqueued -> last one done on the '
-                             'communication stream, median of 3 untimed steps'}
+                     'note': 'completion order inside taco_backward; us = segment final (its event reached on the communication '
+                             'stream) -> its last collective done, median of 3 untimed steps'}
     elif reducer is not None:
         for _ in range(3):
             model.step()   # (collectives need every rank)

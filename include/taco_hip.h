@@ -23,7 +23,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default)
 
-#define TACO_VERSION 112
+#define TACO_VERSION 113
 
 #define TACO_OK 0
 #define TACO_EINVAL (-1)   /* bad argument / unsupported shape   */
@@ -147,26 +147,36 @@ int taco_clip_adam_step_guarded(float* params, const float* grads, float* m, flo
                                 int64_t step, float* scratch, float* gnorm_out, const int32_t* err_words, void* stream);
 int taco_clear_error(const TacoShape* shape, int train, void* workspace, void* stream);
 
+/* Process-wide decoder mode.  The default persistent decoder kernels (decoder3.hip) exchange data between the 32 workgroups of
+ * a cluster through granules that are published with WORKGROUP-scope stores and read with L1-bypassing agent-scope loads when
+ * the whole cluster sits on one XCD (verified at kernel start from HW_REG_XCC_ID).  That is faster than the placement-
+ * independent agent-scope form (0.21 vs 0.37 us per hop) but leans on gfx942 / gfx950 implementation behaviour: a write-through
+ * L1 and one L2 per XCD shared by its CUs.  Granules are epoch-tagged, so a stale read can only delay or time out, never
+ * corrupt; a time-out sets the sticky error word (taco_clip_adam_step_guarded).
+ *   mode 0 (default)  decoder3.hip, XCD-local exchange where placement allows
+ *   mode 1            decoder3.hip, agent-scope exchange only (environment TACO_DEC_V3_AGENT=1)
+ *   mode 2            decoder.hip (round-1/2 kernels: one cluster of 8-16 workgroups per batch row; environment TACO_DEC_V3=0)
+ * taco_decoder_mode(mode) sets the mode (mode < 0: query only) and returns the previous one.  The Python host escalates
+ * 0 -> 1 -> 2 when Tacotron.check() finds an error word set, so a box where the fast form misbehaves degrades instead of
+ * skipping every update. */
+int taco_decoder_mode(int mode);
+
 /* ---- data-parallel overlap (no reference counterpart: train.py:24 is a single Session) ---------------- */
-/* The flat gradient buffer becomes final in three contiguous segments, in this order during taco_backward:
- *   segment 2 = [bounds[2], bounds[3])  post-net CBHG + final dense   (before the decoder BPTT starts)
- *   segment 1 = [bounds[1], bounds[2])  attention memory layer + decoder
- *   segment 0 = [bounds[0], bounds[1])  embedding(s) + encoder       (end of taco_backward)
- * taco_grad_segments fills bounds[4] (float offsets) and returns 3.  taco_wait_grad_segment makes `stream` wait (device
+/* The flat gradient buffer becomes final in FOUR contiguous segments, in this order during taco_backward:
+ *   segment 3 = [bounds[3], bounds[4])  post-net CBHG + final dense   (final before the decoder BPTT; ANNOUNCED right after it)
+ *   segment 2 = [bounds[2], bounds[3])  attention memory layer + decoder
+ *   segment 1 = [bounds[1], bounds[2])  encoder CBHG without its conv bank: projections, highways, bi-GRU
+ *   segment 0 = [bounds[0], bounds[1])  embedding(s) + encoder pre_net + encoder conv bank   (end of taco_backward)
+ * taco_grad_segments fills bounds[5] (float offsets) and returns 4.  taco_wait_grad_segment makes `stream` wait (device
  * side, hipStreamWaitEvent) until segment `seg` of the most recent taco_backward enqueued by the calling thread on the
- * current device is final, so an all-reduce enqueued on `stream` afterwards overlaps the rest of the backward pass. */
+ * current device is final, so an all-reduce enqueued on `stream` afterwards overlaps the rest of the backward pass.
+ * Segment 3 is announced AFTER the decoder BPTT kernel although it is final before it: that kernel is a persistent launch
+ * whose 256 workgroups must all be co-resident (one per CU), so no collective is ever allowed to compete with it for CUs;
+ * segments 3 and 2 (13.7 MB) travel under the encoder backward, segment 1 (4.7 MB) under the encoder conv-bank gradients, and
+ * only segment 0 (9.4 MB, of which the conv bank -- the last 0.6 ms of the pass -- is 8.9 MB) is exposed. */
 int taco_grad_segments(const TacoShape* shape, int64_t* bounds);
 int taco_wait_grad_segment(int seg, void* stream);
-/* Process-wide data-parallel options (defaults 0, 0; environment TACO_DP_OVERLAP_BPTT / TACO_DEC_LDS_RESERVE_KB before the
- * first call).  The decoder BPTT is a persistent launch that needs ALL its B * 8 workgroups co-resident, one per CU, with up to
- * 158 KB of LDS each; a collective's kernel that took CUs first would leave clusters spinning on peers that cannot start.
- *   overlap_bptt = 0 (default): segment 2's event is recorded AFTER the BPTT kernel, so a collective waiting for it never
- *     competes with that launch -- its bytes travel under the encoder backward instead;
- *   overlap_bptt = 1: segment 2 is announced before the BPTT kernel (its all-reduce runs underneath it).  Combine with
- *     lds_reserve_kb > 0: every persistent decoder workgroup then leaves that much LDS of its CU free, so that one
- *     communication workgroup per CU fits beside it whichever is dispatched first (tests/test_gpu_dist.py measures both orders). */
-int taco_dp_config(int overlap_bptt, int lds_reserve_kb);
-/* Communication-kernel stand-in for those tests: `blocks` workgroups x `threads` threads, `lds_bytes` of LDS each, spinning
+/* Communication-kernel stand-in for the co-residency tests (tests/test_gpu_dist.py): `blocks` workgroups x `threads` threads, `lds_bytes` of LDS each, spinning
  * for `usec` microseconds.  Does no work. */
 int taco_debug_spin(int blocks, int threads, int lds_bytes, int usec, void* stream);
 
@@ -202,9 +212,14 @@ int taco_fill_bernoulli(uint8_t* out, int64_t n, float p_one, uint64_t seed, voi
  * algorithmic FLOPs of each launch (2 M N K taps) to the HOST arrays, oldest first, clears the ring, returns the count.
  * Launches that overlap on two streams are each timed by their own events (their times then sum to more than the wall). */
 int taco_profile_enable(int mask);
-/* Workgroups per batch row (cluster width) the most recent decoder forward (which = 0) / backward (1) launch of this process
- * ran with: 8 in training, up to 16 at inference, fewer when B * width workgroups would not be co-resident. */
+/* Workgroups per cluster the most recent decoder forward (which = 0) / backward (1) launch of this process ran with:
+ * 32 on the default path (decoder3.hip: 8 clusters x 32 workgroups, each cluster owning up to 4 batch rows); on the fallback
+ * path (decoder.hip: one cluster per batch row) 8 in training and up to 16 at inference, fewer when B * width workgroups
+ * would not be co-resident. */
 int taco_debug_last_cluster(int which);
+/* Labels of the launches currently in ring `which` (what each timed launch was: kernel family and shape), one line per
+ * launch, oldest first, into the HOST buffer; returns the number of launches.  Call BEFORE taco_profile_read2 (which clears). */
+int taco_debug_profile_labels(int which, char* buf, int cap);
 int taco_profile_read(int which, float* ms, int cap);
 int taco_profile_read2(int which, float* ms, double* flops, int cap);
 

@@ -19,6 +19,46 @@ import torch.nn.functional as F
 BN_EPS = 1e-3
 
 
+class Decisions:
+    """The model's DISCRETE decisions -- which side of a ReLU a pre-activation falls on, which of the two rows a max-pool
+    keeps -- recorded (with their margins) or forced.  fp32 and fp64 evaluate the same graph to ~1e-7, but a pre-activation
+    that is 1e-8 away from zero can land on different sides, and the gradient below that unit then differs by O(1) in its
+    receptive field.  tests/test_gpu_sizes.py uses this to EXHIBIT such flips (HIP decision != fp64 decision, margin at
+    rounding level) and to compare gradients with the HIP path's decisions imposed on the fp64 graph.
+      record mode (force=None): `rec[name]` bool tensor, `margin[name]` |distance to the decision boundary|
+      force mode: `force[name]` float 0/1 tensor replaces the decision at that site (sites not in `force` are recorded)."""
+
+    def __init__(self, force=None):
+        self.force = force or {}
+        self.rec, self.margin = {}, {}
+
+    def relu(self, name, x):
+        if name in self.force:
+            return x * self.force[name]
+        self.rec[name] = (x > 0).detach()
+        self.margin[name] = x.abs().detach()
+        return torch.relu(x)
+
+    def pool2(self, name, z):
+        """max(z[t], z[t+1]) along dim 1, the last row alone; decision True = row t+1 wins (strictly: a tie keeps row t, as
+        torch.max_pool1d's and the HIP kernels' backward do)."""
+        nxt = torch.cat([z[:, 1:], z[:, -1:]], 1)
+        if name in self.force:
+            m = self.force[name]
+            return torch.where(m > 0.5, nxt, z)
+        take = nxt > z
+        take[:, -1] = False
+        self.rec[name] = take.detach()
+        mg = (nxt - z).abs().detach()
+        mg[:, -1] = float('inf')
+        self.margin[name] = mg
+        return torch.where(take, nxt, z)
+
+
+def _relu(dec, name, x):
+    return torch.relu(x) if dec is None else dec.relu(name, x)
+
+
 def _conv_same(x, kernel, bias):
     # x (B,T,Cin); kernel TF layout (k,Cin,Cout) -> torch (Cout,Cin,k).  ops.py:54-60
     k = kernel.shape[0]
@@ -64,19 +104,21 @@ def _bigru(x, p, prefix, h0=None):
     return torch.cat(outs, 2)
 
 
-def _highway(x, p, prefix):
+def _highway(x, p, prefix, dec=None):
     if (prefix + 'adapt/kernel') in p:
         x = F.linear(x, p[prefix + 'adapt/kernel'].t(), p[prefix + 'adapt/bias'])
     t = torch.sigmoid(F.linear(x, p[prefix + 'T/kernel'].t(), p[prefix + 'T/bias']))
-    h = torch.relu(F.linear(x, p[prefix + 'H/kernel'].t(), p[prefix + 'H/bias']))
+    h = _relu(dec, prefix + 'H', F.linear(x, p[prefix + 'H/kernel'].t(), p[prefix + 'H/bias']))
     return h * t + x * (1 - t)
 
 
-def cbhg(x, p, prefix, K, spk=None):
-    bank = torch.cat([torch.relu(_conv_same(x, p[prefix + 'bank_%d/kernel' % k], p[prefix + 'bank_%d/bias' % k]))
+def cbhg(x, p, prefix, K, spk=None, dec=None):
+    bank = torch.cat([_conv_same(x, p[prefix + 'bank_%d/kernel' % k], p[prefix + 'bank_%d/bias' % k])
                       for k in range(1, K + 1)], 2)
-    y = _maxpool(_bn(bank, p[prefix + 'bank_bn/gamma'], p[prefix + 'bank_bn/beta']))
-    y = torch.relu(_conv_same(y, p[prefix + 'proj1/kernel'], p[prefix + 'proj1/bias']))
+    bank = _relu(dec, prefix + 'bank', bank)
+    z = _bn(bank, p[prefix + 'bank_bn/gamma'], p[prefix + 'bank_bn/beta'])
+    y = _maxpool(z) if dec is None else dec.pool2(prefix + 'pool', z)
+    y = _relu(dec, prefix + 'proj1', _conv_same(y, p[prefix + 'proj1/kernel'], p[prefix + 'proj1/bias']))
     y = _bn(y, p[prefix + 'proj1_bn/gamma'], p[prefix + 'proj1_bn/beta'])
     y = _conv_same(y, p[prefix + 'proj2/kernel'], p[prefix + 'proj2/bias'])
     y = _bn(y, p[prefix + 'proj2_bn/gamma'], p[prefix + 'proj2_bn/beta'])
@@ -84,35 +126,36 @@ def cbhg(x, p, prefix, K, spk=None):
     for l in range(4):
         hp = prefix + 'highway_%d/' % l
         if spk is not None:   # ops.py:101-105
-            sv = torch.relu(F.linear(spk, p[hp + 'spk/kernel'].t(), p[hp + 'spk/bias']))
+            sv = _relu(dec, hp + 'spk', F.linear(spk, p[hp + 'spk/kernel'].t(), p[hp + 'spk/bias']))
             h = torch.cat([h, sv[:, None, :].expand(-1, h.shape[1], -1)], 2)
-        h = _highway(h, p, hp)
+        h = _highway(h, p, hp, dec)
     h0 = None
     if spk is not None:       # ops.py:111-115
-        h0 = torch.relu(F.linear(spk, p[prefix + 'gru_init/kernel'].t(), p[prefix + 'gru_init/bias']))
+        h0 = _relu(dec, prefix + 'gru_init', F.linear(spk, p[prefix + 'gru_init/kernel'].t(), p[prefix + 'gru_init/bias']))
     return _bigru(h, p, prefix + 'bigru/', h0)
 
 
-def _prenet(x, p, prefix, k1, k2):
-    l1 = torch.relu(F.linear(x, p[prefix + 'dense/kernel'].t(), p[prefix + 'dense/bias']))
+def _prenet(x, p, prefix, k1, k2, dec=None, tag=''):
+    l1 = _relu(dec, prefix + 'l1' + tag, F.linear(x, p[prefix + 'dense/kernel'].t(), p[prefix + 'dense/bias']))
     if k1 is not None:
         l1 = l1 * (2.0 * k1)
-    l2 = torch.relu(F.linear(l1, p[prefix + 'dense_1/kernel'].t(), p[prefix + 'dense_1/bias']))
+    l2 = _relu(dec, prefix + 'l2' + tag, F.linear(l1, p[prefix + 'dense_1/kernel'].t(), p[prefix + 'dense_1/bias']))
     if k2 is not None:
         l2 = l2 * (2.0 * k2)
     return l2
 
 
-def forward(p, inputs, r, n_steps, train, masks=None):
+def forward(p, inputs, r, n_steps, train, masks=None, dec=None):
     """p: dict name->tensor; inputs: dict of tensors (text int64, text_length int64, mel, stft);
-    masks: dict of float tensors (0/1).  Returns (seq2seq_output, output, alignments, encoded)."""
+    masks: dict of float tensors (0/1); dec: optional Decisions (record / force the ReLU and max-pool decisions; the decoder
+    pre_net sites are named per step: 'decoder/pre_net/l1@<t>').  Returns (seq2seq_output, output, alignments, encoded)."""
     masks = masks or {}
     g = (lambda k: masks.get(k)) if train else (lambda k: None)
     text = inputs['text']
     B, Tt = text.shape
     emb = F.embedding(text, p['embedding'])
     spk = F.embedding(inputs['speaker'], p['speaker_embed']) if ('speaker' in inputs and 'speaker_embed' in p) else None
-    enc = cbhg(_prenet(emb, p, 'encoder/pre_net/', g('enc_keep1'), g('enc_keep2')), p, 'encoder/cbhg/', 16, spk)
+    enc = cbhg(_prenet(emb, p, 'encoder/pre_net/', g('enc_keep1'), g('enc_keep2'), dec), p, 'encoder/cbhg/', 16, spk, dec)
 
     # attention memory (tacotron.py:48-52)
     valid = torch.arange(Tt)[None, :] < inputs['text_length'][:, None]
@@ -129,7 +172,7 @@ def forward(p, inputs, r, n_steps, train, masks=None):
     dk1, dk2, smp = g('dec_keep1'), g('dec_keep2'), g('sample')
     for t in range(n_steps):
         pn = _prenet(prev[:, nmel * (r - 1):], p, 'decoder/pre_net/',
-                     dk1[:, t] if dk1 is not None else None, dk2[:, t] if dk2 is not None else None)
+                     dk1[:, t] if dk1 is not None else None, dk2[:, t] if dk2 is not None else None, dec, '@%d' % t)
         x = F.linear(torch.cat([pn, att], 1), p['decoder/in_proj/kernel'].t(), p['decoder/in_proj/bias'])
         inp = x
         for l in range(3):
@@ -153,7 +196,7 @@ def forward(p, inputs, r, n_steps, train, masks=None):
                 prev = torch.where(smp[t][:, None] > 0.5, o, prev)
     s2s = torch.stack(outs, 1)
     al = torch.stack(aligns, 1)
-    post = cbhg(s2s.reshape(B, n_steps * r, nmel), p, 'post/cbhg/', 8)
+    post = cbhg(s2s.reshape(B, n_steps * r, nmel), p, 'post/cbhg/', 8, None, dec)
     out = F.linear(post, p['post/dense/kernel'].t(), p['post/dense/bias']).reshape(B, n_steps, -1)
     return s2s, out, al, enc
 
@@ -166,8 +209,8 @@ def to_torch(pnp, dtype=torch.float64, requires_grad=False):
     return {k: torch.tensor(v, dtype=dtype, requires_grad=requires_grad) for k, v in pnp.items()}
 
 
-def loss_and_grads(pnp, inputs_np, r, n_steps, masks_np=None, dtype=torch.float64):
-    """Convenience: numpy in, numpy out.  Returns (loss, s2s, out, align, grads dict)."""
+def loss_and_grads(pnp, inputs_np, r, n_steps, masks_np=None, dtype=torch.float64, dec=None):
+    """Convenience: numpy in, numpy out.  Returns (loss, s2s, out, align, grads dict).  dec: optional Decisions."""
     p = to_torch(pnp, dtype, True)
     inputs = {
         'text': torch.tensor(inputs_np['text'], dtype=torch.int64),
@@ -178,7 +221,7 @@ def loss_and_grads(pnp, inputs_np, r, n_steps, masks_np=None, dtype=torch.float6
     if 'speaker' in inputs_np:
         inputs['speaker'] = torch.tensor(inputs_np['speaker'], dtype=torch.int64)
     masks = {k: torch.tensor(v, dtype=dtype) for k, v in (masks_np or {}).items()}
-    s2s, out, al, _ = forward(p, inputs, r, n_steps, True, masks)
+    s2s, out, al, _ = forward(p, inputs, r, n_steps, True, masks, dec)
     loss = loss_fn(s2s, out, inputs['mel'], inputs['stft'])
     loss.backward()
     grads = {k: (t.grad.numpy() if t.grad is not None else None) for k, t in p.items()}

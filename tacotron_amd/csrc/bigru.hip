@@ -273,11 +273,9 @@ int launch_bigru_bwd(const float* dout, const float* out, const float* ruc, cons
   // The recurrence is latency bound and runs on only 2B workgroups.  Independent GEMMs are scheduled beside it on a side
   // stream (model.hip); padding this kernel's LDS request to ~148 KB leaves < 16 KB per CU, less than any GEMM tile
   // needs, so those GEMM workgroups fill the OTHER CUs and never share an issue port with the recurrence.
-  static const size_t pad = [] {
-    const size_t want = 107 * 1024;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(bigru_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)want) == hipSuccess ? want : (size_t)0;
-  }();
+  static DynSmemOnce once;
+  const size_t want = 107 * 1024;
+  const size_t pad = ensure_dyn_smem(once, reinterpret_cast<const void*>(bigru_bwd_kernel), want) ? want : (size_t)0;
   // (only while the recurrence leaves CUs free for those GEMMs: with more sequences it needs every CU slot itself)
   const int pslot = taco_prof_begin(3, s);
   hipLaunchKernelGGL(bigru_bwd_kernel, dim3(B, 2), dim3(NTG), 2 * B <= 128 ? pad : 0, s, dout, out, ruc, w, h0, dxg, rh, dh0, B, T);

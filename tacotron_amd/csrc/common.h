@@ -100,6 +100,22 @@ __device__ __forceinline__ float apply_act(float x, int act) {
   }
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the (function, DEVICE) pair: cache the "already raised" fact per
+// device, not per process (a second GPU used by the same process would otherwise launch without it and fail).  `done` is the
+// call site's own static table.
+struct DynSmemOnce {
+  bool ok[32] = {};
+};
+static inline bool ensure_dyn_smem(DynSmemOnce& done, const void* func, size_t bytes) {
+  if (bytes <= 64 * 1024) return true;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  if (dev >= 0 && dev < 32 && done.ok[dev]) return true;
+  if (hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+  if (dev >= 0 && dev < 32) done.ok[dev] = true;
+  return true;
+}
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

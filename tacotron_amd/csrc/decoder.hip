@@ -1376,7 +1376,7 @@ void lres_plan(size_t& smem, int& r0, int& r1) {
   if (getenv("TACO_DEC_NO_LRES")) return;
   for (int l = 0; l < 2; ++l)
     for (int rows = 8; rows >= 4; rows -= 4)
-      if (smem + (size_t)rows * NT * 16 <= (size_t)158 * 1024 - (size_t)taco_dp().lds_reserve_bytes) {
+      if (smem + (size_t)rows * NT * 16 <= (size_t)158 * 1024) {
         (l == 0 ? r0 : r1) = rows;
         smem += (size_t)rows * NT * 16;
         break;

@@ -1672,20 +1672,35 @@ int launch3b(DecBwdArgs& a, hipStream_t s) {
   return TACO_OK;
 }
 
+// Process-wide decoder mode (include/taco_hip.h taco_decoder_mode): 0 = decoder3 with the XCD-local exchange where a cluster's
+// placement allows it, 1 = decoder3 with the placement-independent agent-scope exchange only, 2 = decoder.hip.  The host
+// escalates it when a launch reports an exchange time-out (Tacotron.check()), so a box on which the fast form misbehaves --
+// other tenants holding CUs, a partition mode whose L2 does not behave like gfx950 SPX -- degrades to a slower mode instead of
+// skipping every update.  The environment (read on every launch: tests and A/B tools switch it inside one process) is a floor
+// under the programmed value: TACO_DEC_V3=0 -> 2, TACO_DEC_V3_AGENT=1 -> 1.
+static int g_dec_mode = 0;
+static int dec_mode() {
+  const char* v3 = getenv("TACO_DEC_V3");
+  const int floor = (v3 && atoi(v3) == 0) ? 2 : (getenv("TACO_DEC_V3_AGENT") ? 1 : 0);
+  return floor > g_dec_mode ? floor : g_dec_mode;
+}
+extern "C" int taco_decoder_mode(int mode) {
+  TACO_REQUIRE(mode <= 2, "taco_decoder_mode: mode %d out of range (0..2, negative = query)", mode);
+  const int prev = dec_mode();
+  if (mode >= 0) g_dec_mode = mode;
+  return prev;
+}
+
 int launch_decoder3_bwd(DecBwdArgs a, hipStream_t s) {
   const char* env = getenv("TACO_DEC_V3");
-  if (env && (atoi(env) == 0 || atoi(env) == 1)) return TACO_ENOTFOUND;   // TACO_DEC_V3=1: forward only (A/B runs)
+  if (dec_mode() >= 2 || (env && atoi(env) == 1)) return TACO_ENOTFOUND;   // TACO_DEC_V3=1: forward only (A/B runs)
   if (a.Tt > TTP || a.B > 32 || a.B < 1 || (a.r != 2 && a.r != 5)) return TACO_ENOTFOUND;
   if (!a.hoisted || (a.trace && !kProbes3)) return TACO_ENOTFOUND;
-  // Opt-in data-parallel mode "collectives underneath the BPTT" (taco_dp_config overlap_bptt): a communication workgroup must
-  // fit on every CU beside the BPTT workgroup.  This kernel fills the CU (8 waves x ~220 VGPRs, ~110 KB LDS), decoder.hip's BPTT
-  // leaves the configured LDS reserve and half the register file: that mode takes decoder.hip.
-  if (taco_dp().overlap_bptt) return TACO_ENOTFOUND;
   const int R = a.B > 16 ? 4 : (a.B > 8 ? 2 : 1);
   const int ncl = (a.B + R - 1) / R;
   if ((int64_t)ncl * R * kX3Row * 8 + 1024 > decoder_xchg_bytes(a.B, a.Tt)) return TACO_ENOTFOUND;
   a.xcc_table_ofs = (int)(decoder_xchg_bytes(a.B, a.Tt) / 4 - 256);
-  a.fast_ok = getenv("TACO_DEC_V3_AGENT") ? 0 : 1;
+  a.fast_ok = dec_mode() == 0 ? 1 : 0;
   a.fakew = kProbes3 ? ((getenv("TACO_DEC_FAKEX") ? 2 : 0)) : 0;
   a.P = P3;
   decoder_note_cluster(1, P3);
@@ -1695,8 +1710,7 @@ int launch_decoder3_bwd(DecBwdArgs a, hipStream_t s) {
 
 // Returns TACO_ENOTFOUND (nothing enqueued) when the shape is outside this kernel's scope; the caller then takes decoder.hip.
 int launch_decoder3_fwd(DecFwdArgs a, hipStream_t s) {
-  const char* env = getenv("TACO_DEC_V3");
-  if (env && atoi(env) == 0) return TACO_ENOTFOUND;
+  if (dec_mode() >= 2) return TACO_ENOTFOUND;
   if (a.Tt > TTP || a.B > 32 || a.B < 1 || (a.r != 2 && a.r != 5)) return TACO_ENOTFOUND;
   if (a.mel && !a.pre2) return TACO_ENOTFOUND;   // training needs the hoisted pre-net
   if (a.trace && !kProbes3) return TACO_ENOTFOUND;   // (the production build carries no stamps; decoder.hip's trace then)
@@ -1704,7 +1718,7 @@ int launch_decoder3_fwd(DecFwdArgs a, hipStream_t s) {
   const int ncl = (a.B + R - 1) / R;
   if ((int64_t)ncl * R * kX3Row * 8 + 1024 > decoder_xchg_bytes(a.B, a.Tt)) return TACO_ENOTFOUND;
   a.xcc_table_ofs = (int)(decoder_xchg_bytes(a.B, a.Tt) / 4 - 256);   // last 1 KB of the exchange area
-  a.fast_ok = getenv("TACO_DEC_V3_AGENT") ? 0 : 1;
+  a.fast_ok = dec_mode() == 0 ? 1 : 0;
   a.P = P3;
   a.fakew = kProbes3 ? ((getenv("TACO_DEC_FAKEX") ? 2 : 0)) : 0;
   decoder_note_cluster(0, P3);

@@ -536,6 +536,16 @@ int launch_conv_gemm_batch(ConvGemmBatch& batch, hipStream_t stream) {
   double flops = 0;
   for (int i = 0; i < batch.n; ++i) flops += 2.0 * batch.p[i].M * batch.p[i].N * batch.p[i].K * batch.p[i].taps;
   const int pslot = taco_prof_begin(2, stream);
+  {
+    int tmax = 0, tmin = 1 << 30;
+    for (int i = 0; i < batch.n; ++i) {
+      tmax = std::max(tmax, batch.p[i].taps);
+      tmin = std::min(tmin, batch.p[i].taps);
+    }
+    const ConvGemmProblem& q = batch.p[0];
+    taco_prof_label(2, pslot, "nn n=%d M=%d N=%d K=%d taps=%d..%d%s%s%s%s%s", batch.n, q.M, q.N, q.K, tmin, tmax, q.pool ? (q.pool == 2 ? " pool2" : " pool1") : "",
+                    q.keep ? " keep" : "", q.residual ? " res" : "", q.atomic_out ? " atomic" : "", q.bias_stride ? " rowbias" : "");
+  }
   if (flags == 3) {
     // second-generation kernel (gemm2.hip: DMA-staged 32-deep k-tiles, 128 x 128 tiles) whenever the batch meets its
     // contract and has enough tiles to occupy the chip
@@ -600,6 +610,7 @@ int launch_conv_gemm_tapsplit(const ConvGemmProblem& p, float* slabs, int64_t sl
           conv_gemm_set_flags(r);
         }
         const int pslot = taco_prof_begin(2, stream);
+        taco_prof_label(2, pslot, "nn-ksplit S=%d M=%d N=%d K=%d taps=%d", bestS, p.M, p.N, p.K, p.taps);
         const int rc = launch_conv_gemm2(b, stream, /*force=*/true);
         if (rc == TACO_OK) {
           const int64_t total4 = mn / 4;
@@ -714,6 +725,7 @@ int launch_gemm_tn(GemmTnArgs a, bool zero_first, hipStream_t stream) {
   dim3 grid;
   const int bm = plan_gemm_tn(a, false, grid);
   const int pslot = taco_prof_begin(2, stream);
+  taco_prof_label(2, pslot, "tn M=%d N=%d K=%d taps=%d batch=%d splits=%d bm=%d", a.M, a.N, a.K, a.taps, a.batch, a.splits, bm);
   if (bm == 128)
     dispatch_tn<2, 2>(a.flags, grid, stream, a);
   else
@@ -774,6 +786,8 @@ int launch_gemm_tn_batch(GemmTnBatch& b, hipStream_t stream) {
     for (int i = 0; i < grouped.n; ++i)
       flops += 2.0 * grouped.p[i].M * grouped.p[i].N * grouped.p[i].K * grouped.p[i].taps * grouped.p[i].batch;
     const int pslot = taco_prof_begin(2, stream);
+    taco_prof_label(2, pslot, "tn-batch n=%d blocks=%d first: M=%d N=%d K=%d taps=%d", grouped.n, blocks, grouped.p[0].M, grouped.p[0].N, grouped.p[0].K,
+                    grouped.p[0].taps);
     hipLaunchKernelGGL(gemm_tn_batch_kernel, dim3(blocks), dim3(256), 0, stream, grouped);
     taco_prof_end(2, pslot, stream, flops);
     TACO_LAUNCH_CHECK("gemm_tn_batch");

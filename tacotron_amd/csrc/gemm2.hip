@@ -654,10 +654,9 @@ Variant env_variant() {   // read on every launch (tests and the tuning harness 
 template <int BK, int NS>
 int launch_variant(const Gemm2Args& g, int tiles, hipStream_t s) {
   constexpr size_t smem = (size_t)NS * (TM * BK + BK * TN) * sizeof(float);
-  static const bool ok = smem <= 64 * 1024 ||
-                         hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm2_kernel<BK, NS>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess;
-  TACO_REQUIRE(ok, "conv_gemm2: cannot reserve %zu bytes of LDS", smem);
+  static DynSmemOnce once;
+  TACO_REQUIRE(ensure_dyn_smem(once, reinterpret_cast<const void*>(conv_gemm2_kernel<BK, NS>), smem),
+               "conv_gemm2: cannot reserve %zu bytes of LDS", smem);
   hipLaunchKernelGGL((conv_gemm2_kernel<BK, NS>), dim3(tiles), dim3(256), smem, s, g);
   return TACO_OK;
 }

@@ -232,10 +232,11 @@ __global__ __launch_bounds__(256, 2) void highway_stack_bwd_kernel(HighwayStackB
 
 int launch_highway_stack_bwd(const HighwayStackBwdArgs& a, hipStream_t s) {
   TACO_REQUIRE(a.M > 0 && a.nl >= 1 && a.nl <= 4 && a.g && a.gout, "highway_stack_bwd: bad arguments");
-  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(highway_stack_bwd_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHwBwdSmem) == hipSuccess;
-  TACO_REQUIRE(ok, "highway_stack_bwd: cannot reserve %zu bytes of LDS", kHwBwdSmem);
+  static DynSmemOnce once;
+  TACO_REQUIRE(ensure_dyn_smem(once, reinterpret_cast<const void*>(highway_stack_bwd_kernel), kHwBwdSmem),
+               "highway_stack_bwd: cannot reserve %zu bytes of LDS", kHwBwdSmem);
   const int pslot = taco_prof_begin(2, s);
+  taco_prof_label(2, pslot, "highway-bwd M=%d nl=%d", a.M, a.nl);
   hipLaunchKernelGGL(highway_stack_bwd_kernel, dim3(cdiv(a.M, HB)), dim3(256), kHwBwdSmem, s, a);
   taco_prof_end(2, pslot, s, 2.0 * a.M * HC * 2 * HC * a.nl);
   TACO_LAUNCH_CHECK("highway_stack_bwd");
@@ -245,6 +246,7 @@ int launch_highway_stack_bwd(const HighwayStackBwdArgs& a, hipStream_t s) {
 int launch_highway_stack_fwd(const HighwayStackArgs& a, hipStream_t s) {
   TACO_REQUIRE(a.M > 0 && a.nl >= 1 && a.nl <= 4 && a.x, "highway_stack_fwd: bad arguments");
   const int pslot = taco_prof_begin(2, s);
+  taco_prof_label(2, pslot, "highway-fwd M=%d nl=%d", a.M, a.nl);
   hipLaunchKernelGGL(highway_stack_fwd_kernel, dim3(cdiv(a.M, HB)), dim3(256), 0, s, a);
   taco_prof_end(2, pslot, s, 2.0 * a.M * HC * 2 * HC * a.nl);
   TACO_LAUNCH_CHECK("highway_stack_fwd");

@@ -7,6 +7,7 @@
 // category is not being recorded); end stamps the stop event and the launch's algorithmic FLOPs.
 int taco_prof_begin(int which, hipStream_t s);
 void taco_prof_end(int which, int slot, hipStream_t s, double flops);
+void taco_prof_label(int which, int slot, const char* fmt, ...) __attribute__((format(printf, 3, 4)));   // no-op when slot < 0
 
 // ---------------------------------------------------------------- gemm.hip
 constexpr int kMaxGemmBatch = 16;
@@ -206,15 +207,6 @@ struct InitBatch {
   }
 };
 int launch_init_batch(InitBatch& b, hipStream_t s);   // communication-kernel stand-in (tests)
-
-// ---------------------------------------------------------------- data-parallel options (model.hip, taco_dp_config)
-// overlap_bptt: segment 2's all-reduce may start BEFORE the decoder BPTT kernel (else: after it); lds_reserve_bytes: LDS every
-// persistent decoder workgroup leaves free on its CU for a co-resident communication workgroup.
-struct DpConfig {
-  int overlap_bptt = 0;
-  int lds_reserve_bytes = 0;
-};
-const DpConfig& taco_dp();
 
 // ---------------------------------------------------------------- bigru.hip
 struct BiGruWeights {

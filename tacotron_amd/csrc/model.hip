@@ -4,6 +4,7 @@
 //   taco_forward  = Tacotron.inference(train=True) + add_loss_op       (tacotron.py:107-165)
 //   taco_backward = opt.compute_gradients(loss)                        (tacotron.py:172)
 //   taco_infer    = Tacotron.inference(train=False)                    (tacotron.py:107-154, ops.py:5-25)
+#include <cstdarg>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -45,29 +46,14 @@ struct ProfRing {
   static constexpr int kCap = 4096;
   hipEvent_t start[kCap], stop[kCap];
   double flops[kCap];
+  char label[kCap][96];   // what the launch was (taco_prof_label; read by taco_debug_profile_labels before taco_profile_read2)
   int created = 0;   // events created so far (lazily, in steps: creating 2 x 4096 events up front costs milliseconds)
   int n = 0;
 };
 ProfRing g_prof[4];
 int g_prof_mask = 0;   // bit c: category c is recorded
 
-DpConfig g_dp;
-bool g_dp_init = false;
-
 }  // namespace
-
-// Data-parallel options: process-wide, set by taco_dp_config (the host's GradReducer) or, before the first call, by the
-// environment (TACO_DP_OVERLAP_BPTT=1, TACO_DEC_LDS_RESERVE_KB=n).
-const DpConfig& taco_dp() {
-  if (!g_dp_init) {
-    g_dp_init = true;
-    const char* e = getenv("TACO_DP_OVERLAP_BPTT");
-    if (e) g_dp.overlap_bptt = atoi(e) != 0;
-    e = getenv("TACO_DEC_LDS_RESERVE_KB");
-    if (e) g_dp.lds_reserve_bytes = atoi(e) * 1024;
-  }
-  return g_dp;
-}
 
 int taco_prof_begin(int which, hipStream_t s) {
   if (!(g_prof_mask & (1 << which))) return -1;
@@ -78,7 +64,15 @@ int taco_prof_begin(int which, hipStream_t s) {
     ++r.created;
   }
   (void)hipEventRecord(r.start[r.n], s);
+  r.label[r.n][0] = 0;
   return r.n;
+}
+void taco_prof_label(int which, int slot, const char* fmt, ...) {
+  if (slot < 0) return;
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_prof[which].label[slot], sizeof(g_prof[which].label[slot]), fmt, ap);
+  va_end(ap);
 }
 void taco_prof_end(int which, int slot, hipStream_t s, double flops) {
   if (slot < 0) return;
@@ -264,15 +258,16 @@ DecWeights dec_weights(const float* P, const ParamLayout& L) {
 // Side stream: work that is independent of the main chain runs here while a 64-workgroup recurrent kernel (bi-GRU) or the
 // encoder leaves most of the chip idle.  side_fork(): the side stream waits for everything enqueued on `s` so far;
 // side_join(): `s` waits for the side work.  No host synchronisation; TACO_NO_OVERLAP=1 keeps everything on `s`.
+constexpr int kGradSegments = 4;
 struct SideStream {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool off = false;
-  // gradient-segment events of the most recent taco_backward issued by this thread on this device
-  // (taco_wait_grad_segment): [0] encoder, [1] decoder, [2] post-net segment of the flat gradient buffer is final
-  hipEvent_t ev_seg[3] = {nullptr, nullptr, nullptr};
+  // gradient-segment events of the most recent taco_backward issued by this thread on this device (taco_wait_grad_segment):
+  // segment [3] post-net, [2] decoder, [1] encoder projections / highways / bi-GRU, [0] embedding + encoder pre_net + conv bank
+  // of the flat gradient buffer is final
+  hipEvent_t ev_seg[kGradSegments] = {nullptr, nullptr, nullptr, nullptr};
   bool seg_recorded = false;
-  hipEvent_t ev_post = nullptr;   // deferred post-net weight gradients done (taco_backward)
 };
 SideStream& side_stream() {
   static thread_local SideStream ss[16];
@@ -383,6 +378,24 @@ DecComposite dec_composite(const float* ws, const WsLayout& W, int r) {
 
 int prepare_transposes(const float* P, const ParamLayout& L, const TransLayout& T, float* PT, int r, hipStream_t s);
 int build_dec_composites_bwd(const float* P, const ParamLayout& PL, const WsLayout& W, float* ws, int r, hipStream_t s);
+
+// One line on stderr, once per shape, when a launch takes decoder.hip instead of decoder3.hip: Config.validate accepts shapes
+// (r = 1, 3, 4, B > 32, Tt > 256) that the fast kernels do not cover, and the fallback costs about 2x per decoder step.
+void note_decoder_fallback(int B, int Tt, int r) {
+  static std::mutex mu;
+  static std::map<std::tuple<int, int, int>, bool> seen;
+  std::lock_guard<std::mutex> g(mu);
+  bool& s = seen[std::make_tuple(B, Tt, r)];
+  if (s || getenv("TACO_QUIET")) return;
+  s = true;
+  const int mode = taco_decoder_mode(-1);
+  if (mode >= 2)
+    fprintf(stderr, "taco: decoder mode %d (TACO_DEC_V3=0 or escalated after an exchange time-out): decoder.hip runs the decoder "
+                    "(about 2x slower per step than decoder3.hip)\n", mode);
+  else
+    fprintf(stderr, "taco: B=%d Tt=%d r=%d is outside decoder3.hip's scope (B <= 32, Tt <= 256, r in {2, 5}, all 256 workgroups "
+                    "co-resident): decoder.hip runs the decoder, about 2x slower per step\n", B, Tt, r);
+}
 
 // encoder + attention memory + decoder + post-net; shared by train and inference forward.
 int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const float* P, const int32_t* text,
@@ -504,7 +517,10 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
     const int slot = prof_begin(0, s);
     da.xchg_zeroed = 1;
     int rc = launch_decoder3_fwd(da, s);
-    if (rc == TACO_ENOTFOUND) rc = launch_decoder_fwd(da, s);
+    if (rc == TACO_ENOTFOUND) {
+      note_decoder_fallback(B, Tt, r);
+      rc = launch_decoder_fwd(da, s);
+    }
     TACO_TRY(rc);
     prof_end(0, slot, s);
   }
@@ -532,10 +548,6 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
 // Weight-gradient GEMM.  Inside a TnGroup scope the call is queued and launched with its independent siblings in ONE grid
 // (launch_gemm_tn_batch); otherwise it is launched immediately.
 thread_local GemmTnBatch* g_tnq = nullptr;
-// Deferred sink: while set, weight-gradient problems are only COLLECTED (post-net CBHG backward); taco_backward launches them
-// later on the side stream, so that they run underneath the decoder BPTT kernel (which is latency bound and leaves the matrix
-// pipes and most issue slots of every CU idle; the GEMM workgroups co-reside with it -- tools/coresident_probe.py).
-thread_local std::vector<GemmTnArgs>* g_tn_defer = nullptr;
 // Side routing: while set, every weight-gradient launch issued for stream `s` goes to this stream instead, ordered behind the
 // work enqueued on `s` so far by an event.  The CBHG backward passes use it: their ~27 weight-gradient GEMMs (0.5 / 0.7 ms per
 // step) feed nothing but the gradient buffer, so they run beside the activation-gradient chain -- much of which is small
@@ -577,10 +589,6 @@ int tn(const float* A, int lda, int K, const float* Y, int ldy, int N, float* W,
   a.Nld = Nld;
   a.A = A; a.lda = lda; a.Y = Y; a.ldy = ldy; a.W = W; a.ldw = ldw; a.M = M; a.N = N; a.K = K; a.taps = taps; a.T = T;
   a.pad_l = pad_l;
-  if (g_tn_defer) {
-    g_tn_defer->push_back(a);
-    return TACO_OK;
-  }
   if (g_tnq) {
     if (g_tnq->n == kMaxTnBatch) TACO_TRY(tn_launch_batch(*g_tnq, s));
     g_tnq->p[g_tnq->n++] = a;
@@ -677,16 +685,18 @@ int build_dec_composites_bwd(const float* P, const ParamLayout& PL, const WsLayo
 
 struct BwdScratch {
   float *gA, *gB, *gC, *gD, *gE, *gF, *gG;
-  // When the weight-gradient GEMMs are deferred their operands must outlive the rest of cbhg_bwd: these three buffers then
-  // replace the in-place reuse of gD / gC / gA (d pj1, d z1, d pool); null = reuse as before.
+  // When the weight-gradient GEMMs run on the side stream their operands must outlive the chain's in-place reuse: these three
+  // buffers then replace gD / gC / gA (d pj1, d z1, d pool); null = reuse as before.
   float *alt_dpj1 = nullptr, *alt_dz1 = nullptr, *alt_dpool = nullptr;
   bool dx_zeroed = false;   // dx_out was zeroed by the caller (taco_backward's batched init launch)
 };
 
 // CBHG backward.  dOut (M,256) -> dX (M,cin) written to `dx_out`; parameter gradients accumulated into G.
 // x is the CBHG input.  Scratch: gA/gB (M, K*128), gC (M,768), gD..gG (M,256).
+// seg_after_p1 >= 0: that gradient segment (projections, highways, bi-GRU -- everything of this CBHG except the conv bank) is
+// announced as soon as its last contributor, proj1's weight gradient, has been enqueued.
 int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const CbhgT& t, const float* x, const float* dOut,
-             int B, int T, const CbhgBufs& w, const BwdScratch& sc, float* dx_out, hipStream_t s) {
+             int B, int T, const CbhgBufs& w, const BwdScratch& sc, float* dx_out, int seg_after_p1, hipStream_t s) {
   const int M = B * T, KC = c.K * kCb;
   // ---- bi-GRU ----
   float* dxg = sc.gC;   // (M,768)
@@ -809,9 +819,16 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
     p.taps = 3; p.T = T; p.pad_l = 1; p.act = TACO_ACT_NONE;
     TACO_TRY(launch_conv_gemm(p, s));
   }
-  float* dz1 = sc.alt_dz1 ? sc.alt_dz1 : sc.gC;    // (M,c1)  (dxg no longer needed unless its weight gradients are deferred)
+  float* dz1 = sc.alt_dz1 ? sc.alt_dz1 : sc.gC;    // (M,c1)  (dxg no longer needed unless its weight gradients run on the side stream)
   TACO_TRY(launch_affine_act_bwd(w.pj1pre, P + c.p1_g, dpj1, dz1, G + c.p1_g, G + c.p1_be, M, c.c1, TACO_ACT_RELU, s));
   TACO_TRY(tn(w.pool, KC, KC, dz1, c.c1, c.c1, G + c.p1_w, c.c1, M, T, 1, s, 3, G + c.p1_b));
+  if (seg_after_p1 >= 0) {
+    // every gradient in [p1_w, end of this CBHG) has been enqueued: on the weight-gradient stream (ordered behind the main
+    // stream's work so far by tn_route's event), or on `s` itself
+    hipStream_t q;
+    TACO_TRY(tn_route(s, &q));
+    TACO_TRY(record_segment(seg_after_p1, q));
+  }
   float* dpool = sc.alt_dpool ? sc.alt_dpool : sc.gA;  // (M,KC)
   float* dbank = sc.gB;  // (M,KC)
   {
@@ -968,7 +985,7 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
   // ONE batched init launch for every accumulator of the pass: the gradient buffer, [d keys | E] (one (M1, 512) buffer), the small
   // decoder weight-gradient factors, the two CBHG input-gradient accumulators (when they have buffers of their own) and the
   // decoder exchange area (the forward kernel is long done with it)
-  const bool own_dx = getenv("TACO_NO_SIDE_TN") == nullptr && getenv("TACO_DEFER_POST_TN") == nullptr && !side_stream().off &&
+  const bool own_dx = getenv("TACO_NO_SIDE_TN") == nullptr && !side_stream().off &&
                       side_stream().side != nullptr;
   {
     InitBatch ib;
@@ -1000,64 +1017,31 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
   hipStream_t side = side_fork(s);
   TACO_TRY(tn(pb.out, 2 * kCb, 2 * kCb, dOutPad, 1028, kFft, G + PL.post_dense.w, kFft, M2, M2, 0, side, 1, G + PL.post_dense.b, 1028));
   // ---- post-net CBHG (input = seq2seq_output viewed as (B, Td*r, 80)) ----
-  // Only the activation-gradient chain is on the critical path to the decoder BPTT: the CBHG's ~27 weight-gradient GEMMs are
-  // collected here and launched on the side stream below, where they run underneath the (latency-bound) BPTT kernel.
-  // OPT-IN (TACO_DEFER_POST_TN=1).  Measured on MI355X (S1): step 15.68 -> 15.59 ms; the BPTT kernel itself stretches from
-  // 5.12 to 5.64 ms while it shares its CUs with 0.62 ms worth of GEMMs (tools/coresident_probe.py: both sides run ~1.5x
-  // slower while they overlap), so the net gain is 0.6 % -- not worth making the dominant kernel's timing depend on it.
-  const bool defer = side != s && getenv("TACO_DEFER_POST_TN") != nullptr;
-  std::vector<GemmTnArgs> post_tn;
+  // The CBHG's ~27 weight-gradient GEMMs feed nothing but the gradient buffer: they go to the side stream (g_tn_side) and run
+  // beside the activation-gradient chain, much of which is small launches that leave most CUs idle.  (Running them UNDERNEATH
+  // the BPTT kernel instead was measured in rounds 2 and 3 -- both sides run ~1.5x slower while they share CUs, net 0.6 % -- and
+  // removed in round 4 together with the data-parallel mode that overlapped collectives with that launch.)
   BwdScratch scp = sc;
   float* dPostIn = sc.gC;   // (M2, 80)
-  if (defer) {
-    scp.alt_dpj1 = ws + W.post_dpj1; scp.alt_dz1 = ws + W.post_dz1; scp.alt_dpool = ws + W.post_dpool;
-    dPostIn = ws + W.post_dx;
-    g_tn_defer = &post_tn;
-  }
-  const bool side_tn = side != s && !defer && getenv("TACO_NO_SIDE_TN") == nullptr;
+  const bool side_tn = side != s && getenv("TACO_NO_SIDE_TN") == nullptr;
   if (side_tn) {
     scp.alt_dpj1 = ws + W.post_dpj1; scp.alt_dz1 = ws + W.post_dz1; scp.alt_dpool = ws + W.post_dpool;
     dPostIn = ws + W.post_dx;
     scp.dx_zeroed = own_dx;
     g_tn_side = side;
   }
-  const int rc_post = cbhg_bwd(P, PT, G, PL.post, TL.post, seq2seq_output, dPostOut, B, F, pb, scp, dPostIn, s);
-  g_tn_defer = nullptr;
+  const int rc_post = cbhg_bwd(P, PT, G, PL.post, TL.post, seq2seq_output, dPostOut, B, F, pb, scp, dPostIn, -1, s);
   g_tn_side = nullptr;
   TACO_TRY(rc_post);
   // d seq2seq_output = sign(s2s - mel) + post-net path
   float* dS2S = ws + W.ds2s_tot;
   if (side_tn && own_dx && !taco_deterministic()) dS2S = dPostIn;   // (accumulated on top of the L1 term, see the init launch)
   else TACO_TRY(launch_add(ws + W.ds2s, dPostIn, dS2S, (int64_t)MD * R80, s));
-  SideStream& ssx = side_stream();
-  if (defer) {
-    // side: wait for the producers of the deferred operands (everything enqueued on `s` so far), then the grouped launches
-    if (hipEventRecord(ssx.ev_fork, s) != hipSuccess || hipStreamWaitEvent(side, ssx.ev_fork, 0) != hipSuccess) {
-      taco_set_error("taco_backward: event record/wait failed");
-      return TACO_ELAUNCH;
-    }
-    GemmTnBatch gb;
-    for (const GemmTnArgs& q : post_tn) {
-      if (gb.n == kMaxTnBatch) TACO_TRY(launch_gemm_tn_batch(gb, side));
-      gb.p[gb.n++] = q;
-    }
-    if (gb.n) TACO_TRY(launch_gemm_tn_batch(gb, side));
-    if (!ssx.ev_post && hipEventCreateWithFlags(&ssx.ev_post, hipEventDisableTiming) != hipSuccess) {
-      taco_set_error("taco_backward: cannot create an event");
-      return TACO_ELAUNCH;
-    }
-    (void)hipEventRecord(ssx.ev_post, side);
-    // gradient segment 2 (post-net CBHG + final dense) is final when the side stream gets here: data-parallel callers start
-    // its all-reduce at this point, under the decoder BPTT (taco_wait_grad_segment)
-    TACO_TRY(record_segment(2, side));
-  } else {
-    TACO_TRY(side_join(s, side));
-    // Default (taco_dp_config overlap_bptt = 0): segment 2 is ANNOUNCED only after the BPTT kernel below, so that a collective
-    // waiting for it can never compete with the persistent decoder launch for CUs (that kernel needs all B * P workgroups
-    // co-resident; a communication kernel that takes CUs first would leave part of every cluster spinning on peers that
-    // cannot start).  The bytes then travel under the encoder backward instead -- 2 ms of ordinary kernels.
-    if (taco_dp().overlap_bptt) TACO_TRY(record_segment(2, s));
-  }
+  TACO_TRY(side_join(s, side));
+  // Gradient segment 3 (post-net CBHG + final dense) is final HERE, but it is ANNOUNCED only after the BPTT kernel below: that
+  // kernel is a persistent launch that needs all 256 workgroups co-resident, one per CU, and a collective's kernel that took
+  // CUs first would leave part of every cluster spinning on peers that cannot start.  The bytes travel under the encoder
+  // backward instead -- 1.5 ms of ordinary kernels.
 
   // ---- decoder BPTT ----
   float* gs = ws + W.gstash;
@@ -1087,12 +1071,7 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     if (rc == TACO_ENOTFOUND) rc = launch_decoder_bwd(a, s);
     TACO_TRY(rc);
     prof_end(1, slot, s);
-    if (!defer && !taco_dp().overlap_bptt) TACO_TRY(record_segment(2, s));
-    // the scratch buffers the deferred post-net GEMMs read are reused from here on
-    if (defer && hipStreamWaitEvent(s, ssx.ev_post, 0) != hipSuccess) {
-      taco_set_error("taco_backward: event wait failed");
-      return TACO_ELAUNCH;
-    }
+    TACO_TRY(record_segment(3, s));
   }
   // ---- attention memory.  The kernel never forms the context or its gradient (decoder.hip); everything they carried follows
   //      from E[b] = sum_t alignments[b,t-1]^T dx[b,t]  (Tt x 256 per row; one batched launch):
@@ -1191,9 +1170,9 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
                             kPre1, TACO_ACT_NONE);
     b2.p[1].residual = G + PL.out_proj.b + (R80 - kMel); b2.p[1].ldr = R80;
     TACO_TRY(launch_conv_gemm_batch(b2, s));
-    // gradient segment 1 (memory layer + decoder) is final here: everything the main stream contributed (memory-layer
+    // gradient segment 2 (memory layer + decoder) is final here: everything the main stream contributed (memory-layer
     // kernel, attention_v from the BPTT kernel) was enqueued before this side stream forked
-    TACO_TRY(record_segment(1, s));
+    TACO_TRY(record_segment(2, s));
   }
   // ---- encoder CBHG ----
   float* dP2 = sc.gC;       // (M1,128)
@@ -1212,7 +1191,7 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     pre_dz2 = ws + W.pre_dz2; pre_dz1 = ws + W.pre_dz1; pre_demb = ws + W.pre_demb;
     g_tn_side = side_stream().side;
   }
-  int rc_enc = cbhg_bwd(P, PT, G, PL.enc, TL.enc, ws + W.p2, dEnc, B, Tt, eb, sce, dP2, s);
+  int rc_enc = cbhg_bwd(P, PT, G, PL.enc, TL.enc, ws + W.p2, dEnc, B, Tt, eb, sce, dP2, 1, s);
   if (rc_enc != TACO_OK) {
     g_tn_side = nullptr;
     return rc_enc;
@@ -1253,14 +1232,15 @@ extern "C" int taco_grad_segments(const TacoShape* shape, int64_t* bounds) {
   TACO_REQUIRE(bounds != nullptr, "taco_grad_segments: null bounds");
   const ParamLayout& PL = layouts_for(*shape).P;
   bounds[0] = 0;
-  bounds[1] = PL.mem_w;            // [0, mem_w): embedding(s) + encoder pre_net + encoder CBHG
-  bounds[2] = PL.post.bank_w[0];   // [mem_w, post): attention memory layer + decoder
-  bounds[3] = PL.total;            // [post, total): post-net CBHG + final dense
-  return 3;
+  bounds[1] = PL.enc.p1_w;         // [0, enc proj1): embedding(s) + encoder pre_net + encoder conv bank (final LAST)
+  bounds[2] = PL.mem_w;            // [enc proj1, mem_w): encoder projections, highways, bi-GRU
+  bounds[3] = PL.post.bank_w[0];   // [mem_w, post): attention memory layer + decoder
+  bounds[4] = PL.total;            // [post, total): post-net CBHG + final dense (final FIRST)
+  return kGradSegments;
 }
 
 extern "C" int taco_wait_grad_segment(int seg, void* stream) {
-  TACO_REQUIRE(seg >= 0 && seg < 3, "taco_wait_grad_segment: segment %d out of range", seg);
+  TACO_REQUIRE(seg >= 0 && seg < kGradSegments, "taco_wait_grad_segment: segment %d out of range", seg);
   SideStream& x = side_stream();
   TACO_REQUIRE(x.seg_recorded && x.ev_seg[seg], "taco_wait_grad_segment: no taco_backward was issued by this thread on this device");
   if (hipStreamWaitEvent(as_stream(stream), x.ev_seg[seg], 0) != hipSuccess) {
@@ -1379,14 +1359,6 @@ extern "C" int taco_fill_bernoulli(uint8_t* out, int64_t n, float p_one, uint64_
 
 extern "C" int taco_debug_last_cluster(int which) { return decoder_last_cluster(which); }
 
-extern "C" int taco_dp_config(int overlap_bptt, int lds_reserve_kb) {
-  TACO_REQUIRE(lds_reserve_kb >= 0 && lds_reserve_kb <= 96, "taco_dp_config: lds_reserve_kb=%d out of range [0, 96]", lds_reserve_kb);
-  (void)taco_dp();   // (environment defaults first, so that they do not overwrite this call later)
-  g_dp.overlap_bptt = overlap_bptt != 0;
-  g_dp.lds_reserve_bytes = lds_reserve_kb * 1024;
-  return TACO_OK;
-}
-
 extern "C" int taco_debug_spin(int blocks, int threads, int lds_bytes, int usec, void* stream) {
   return launch_spin(blocks, threads, lds_bytes, usec, as_stream(stream));
 }
@@ -1410,6 +1382,19 @@ extern "C" int taco_profile_read2(int which, float* ms, double* flops, int cap) 
   }
   r.n = 0;
   return n;
+}
+
+extern "C" int taco_debug_profile_labels(int which, char* buf, int cap) {
+  TACO_REQUIRE(which >= 0 && which < 4 && buf && cap > 0, "profile_labels: bad arguments");
+  ProfRing& r = g_prof[which];
+  int pos = 0;
+  for (int i = 0; i < r.n; ++i) {
+    const int w = snprintf(buf + pos, cap - pos, "%s\n", r.label[i]);
+    if (w < 0 || pos + w >= cap) break;
+    pos += w;
+  }
+  buf[pos < cap ? pos : cap - 1] = 0;
+  return r.n;
 }
 
 extern "C" int taco_profile_read(int which, float* ms, int cap) { return taco_profile_read2(which, ms, nullptr, cap); }

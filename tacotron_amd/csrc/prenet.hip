@@ -241,11 +241,11 @@ __global__ __launch_bounds__(256, 2) void mlp2_kernel(PrenetArgs a) {
 template <int K1, int N1, int N2, bool BWD>
 int launch_mlp2(const PrenetArgs& a, hipStream_t s, const char* what) {
   constexpr size_t smem = sizeof(float) * (size_t)(K1 + N1) * PPAD;
-  static const bool ok = smem <= 64 * 1024 ||
-                         hipFuncSetAttribute(reinterpret_cast<const void*>(mlp2_kernel<K1, N1, N2, BWD>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess;
-  TACO_REQUIRE(ok, "%s: cannot reserve %zu bytes of LDS", what, smem);
+  static DynSmemOnce once;
+  TACO_REQUIRE(ensure_dyn_smem(once, reinterpret_cast<const void*>(mlp2_kernel<K1, N1, N2, BWD>), smem),
+               "%s: cannot reserve %zu bytes of LDS", what, smem);
   const int pslot = taco_prof_begin(2, s);
+  taco_prof_label(2, pslot, "%s M=%d", what, a.M);
   hipLaunchKernelGGL((mlp2_kernel<K1, N1, N2, BWD>), dim3(cdiv(a.M, PB)), dim3(256), smem, s, a);
   taco_prof_end(2, pslot, s, 2.0 * a.M * ((double)K1 * N1 + (double)N1 * N2));
   return TACO_OK;

@@ -9,7 +9,14 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-import torch
+# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  One train step uses the caller's
+# stream, the library's side stream, the weight-gradient stream and -- data parallel -- a communication stream plus RCCL's own:
+# with 4 queues two of them share a queue and one's kernels sit behind a millisecond of the other's already-enqueued launches
+# (measured in round 4: the post-net segment's collective finished 1.47 ms after it became eligible, 30 us with 8 queues).
+# The variable is read when the HIP runtime initialises, i.e. at the first device call -- set it before anything touches the GPU.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
+import torch  # noqa: E402
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TACO_LIB') or os.path.join(_HERE, 'libtaco_hip.so')   # TACO_LIB: an alternative build (tuning A/B)
@@ -63,7 +70,7 @@ EXPORTS = {
     'taco_clear_error': (C.c_int, [_SH, _I, _P, _P]),
     'taco_grad_segments': (C.c_int, [_SH, C.POINTER(C.c_int64)]),
     'taco_wait_grad_segment': (C.c_int, [_I, _P]),
-    'taco_dp_config': (C.c_int, [_I, _I]),
+    'taco_decoder_mode': (C.c_int, [_I]),
     'taco_debug_spin': (C.c_int, [_I, _I, _I, _I, _P]),
     'taco_denorm_unframe': (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'taco_griffinlim_workspace_bytes': (C.c_int64, [_I, _I]),
@@ -72,6 +79,7 @@ EXPORTS = {
     'taco_profile_enable': (C.c_int, [_I]),
     'taco_debug_last_cluster': (C.c_int, [_I]),
     'taco_profile_read': (C.c_int, [_I, C.POINTER(C.c_float), _I]),
+    'taco_debug_profile_labels': (C.c_int, [_I, C.c_char_p, _I]),
     'taco_profile_read2': (C.c_int, [_I, C.POINTER(C.c_float), C.POINTER(C.c_double), _I]),
 }
 for _name, (_res, _args) in EXPORTS.items():
@@ -211,13 +219,13 @@ def clear_error(shape, train, workspace):
 
 
 def grad_segments(shape):
-    """Float offsets [b0, b1, b2, b3] of the three gradient segments (encoder, decoder, post-net); they become final in
-    the order 2, 1, 0 during taco_backward."""
-    b = (C.c_int64 * 4)()
+    """Float offsets [b0 .. b4] of the four gradient segments (0 embedding + encoder pre_net + conv bank, 1 rest of the
+    encoder, 2 decoder, 3 post-net); they become final in the order 3, 2, 1, 0 during taco_backward."""
+    b = (C.c_int64 * 8)()
     n = _lib.taco_grad_segments(C.byref(shape), b)
-    if n != 3:
+    if n < 1 or n > 7:
         raise TacoError('taco_grad_segments: ' + last_error())
-    return [int(x) for x in b]
+    return [int(x) for x in b[:n + 1]]
 
 
 def wait_grad_segment(seg, stream):
@@ -225,9 +233,10 @@ def wait_grad_segment(seg, stream):
     _check(_lib.taco_wait_grad_segment(int(seg), C.c_void_p(stream.cuda_stream)), 'taco_wait_grad_segment')
 
 
-def dp_config(overlap_bptt=False, lds_reserve_kb=0):
-    """Process-wide data-parallel options (include/taco_hip.h taco_dp_config)."""
-    _check(_lib.taco_dp_config(int(bool(overlap_bptt)), int(lds_reserve_kb)), 'taco_dp_config')
+def decoder_mode(mode=-1) -> int:
+    """Process-wide decoder mode (include/taco_hip.h): 0 decoder3 fast exchange, 1 decoder3 agent-scope exchange, 2 decoder.hip.
+    Sets it when mode >= 0; returns the PREVIOUS mode."""
+    return _lib.taco_decoder_mode(int(mode))
 
 
 def debug_spin(blocks, threads, lds_bytes, usec, stream=None):
@@ -276,6 +285,16 @@ def last_cluster(which: int) -> int:
 def profile_enable(mask):
     """mask: bit c = category c (0 decoder fwd, 1 decoder bwd, 2 GEMM family, 3 bi-GRU); True = both decoder kernels."""
     _check(_lib.taco_profile_enable(3 if mask is True else int(mask)), 'taco_profile_enable')
+
+
+def profile_labels(which: int):
+    """What each launch currently in ring `which` was (kernel family + shape); call before profile_read."""
+    cap = 1 << 19
+    buf = C.create_string_buffer(cap)
+    n = _lib.taco_debug_profile_labels(int(which), buf, cap)
+    if n < 0:
+        raise TacoError('taco_debug_profile_labels: ' + last_error())
+    return buf.value.decode().split('\n')[:n]
 
 
 def profile_read(which: int, with_flops=False):

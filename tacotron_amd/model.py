@@ -163,8 +163,16 @@ class Tacotron(object):
         flags = self._err.tolist()
         if flags[0] or flags[1]:
             lib.clear_error(self.shape, self.train, self.workspace)
-            raise lib.TacoError('decoder cluster exchange timed out (forward=%d, backward=%d); parameter updates were '
-                                'skipped while the flag was set' % (flags[0], flags[1]))
+            # self-heal: the next launches of this PROCESS use the next more conservative decoder mode (include/taco_hip.h
+            # taco_decoder_mode: XCD-local exchange -> agent-scope exchange -> decoder.hip); the caller decides whether to go on
+            mode = lib.decoder_mode()
+            e = lib.TacoError('decoder cluster exchange timed out (forward=%d, backward=%d) in decoder mode %d; parameter updates '
+                              'were skipped while the flag was set%s' %
+                              (flags[0], flags[1], mode, '; switched to decoder mode %d' % (mode + 1) if mode < 2 else ''))
+            e.recoverable = mode < 2
+            if mode < 2:
+                lib.decoder_mode(mode + 1)
+            raise e
 
     def placement_census(self):
         """Diagnostic, accumulated over the decoder-forward launches since the last clear_error(); host synchronisation.

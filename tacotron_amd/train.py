@@ -11,6 +11,7 @@ import pickle as pkl
 import numpy as np
 import torch
 
+from . import config as config_module
 from .config import SAVE_EVERY, Config
 from .data import synthetic_batch
 from .dist import GradReducer, init_from_env
@@ -98,12 +99,20 @@ def train(config, num_steps=1000000, log_every=50, save_every=SAVE_EVERY):
         return {k: torch.from_numpy(v[idx]) for k, v in data.items()}
 
     # same initial parameters on every rank (seed 0); the dropout / sampling streams are offset by the reducer's rank
-    model = Tacotron(config, next_batch(0), train=True, seed=0, reducer=GradReducer() if world > 1 else None)
+    # TACO_FORCE_DIST=1 at world size 1 takes every distributed branch too (as bench.py does): reducer, collectives, barriers
+    forced = torch.distributed.is_initialized() and world == 1
+    distributed = world > 1 or forced
+    model = Tacotron(config, next_batch(0), train=True, seed=0, reducer=GradReducer(force=forced) if distributed else None)
     model.stft_mean, model.stft_std = stft_mean, stft_std
     ckpt_prefix = os.path.join('weights', config.save_path)   # 'weights/nancy/tacotron' or 'weights/debug'
     if config.restore:
-        path = latest_checkpoint(ckpt_prefix)
+        # train.py:49-58: the latest checkpoint, unless the module constant RESTORE_FROM names a step -- then exactly
+        # '<prefix>-<RESTORE_FROM>' (a missing file is an error there as well: saver.restore raises)
+        restore_from = config_module.RESTORE_FROM
+        path = latest_checkpoint(ckpt_prefix) if restore_from is None else '%s-%s' % (ckpt_prefix, restore_from)
         if path is not None:
+            if restore_from is not None and not os.path.exists(path):
+                raise FileNotFoundError('RESTORE_FROM=%s: %s does not exist' % (restore_from, path))
             model.load_state_dict(torch.load(path))
             if rank == 0:
                 print('restored %s (global_step %d)' % (path, model.global_step))
@@ -114,8 +123,12 @@ def train(config, num_steps=1000000, log_every=50, save_every=SAVE_EVERY):
         gs = model.global_step
         if gs % log_every == 0 or gs % save_every == 0:
             loss = float(model.loss)                      # the only host sync, every log_every steps
-            model.check()                                 # decoder exchange time-outs surface here (sticky flag; the
-            #                                               guarded Adam update skipped itself in the meantime)
+            try:
+                model.check()                             # decoder exchange time-outs surface here (sticky flag; the
+            except Exception as e:                        # guarded Adam update skipped itself in the meantime)
+                if not getattr(e, 'recoverable', False):
+                    raise
+                print('WARNING (rank %d): %s -- continuing' % (rank, e))   # check() moved to a more conservative decoder mode
             if rank == 0:
                 print('step %d loss %.1f gnorm %.2f' % (gs, loss, float(model.global_gradient_norm)))
             if loss > 1e8 and gs > 500:                   # train.py:77-80
@@ -130,10 +143,13 @@ def train(config, num_steps=1000000, log_every=50, save_every=SAVE_EVERY):
                 torch.save(model.state_dict(), '%s-%d' % (ckpt_prefix, gs))
                 print('saving sample')
                 save_sample(model, os.path.join('log', config.save_path), gs)
-            if world > 1:
+            if distributed:
                 # rank 0 spent a while on the host; the others must not run ahead into the next step's collectives (and the
                 # persistent decoder kernels of a rank that waits inside a collective keep spinning on their peers)
                 torch.distributed.barrier()
+    if torch.distributed.is_initialized():
+        torch.cuda.synchronize()
+        torch.distributed.destroy_process_group()
     return model
 
 

@@ -7,7 +7,10 @@ configs[3]  free-running inference at Tt=140 (data_input.MAX_TEXT_LEN), Td=180, 
 configs[4]  VCTK shape on one GPU: 109 speakers at S1 (B=32, Tt=200, Td=180) -- forward + every gradient incl. the speaker
             table and the per-layer speaker adapters
 Stated tolerances: outputs rel-L2 <= 1e-4 / max-abs <= 1e-3, alignments max-abs <= 1e-5, loss rel <= 1e-5,
-gradients rel-L2 <= 1e-3 per tensor, arg-max exact where the oracle's top-1/top-2 margin >= 1e-5."""
+gradients rel-L2 <= 1e-3 per tensor (with the HIP path's ReLU / max-pool decisions imposed on the fp64 graph where the two
+disagree within rounding -- the disagreements are listed and bounded, tests/decisions.py), arg-max exact where the oracle's
+top-1/top-2 margin >= 1e-5.
+configs[1]+ S1 with PEAKED attention (trained-model regime): arg-max bit-exact on >= 95 % of the 5,760 (b,t)."""
 import os
 
 import numpy as np
@@ -124,13 +127,28 @@ def test_config4_vctk_109_speakers_full_size(built_lib):
     got_tab = R.pb.to_dict(R.grads)[tab[0]]
     unused = np.setdiff1d(np.arange(S), used)
     assert np.all(got_tab[unused] == 0) and np.all(np.abs(got_tab[used]).sum(1) > 0)
-    # Stated 1e-3 for every tensor but the two at the very bottom of the encoder: their reference norm is ~20x smaller than
-    # the gradients feeding them (cancellation), and ONE ReLU / max-pool tie inside the CBHG that fp32 and fp64 decide
-    # differently moves them by ~1e-3 here (test_encoder_bottom_gradient_deviation_is_localized shows that this is where the
-    # whole deviation lives: ten adjacent positions of one sequence; everywhere else the input gradient agrees to 1e-6).
-    bad = check_grads(R, {k: v for k, v in ref.items() if k not in ('embedding', 'encoder/pre_net/dense/kernel')}, tol=1e-3)
+    # Every tensor at the stated 1e-3 -- with the HIP path's DISCRETE decisions imposed on the fp64 graph.  Without that, ONE
+    # ReLU / max-pool decision that fp32 and fp64 take differently (a pre-activation within rounding of its boundary) moves the
+    # two tensors at the very bottom of the encoder by ~1e-3, because their reference norm is ~20x smaller than the gradients
+    # feeding them.  The flips are exhibited, not assumed: read back from the workspace, compared with the fp64 decisions, and
+    # each one must sit within rounding of its boundary.
+    from tests.decisions import as_force, flips, hip_decisions
+    hip, ok, how = hip_decisions(R, p, masks, B, Tt, Td, r, S)
+    dec = ot.Decisions()
+    ot.loss_and_grads(p, f64(adj), r, Td, f64(masks), dec=dec)
+    fl = flips(hip, ok, dec)
+    n_dec = sum(v.size for v in hip.values())
+    print('  BN affine reproduced as %s; %d of %d discrete decisions differ from fp64:' % (how, len(fl), n_dec))
+    for name, idx, mg in fl[:20]:
+        print('    %-34s %-18s fp64 margin %.2e' % (name, idx, mg))
+    assert len(fl) <= 64, 'more decision flips than rounding can explain: %d' % len(fl)
+    assert all(mg <= 1e-5 for _, _, mg in fl), fl
+    _, _, _, _, ref_forced = ot.loss_and_grads(p, f64(adj), r, Td, f64(masks), dec=ot.Decisions(as_force(hip)))
+    bad = check_grads(R, ref_forced, tol=1e-3)
     assert not bad, bad
-    bad = check_grads(R, {k: ref[k] for k in ('embedding', 'encoder/pre_net/dense/kernel')}, tol=5e-3)
+    # ... and without the forcing, everything except what lies below a flipped decision still meets it
+    below = ('embedding', 'encoder/pre_net/dense/kernel') if any(n.startswith('encoder/cbhg') for n, _, _ in fl) else ()
+    bad = check_grads(R, {k: v for k, v in ref.items() if k not in below}, tol=1e-3)
     assert not bad, bad
 
 
@@ -161,7 +179,8 @@ def test_encoder_bottom_gradient_deviation_is_localized(built_lib):
     R.forward()
     R.backward()
     got = R.pb.to_dict(R.grads)['embedding'].reshape(V, 256).astype(np.float64)
-    ref = ot.loss_and_grads(p, f64(inp), r, Td, f64(masks))[4]['embedding'].reshape(V, 256)
+    dec = ot.Decisions()
+    ref = ot.loss_and_grads(p, f64(inp), r, Td, f64(masks), dec=dec)[4]['embedding'].reshape(V, 256)
     err2 = ((got - ref) ** 2).sum(-1)
     srt = np.sort(err2)[::-1]
     med = float(np.sqrt(np.median(err2)) / np.sqrt(np.median((ref ** 2).sum(-1))))
@@ -172,3 +191,74 @@ def test_encoder_bottom_gradient_deviation_is_localized(built_lib):
     assert med <= 1e-5
     overall = np.sqrt(err2.sum()) / np.linalg.norm(ref)
     assert overall <= 2e-4 or top64 >= 0.99
+    # The cause, exhibited: the encoder-CBHG decisions the HIP path took differently from fp64.  Each sits within rounding of its
+    # boundary, the squared error lives inside their receptive field (same sequence, within 12 positions: bank taps +-8, pool
+    # +1, three 3-tap projections / the highway path +-3), and with the HIP path's decisions imposed on the fp64 graph the whole
+    # per-position gradient agrees.
+    from tests.decisions import as_force, flips, hip_decisions
+    hip, ok, how = hip_decisions(R, p, masks, B, Tt, Td, r, S)
+    fl = [f for f in flips(hip, ok, dec)]
+    enc_fl = [f for f in fl if f[0].startswith('encoder/')]
+    print('  %d decision flips (%d in the encoder), BN affine as %s' % (len(fl), len(enc_fl), how))
+    for name, idx, mg in fl[:20]:
+        print('    %-34s %-18s fp64 margin %.2e' % (name, idx, mg))
+    assert all(mg <= 1e-5 for _, _, mg in fl), fl
+    if overall > 2e-4:
+        assert enc_fl, 'a localised deviation without a flipped encoder decision'
+        near = np.zeros(V, dtype=bool)
+        for name, idx, mg in enc_fl:
+            if len(idx) == 3:
+                b_, t_ = idx[0], idx[1]
+                near[b_ * Tt + max(0, t_ - 12): b_ * Tt + min(Tt, t_ + 13)] = True
+        inside = float(err2[near].sum() / err2.sum())
+        print('  %.2f%% of the squared error lies within 12 positions of a flipped decision' % (100 * inside))
+        assert inside >= 0.99
+    ref_forced = ot.loss_and_grads(p, f64(inp), r, Td, f64(masks), dec=ot.Decisions(as_force(hip)))[4]['embedding'].reshape(V, 256)
+    forced = float(np.linalg.norm(got - ref_forced) / np.linalg.norm(ref_forced))
+    print('  with the HIP decisions imposed on the fp64 graph: overall rel-L2 %.2e' % forced)
+    assert forced <= 2e-4
+
+
+def test_config1_peaked_attention_full_size(built_lib):
+    """north_star's "bit-exact attention arg-max" is about TRAINED (peaked) attention at full size; at initialisation the
+    softmax over 200 positions is nearly flat (max alpha ~ 0.016) and only a third of the (b,t) of S1 have a margin at all.
+    Here the S1 shape (B=32, Tt=200, Td=180, r=2) runs with oracle.make_golden's peaking (attention_v x100, memory_layer x8,
+    query_layer x4 on perturbed parameters: max alpha median 0.999, > 0.9 on 74 % of the steps, 143 distinct arg-max positions,
+    every top-1/top-2 margin >= 1e-4; generated on the fly, the fp64 oracle takes seconds): arg-max bit-exact on >= 95 % of the
+    5,760 (b,t) -- forward, backward, and 180 steps of free-running inference.  Energies are O(1e3) here, so the alignment
+    tolerance is 1e-4 as for the committed medium fixture (fp32 rounding of the energy sum; see make_golden.make_peaked)."""
+    from oracle.make_golden import PEAKED_SCALES
+    from tests.test_gpu_model import _full_case
+    B, Tt, Td, r, V = 32, 200, 180, 2, 60
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    inp, masks = _full_case(B, Tt, Td, r, V)
+    p = on.init_params(V, r, seed=11, perturb=0.3)
+    for k, sc in PEAKED_SCALES:
+        p[k] = p[k] * sc
+    R = Runner(built_lib, B, Tt, Td, r, V)
+    R.set(p, inp, masks)
+    R.forward()
+    R.backward()
+    adj, n_ties = l1_tie_adjusted(R, p, inp, masks, r, Td)
+    lt, s2, o2, a2, ref = ot.loss_and_grads(p, f64(adj), r, Td, f64(masks))
+    al = R.al.cpu().numpy()
+    r1, m1 = report('S1 peaked seq2seq_output', R.s2s.cpu().numpy(), s2)
+    r2, m2 = report('S1 peaked output', R.out.cpu().numpy(), o2)
+    r3, m3 = report('S1 peaked alignments', al, a2)
+    assert r1 < 1e-4 and m1 < 1e-3 and r2 < 1e-4 and m2 < 1e-3 and m3 < 1e-4
+    assert abs(R.loss[0].item() - lt) <= 1e-5 * lt
+    mx = a2.max(-1)
+    assert float(np.median(mx)) > 0.9 and float((mx > 0.9).mean()) > 0.5 and len(np.unique(a2.argmax(-1))) > 50
+    n = _argmax_check(al, a2, inp['text_length'])
+    assert n >= 0.95 * B * Td, 'only %d of %d (b,t) clear the margin' % (n, B * Td)
+    bad = check_grads(R, ref, tol=1e-3)
+    assert not bad, bad
+    Ri = Runner(built_lib, B, Tt, Td, r, V, train=False)
+    Ri.set(p, {'text': inp['text'], 'text_length': inp['text_length']})
+    Ri.infer()
+    si, oi, ai = _oracle_infer(p, inp['text'], inp['text_length'], r, Td)
+    ri1, mi1 = report('S1 peaked infer seq2seq_output', Ri.s2s.cpu().numpy(), si)
+    ri3, mi3 = report('S1 peaked infer alignments', Ri.al.cpu().numpy(), ai)
+    assert ri1 < 1e-4 and mi3 < 1e-4
+    ni = _argmax_check(Ri.al.cpu().numpy(), ai, inp['text_length'])
+    assert ni >= 0.95 * B * Td

@@ -182,3 +182,34 @@ def test_griffinlim_oracle_stft_istft_are_consistent():
     e0 = gl.spectral_convergence(gl.griffinlim(mag, ph, 0), mag)
     e20 = gl.spectral_convergence(gl.griffinlim(mag, ph, 20), mag)
     assert e20 < 0.6 * e0
+
+
+def test_decisions_record_and_force_are_consistent():
+    """oracle.taco_torch.Decisions: recording changes nothing, and forcing the graph's OWN decisions reproduces its loss and
+    gradients (to summation-order rounding); forcing ONE flipped ReLU decision changes the gradient below that unit."""
+    from tests.util import small_case
+    r, V, B, Tt, Td = 2, 20, 2, 9, 5
+    p = on.init_params(V, r, seed=3, perturb=0.2)
+    inp, masks = small_case(r=r, V=V, B=B, Tt=Tt, Td=Td)
+    f = lambda d: {k: (np.asarray(v, dtype=np.float64) if np.asarray(v).dtype.kind in 'fu' and k not in ('text', 'text_length') else v)
+                   for k, v in d.items()}
+    l0, _, _, _, g0 = ot.loss_and_grads(p, f(inp), r, Td, f(masks))
+    dec = ot.Decisions()
+    l1, _, _, _, g1 = ot.loss_and_grads(p, f(inp), r, Td, f(masks), dec=dec)
+    assert l0 == l1
+    sites = set(dec.rec)
+    assert {'encoder/cbhg/bank', 'encoder/cbhg/pool', 'encoder/cbhg/proj1', 'encoder/cbhg/highway_3/H', 'post/cbhg/pool',
+            'encoder/pre_net/l1', 'decoder/pre_net/l2@%d' % (Td - 1)} <= sites
+    force = {k: v.to(torch.float64) for k, v in dec.rec.items()}
+    l2, _, _, _, g2 = ot.loss_and_grads(p, f(inp), r, Td, f(masks), dec=ot.Decisions(force))
+    assert abs(l2 - l0) <= 1e-12 * abs(l0)
+    for k in g0:
+        if g0[k] is not None:
+            assert np.abs(g0[k] - g1[k]).max() <= 1e-12 * (np.abs(g0[k]).max() + 1e-300), k
+            assert np.abs(g0[k] - g2[k]).max() <= 1e-12 * (np.abs(g0[k]).max() + 1e-300), k
+    flipped = dict(force)
+    m = flipped['encoder/cbhg/bank'].clone()
+    m[0, 4, 7] = 1.0 - m[0, 4, 7]
+    flipped['encoder/cbhg/bank'] = m
+    _, _, _, _, g3 = ot.loss_and_grads(p, f(inp), r, Td, f(masks), dec=ot.Decisions(flipped))
+    assert np.abs(g3['encoder/pre_net/dense_1/kernel'] - g0['encoder/pre_net/dense_1/kernel']).max() > 0

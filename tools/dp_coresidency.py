@@ -1,11 +1,10 @@
 """Data-parallel co-residency probe (VERDICT r2 #1a): does a collective-sized kernel on a second stream disturb the
 persistent decoder BPTT launch (256 workgroups x 512 threads, up to 158 KB LDS each -- one per CU, every CU), and the other way
 round?  RCCL cannot run with one GPU, so an RCCL-footprint stand-in is used: 64 workgroups x 256 threads x 64 KB LDS spinning
-for a fixed time (taco_debug_spin).  Measured per mode (taco_dp_config) and per dispatch order:
+for a fixed time (taco_debug_spin), enqueued exactly where GradReducer enqueues the post-net segment's all-reduce:
 
-  bptt_ms      BPTT kernel launch -> end (HIP events on its stream; includes any wait for CUs).  Default mode: decoder3_bwd_kernel,
-               which fills every CU and therefore never runs beside a collective (segment 2 is announced after it); opt-in
-               overlap mode: decoder.hip's decoder_bwd_kernel, which leaves the LDS reserve and half the register file free
+  bptt_ms      BPTT kernel launch -> end (HIP events on its stream; includes any wait for CUs): decoder3_bwd_kernel fills every
+               CU and therefore must never run beside a collective -- the post-net segment is announced AFTER it
   spin_ms      stand-in enqueue-point -> end on the communication stream (nominal = its spin time; more = it waited for CUs)
   bwd_ms       whole taco_backward on the main stream
   err          decoder error words (exchange time-outs)
@@ -31,8 +30,8 @@ def build_model(B=32, Tt=200, Td=180):
 
 
 def one(m, masks, order, spin_us, comm):
-    """order: None (no stand-in), 'first' (stand-in enqueued just before taco_backward), 'segment' (on the communication stream
-    behind taco_wait_grad_segment(2), i.e. exactly where GradReducer would enqueue the post-net all-reduce)."""
+    """order: None (no stand-in), 'segment' (on the communication stream behind taco_wait_grad_segment(3), i.e. exactly where
+    GradReducer enqueues the post-net all-reduce)."""
     from tacotron_amd import lib
     m.forward(masks)
     torch.cuda.synchronize()
@@ -41,18 +40,12 @@ def one(m, masks, order, spin_us, comm):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     main = torch.cuda.current_stream()
-    if order == 'first':
-        comm.wait_stream(main)
-        with torch.cuda.stream(comm):
-            e0.record(comm)
-            lib.debug_spin(SPIN_BLOCKS, SPIN_THREADS, SPIN_LDS, spin_us, comm)
-            e1.record(comm)
     b0.record(main)
     m.backward()
     b1.record(main)
     if order == 'segment':
         with torch.cuda.stream(comm):
-            lib.wait_grad_segment(2, comm)
+            lib.wait_grad_segment(3, comm)
             e0.record(comm)
             lib.debug_spin(SPIN_BLOCKS, SPIN_THREADS, SPIN_LDS, spin_us, comm)
             e1.record(comm)
@@ -71,7 +64,7 @@ def one(m, masks, order, spin_us, comm):
 def measure(spin_us=2000, reps=3, verbose=True):
     from tacotron_amd import lib
     m, masks = build_model()
-    comm = torch.cuda.Stream()
+    comm = torch.cuda.Stream(priority=-1)   # as GradReducer's communication stream
     out = {}
     for _ in range(2):
         one(m, masks, None, 0, comm)
@@ -80,15 +73,9 @@ def measure(spin_us=2000, reps=3, verbose=True):
         v = sorted(x[k] for x in xs if x[k] is not None)
         return v[len(v) // 2] if v else None
 
-    cases = [('solo', (0, 0), None, 0),
-             ('solo, overlap_bptt mode (decoder.hip BPTT kernel + 64 KB LDS reserve)', (1, 64), None, 0),
-             ('default: segment 2 announced after the BPTT kernel', (0, 0), 'segment', spin_us),
-             ('overlap_bptt + 64 KB LDS reserve, stand-in behind the segment event', (1, 64), 'segment', spin_us),
-             ('overlap_bptt + 64 KB LDS reserve, stand-in dispatched first', (1, 64), 'first', 2 * spin_us),
-             ('overlap_bptt, NO reserve, stand-in behind the segment event', (1, 0), 'segment', spin_us),
-             ('overlap_bptt, NO reserve, stand-in dispatched first', (1, 0), 'first', 2 * spin_us)]
-    for name, (ov, kb), order, us in cases:
-        lib.dp_config(ov, kb)
+    cases = [('solo', None, 0),
+             ('default: post-net segment announced after the BPTT kernel', 'segment', spin_us)]
+    for name, order, us in cases:
         runs = [one(m, masks, order, us, comm) for _ in range(reps)]
         r = {k: med(runs, k) for k in ('bptt_ms', 'bwd_ms', 'spin_ms', 'spin_start_after_bwd_start_ms')}
         r['err'] = [max(x['err'][0] for x in runs), max(x['err'][1] for x in runs)]
@@ -98,7 +85,6 @@ def measure(spin_us=2000, reps=3, verbose=True):
             print('%-72s bptt %.2f ms  backward %.2f ms  stand-in %s (nominal %.1f, enqueue point %s ms after backward start)  err %s' %
                   (name, r['bptt_ms'], r['bwd_ms'], '%.2f ms' % r['spin_ms'] if r['spin_ms'] is not None else '-', us / 1e3,
                    '%.2f' % r['spin_start_after_bwd_start_ms'] if r['spin_start_after_bwd_start_ms'] is not None else '-', r['err']))
-    lib.dp_config(0, 0)
     return out
 
 

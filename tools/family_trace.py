@@ -21,6 +21,7 @@ N = 4
 for _ in range(N): m.step()
 torch.cuda.synchronize()
 lib.profile_enable(0)
+labels = lib.profile_labels(2)
 ms, fl = lib.profile_read(2, with_flops=True)
 n = len(ms) // N
 tot = 0.0
@@ -28,7 +29,7 @@ print('%d launches per step' % n)
 for i in range(n):
     t = sum(ms[i + k * n] for k in range(N)) / N
     tot += t
-    print('#%2d %8.1f us %8.2f GF %6.1f TF' % (i, t * 1e3, fl[i] / 1e9, fl[i] / (t * 1e-3) / 1e12 if t > 0 else 0))
+    print('#%2d %8.1f us %8.2f GF %6.1f TF  %s' % (i, t * 1e3, fl[i] / 1e9, fl[i] / (t * 1e-3) / 1e12 if t > 0 else 0, labels[i] if i < len(labels) else ''))
 print('sum %.1f us' % (tot * 1e3))
 rm = lib.profile_read(3)
 print('bigru', ['%.1f' % (x * 1e3) for x in rm[:4]])
