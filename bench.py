@@ -139,6 +139,29 @@ def family_profile(model, steps=3):
             'bigru_ms': sum(rm) / steps, 'bigru_launches': len(rm) / steps}
 
 
+def sustained_fp32_mfma():
+    """What the library's own NN kernel sustains on a 4096^3 fp32 GEMM on THIS box (two full waves of 128 x 128 tiles, 128 k-tiles
+    each: no tail, no epilogue to speak of).  The 157.3 TFLOP/s peak assumes 2.4 GHz; under sustained fp32 MFMA load the chip
+    clocks to its power budget (PMC: ~2.05 GHz at 80 % matrix-pipe utilisation, profiles/r04_gemm_pmc.txt), so this number -- not
+    157.3 -- is what a GEMM-family fraction can approach here."""
+    from tacotron_amd import lib
+    n = 4096
+    A = torch.randn(n, n, device='cuda')
+    W = torch.randn(1, n, n, device='cuda') * 0.05
+    C = torch.empty(n, n, device='cuda')
+    for _ in range(2):
+        lib.conv_gemm(A, W, C, n, n, n, taps=1, T=n, pad_l=0, act=0)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        lib.conv_gemm(A, W, C, n, n, n, taps=1, T=n, pad_l=0, act=0)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    return 2.0 * n ** 3 / (ms * 1e-3) / 1e12
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -277,15 +300,20 @@ def main():
         achieved = flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         # HBM-side traffic per launch from the PMC passes of tools/profile_round.sh -- only if they were collected on THIS
         # build of the kernels (source hash), else null
-        traffic = None
+        traffic = traffic_step = None
         pmc = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
         if os.path.exists(pmc):
             try:
                 pj = json.load(open(pmc))
                 if pj.get('build') == source_hash():
                     traffic = pj.get(dom, {}).get('hbm_bytes_per_launch')
+                    st = pj.get('step')
+                    if st:
+                        traffic_step = {'bytes': st['step_bytes'], 'algorithmic_bytes': st['algorithmic_step_bytes'],
+                                        'ratio': st['ratio'],
+                                        'families': {k: v['bytes'] for k, v in st['families'].items()}}
             except Exception:
-                traffic = None
+                traffic = traffic_step = None
         PEAK = 157.3
         step_flops = 3 * model_flops(B, Tt, Td, c.r)
         rooflines = [
@@ -294,6 +322,7 @@ def main():
             {'what': dom, 'bound': 'mfma', 'limiter': 'latency', 'achieved': achieved, 'peak': PEAK, 'unit': 'TFLOP/s',
              'frac': achieved / PEAK,
              'avg_ms': dom_ms, 'us_per_decoder_step': dom_ms * 1e3 / Td, 'flops_per_launch': flops, 'traffic': traffic,
+             'traffic_step': traffic_step,
              'traffic_source': 'profiles/pmc_latest.json (rocprofv3 --pmc passes of tools/profile_round.sh; a committed constant, '
                                'used only when its source hash equals this build -- not measured in this run)' if traffic else None,
              'note': 'persistent recurrence (decoder3.hip: 8 clusters x 32 workgroups x 4 rows, register-resident weights): %d strictly '
@@ -305,8 +334,12 @@ def main():
         ]
         if fam and fam['gemm_ms'] > 0:
             g = fam['gemm_flops'] / (fam['gemm_ms'] * 1e-3) / 1e12
+            sus = sustained_fp32_mfma()
             rooflines.insert(1, {'what': 'MFMA GEMM family (conv_gemm + gemm_tn + fused highway launches)', 'bound': 'mfma',
                                  'achieved': g, 'peak': PEAK, 'unit': 'TFLOP/s', 'frac': g / PEAK,
+                                 'sustained_fp32_mfma_tflops': sus, 'frac_of_sustained': g / sus,
+                                 'sustained_note': 'a 4096^3 fp32 GEMM on the same kernel, measured in this run: the chip clocks down '
+                                                   'under sustained fp32 MFMA load (DVFS), so 157.3 TFLOP/s is not reachable on random data',
                                  'ms_per_step_summed': fam['gemm_ms'], 'flops_per_step': fam['gemm_flops'],
                                  'launches_per_step': fam['gemm_launches'],
                                  'note': 'HIP events around every launch; measured in a separate pass with the side stream switched off '

@@ -50,8 +50,16 @@ constexpr bool kProbes3 = true;   // timing probes (garbage results, real timing
 #else
 constexpr bool kProbes3 = false;
 #endif
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+#if !defined(TACO_NO_POLL128)
+constexpr bool kPoll128 = true;    // polls fetch a unit's TWO granules with one 16-byte buffer load (round 4); -DTACO_NO_POLL128: A/B
+#else
+constexpr bool kPoll128 = false;
+#endif
 struct Xc {
   gu64* base;
+  __amdgpu_buffer_rsrc_t rs;   // the cluster's granule area as a raw buffer: polls are `buffer_load_dwordx4 ... offen sc1`
   unsigned epoch;
   int* err;
   int* dead;   // LDS
@@ -94,9 +102,6 @@ __device__ __forceinline__ bool spin_fail(unsigned& spin, const Xc& X) {
   return false;
 }
 
-// All-gather of an N-column vector (R rows per column) published in region `reg`: every thread polls up to MAXU units of
-// G = min(R, 2) adjacent granules until their tags carry this step's epoch.  own(n): column computed by this workgroup (already
-// in LDS).  put(n, rho, v): LDS state update.
 // threadIdx.x behind an opaque move: everything a round derives from it (columns, row selections, stash / granule / LDS addresses)
 // is recomputed at the head of that round with a handful of VALU ops instead of being hoisted out of the step loop into
 // long-lived registers (first build: 256 VGPRs + 350 spilled; the resident weights need that room)
@@ -108,114 +113,146 @@ __device__ __forceinline__ int opaque_tid() {
 struct NeedAll {
   __device__ __forceinline__ bool operator()(int, int) const { return true; }
 };
-// NP: number of polling threads (the first NP of the workgroup, whole waves).  The others pass through WITHOUT touching the
-// vector-memory counter, so loads they have in flight (the backward kernel's next-step prefetch) keep flying across this round.
-template <int R, int MAXU, int NP = NT, class Own, class Put, class Need = NeedAll>
-__device__ __forceinline__ void gather(Xc& X, int reg, int N, Own own, Put put, Need need = Need()) {
-  constexpr int G = R >= 2 ? 2 : 1;
-  constexpr int UPC = R / G;   // units per column
-  static_assert(NP % 64 == 0 && NP <= NT, "pollers are whole waves");
-  const int tid = opaque_tid();
-  if (NP < NT && tid >= NP) return;
-  const bool skip = *X.dead || (kProbes3 && (X.fake & 2));
+// Work done in the shadow of a gather's first poll (round 4): the poll loads are in flight for >= one L2 round trip (~500 cycles)
+// whatever the peers do, and with register-resident weights a partial mat-vec needs nothing but LDS reads and FMAs -- no
+// vector-memory instruction that would queue behind the polls.  Every round whose NEXT mat-vec has inputs that are already
+// final (the recurrent half of the next gate mat-vec, the [cell_output ; h1] rows of round G0) computes that part here.
+#if !defined(TACO_NO_SHADOW)
+constexpr bool kShadow = true;    // -DTACO_NO_SHADOW: the whole mat-vec in its own round, as in round 3 (A/B builds)
+#else
+constexpr bool kShadow = false;
+#endif
+// round E's shadow (the [cell_output ; h1] rows of the next G0): bit 0 = the x mat-vec's part, bits 1-2 = the gates' part:
+// 2 = all of it (rows >= 128; 13 weight registers -- measured: spills), 4 = its first five registers only (the cell_output rows)
+#ifndef TACO_ESHADOW
+#define TACO_ESHADOW 5
+#endif
+constexpr int kEShadow = kShadow ? TACO_ESHADOW : 0;
+template <int KPLG0, int MODE>
+struct EShadowSplit {
+  static constexpr int lo = 4;                                                   // first weight register behind the pre-net rows
+  static constexpr int hi = (MODE & 2) ? KPLG0 : ((MODE & 4) ? (KPLG0 < 9 ? KPLG0 : 9) : 4);   // shadow covers [lo, hi)
+};
+// One poll of a unit = G adjacent granules ([value, epoch] pairs, 8 bytes each).  G == 2: ONE 16-byte load through the buffer
+// resource (agent scope = sc1: served by the L2, never by this CU's L1) with a 32-bit byte offset -- half the vector-memory
+// instructions of two 8-byte atomic loads and no 64-bit address arithmetic; each 8-byte half is written by one store, so a
+// half is never torn (MI355X guide, R2 granules; the epoch tag of each half is checked by itself).
+template <int G>
+struct Unit {
+  unsigned val[G], tag[G];
+};
+template <int G>
+__device__ __forceinline__ Unit<G> poll_unit(const Xc& X, unsigned granule_index) {
+  Unit<G> u;
+  if constexpr (G == 2 && kPoll128) {
+    const v4u g = __builtin_amdgcn_raw_buffer_load_b128(X.rs, granule_index * 8u, 0, 16 /* sc1 */);
+    u.val[0] = g[0]; u.tag[0] = g[1]; u.val[1] = g[2]; u.tag[1] = g[3];
+  } else {
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+      const u64 g = __hip_atomic_load(X.base + granule_index + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      u.val[q] = (unsigned)g;
+      u.tag[q] = (unsigned)(g >> 32);
+    }
+  }
+  return u;
+}
+
+// An all-gather in two halves, so that the caller can put straight-line work between them (the poll SHADOW, see above):
+//   gather_begin   decides what this thread polls and issues the first batch of poll loads
+//   gather_end     checks them, stores what has arrived through put(n, rho, v) and keeps polling the rest
+// Col maps a unit's column number to its granule column (one region, or two regions behind each other).
+template <int R, int MAXU>
+struct GatherState {
+  static constexpr int G = R >= 2 ? 2 : 1;
   int un[MAXU], uh[MAXU];
   bool pend[MAXU];
-  bool any = false;
+  bool any;
+  Unit<G> g[MAXU];
+};
+struct OneRegion {
+  int reg;
+  __device__ __forceinline__ int operator()(int n) const { return reg + n; }
+};
+struct TwoRegions {
+  int reg1, n1, reg2;
+  __device__ __forceinline__ int operator()(int n) const { return n < n1 ? reg1 + n : reg2 + n - n1; }
+};
+template <int R, int MAXU, int NP, class Col>
+__device__ __forceinline__ void poll_batch(Xc& X, GatherState<R, MAXU>& S, Col col) {
+  constexpr int G = GatherState<R, MAXU>::G;
+  if (kProbes3) X.polls++;
+#pragma unroll
+  for (int i = 0; i < MAXU; ++i)
+    if (S.pend[i]) S.g[i] = poll_unit<G>(X, (unsigned)(col(S.un[i]) * R + S.uh[i] * G));
+}
+template <int R, int MAXU, int NP = NT, class Col, class Own>
+__device__ __forceinline__ GatherState<R, MAXU> gather_begin(Xc& X, Col col, int N, Own own) {
+  constexpr int G = GatherState<R, MAXU>::G;
+  constexpr int UPC = R / G;   // units per column
+  static_assert(NP % 64 == 0 && NP <= NT, "pollers are whole waves");
+  GatherState<R, MAXU> S;
+  const int tid = opaque_tid();
+  const bool skip = (NP < NT && tid >= NP) || *X.dead || (kProbes3 && (X.fake & 2));
+  S.any = false;
 #pragma unroll
   for (int i = 0; i < MAXU; ++i) {
     const int u = tid + i * NP;
-    un[i] = UPC == 2 ? (u >> 1) : u;
-    uh[i] = UPC == 2 ? (u & 1) : 0;
-    pend[i] = !skip && un[i] < N && !own(un[i]);
-    any |= pend[i];
+    S.un[i] = UPC == 2 ? (u >> 1) : u;
+    S.uh[i] = UPC == 2 ? (u & 1) : 0;
+    S.pend[i] = !skip && S.un[i] < N && !own(S.un[i]);
+    S.any |= S.pend[i];
   }
+  if (S.any) poll_batch<R, MAXU, NP>(X, S, col);
+  return S;
+}
+template <int R, int MAXU, int NP = NT, class Col, class Put, class Need = NeedAll>
+__device__ __forceinline__ void gather_end(Xc& X, GatherState<R, MAXU>& S, Col col, Put put, Need need = Need()) {
+  constexpr int G = GatherState<R, MAXU>::G;
   unsigned spin = 0;
-  while (any) {
-    if (kProbes3) X.polls++;
-    u64 g[MAXU][G];
+  while (S.any) {
+    S.any = false;
 #pragma unroll
     for (int i = 0; i < MAXU; ++i)
-      if (pend[i]) {
-        const gu64* p = X.base + (unsigned)((reg + un[i]) * R + uh[i] * G);
-#pragma unroll
-        for (int q = 0; q < G; ++q) g[i][q] = __hip_atomic_load(p + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    any = false;
-#pragma unroll
-    for (int i = 0; i < MAXU; ++i)
-      if (pend[i]) {
+      if (S.pend[i]) {
         bool ok = true;
 #pragma unroll
-        for (int q = 0; q < G; ++q) ok &= (unsigned)(g[i][q] >> 32) == X.epoch || !need(un[i], uh[i] * G + q);
+        for (int q = 0; q < G; ++q) ok &= S.g[i].tag[q] == X.epoch || !need(S.un[i], S.uh[i] * G + q);
         if (ok) {
 #pragma unroll
           for (int q = 0; q < G; ++q)
-            if (need(un[i], uh[i] * G + q)) put(un[i], uh[i] * G + q, __uint_as_float((unsigned)g[i][q]));
-          pend[i] = false;
+            if (need(S.un[i], S.uh[i] * G + q)) put(S.un[i], S.uh[i] * G + q, __uint_as_float(S.g[i].val[q]));
+          S.pend[i] = false;
         } else {
-          any = true;
+          S.any = true;
         }
       }
-    if (any && spin_fail(spin, X)) break;   // (fatal: the error word is set; every exit passes the wait below)
+    if (S.any) {
+      if (spin_fail(spin, X)) break;   // (fatal: the error word is set; every exit passes the wait below)
+      poll_batch<R, MAXU, NP>(X, S, col);
+    }
   }
   // Tell the compiler's wait-count pass that nothing of this loop is in flight any more (true: the last pass waited for its
   // loads).  Poll destinations that some path skipped would otherwise count as pending, and the next write of such a register --
   // anywhere, e.g. behind the next-step prefetch -- would get a full `s_waitcnt vmcnt(0)`.
   __builtin_amdgcn_s_waitcnt(0x0F70);
 }
-
+// All-gather of an N-column vector (R rows per column) published in region `reg`: every thread polls up to MAXU units of
+// G = min(R, 2) adjacent granules until their tags carry this step's epoch.  own(n): column computed by this workgroup (already
+// in LDS).  put(n, rho, v): LDS state update.
+// NP: number of polling threads (the first NP of the workgroup, whole waves).  The others pass through WITHOUT touching the
+// vector-memory counter, so loads they have in flight (the backward kernel's next-step prefetch) keep flying across this round.
+template <int R, int MAXU, int NP = NT, class Own, class Put, class Need = NeedAll>
+__device__ __forceinline__ void gather(Xc& X, int reg, int N, Own own, Put put, Need need = Need()) {
+  if (NP < NT && opaque_tid() >= NP) return;
+  auto S = gather_begin<R, MAXU, NP>(X, OneRegion{reg}, N, own);
+  gather_end<R, MAXU, NP>(X, S, OneRegion{reg}, put, need);
+}
 // The same over two regions in ONE poll loop: columns [0, N1) live in region reg1, columns [N1, N) in region reg2.
 template <int R, int MAXU, class Own, class Put, class Need = NeedAll>
 __device__ __forceinline__ void gather2(Xc& X, int reg1, int N1, int reg2, int N, Own own, Put put, Need need = Need()) {
-  constexpr int G = R >= 2 ? 2 : 1;
-  constexpr int UPC = R / G;
-  const bool skip = *X.dead || (kProbes3 && (X.fake & 2));
-  const int tid = opaque_tid();
-  int un[MAXU], uh[MAXU];
-  bool pend[MAXU];
-  bool any = false;
-#pragma unroll
-  for (int i = 0; i < MAXU; ++i) {
-    const int u = tid + i * NT;
-    un[i] = UPC == 2 ? (u >> 1) : u;
-    uh[i] = UPC == 2 ? (u & 1) : 0;
-    pend[i] = !skip && un[i] < N && !own(un[i]);
-    any |= pend[i];
-  }
-  unsigned spin = 0;
-  while (any) {
-    if (kProbes3) X.polls++;
-    u64 g[MAXU][G];
-#pragma unroll
-    for (int i = 0; i < MAXU; ++i)
-      if (pend[i]) {
-        const int col = un[i] < N1 ? reg1 + un[i] : reg2 + un[i] - N1;
-        const gu64* p = X.base + (unsigned)(col * R + uh[i] * G);
-#pragma unroll
-        for (int q = 0; q < G; ++q) g[i][q] = __hip_atomic_load(p + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    any = false;
-#pragma unroll
-    for (int i = 0; i < MAXU; ++i)
-      if (pend[i]) {
-        bool ok = true;
-#pragma unroll
-        for (int q = 0; q < G; ++q) ok &= (unsigned)(g[i][q] >> 32) == X.epoch || !need(un[i], uh[i] * G + q);
-        if (ok) {
-#pragma unroll
-          for (int q = 0; q < G; ++q)
-            if (need(un[i], uh[i] * G + q)) put(un[i], uh[i] * G + q, __uint_as_float((unsigned)g[i][q]));
-          pend[i] = false;
-        } else {
-          any = true;
-        }
-      }
-    if (any && spin_fail(spin, X)) break;   // (fatal: the error word is set; every exit passes the wait below)
-  }
-  // Tell the compiler's wait-count pass that nothing of this loop is in flight any more (true: the last pass waited for its
-  // loads).  Poll destinations that some path skipped would otherwise count as pending, and the next write of such a register --
-  // anywhere, e.g. behind the next-step prefetch -- would get a full `s_waitcnt vmcnt(0)`.
-  __builtin_amdgcn_s_waitcnt(0x0F70);
+  auto S = gather_begin<R, MAXU>(X, TwoRegions{reg1, N1, reg2}, N, own);
+  gather_end<R, MAXU>(X, S, TwoRegions{reg1, N1, reg2}, put, need);
 }
 
 // ---- register-resident mat-vec: column `col` of W (K x N, pitch ldw) split over LPC lanes; lane lk holds rows lk + LPC*j ----
@@ -271,15 +308,22 @@ __device__ __forceinline__ XV<R> lds_rows(const float* xp) {
   }
   return o;
 }
+// mat-vecs of at most this many rows per lane issue ALL their reads in one burst (0: never).  Measured in round 4 (same-box A/B,
+// profiles/r04_dec_ab.txt): 4 changes nothing, 8 is SLOWER (fwd 12.12 -> 12.34 us per step) although no register is spilled -- the
+// reads of eight waves queue on the CU's one LDS pipe either way, and a burst only delays the first FMA.
+#ifndef TACO_MV_BURST
+#define TACO_MV_BURST 0
+#endif
+constexpr int kMvBurst = TACO_MV_BURST;
 // x: LDS vector laid out [k][R].  The k loop is software-pipelined in chunks of CH rows (the next chunk's ds_reads are issued in
 // front of the current chunk's FMAs) with scheduling barriers at the chunk boundaries: left alone, hipcc hoists ALL KPL reads
 // of a mat-vec to its head (KPL x R live registers; with the resident weights that spilled ~500 registers to scratch).
-template <int R, int KPL, int LPC>
+template <int R, int KPL, int LPC, int CHX = 0>
 __device__ __forceinline__ void mv(const WReg<KPL>& r, const float* x, int lk, Acc<R>& a) {
 #ifdef TACO_MV_CH
-  constexpr int CH = TACO_MV_CH;
+  constexpr int CH = CHX ? CHX : TACO_MV_CH;
 #else
-  constexpr int CH = R == 4 ? 2 : 4;
+  constexpr int CH = CHX ? CHX : (KPL <= kMvBurst ? KPL : (R == 4 ? 2 : 4));
 #endif
   constexpr int NCH = (KPL + CH - 1) / CH;
   const float* xb = x + lk * R;
@@ -303,6 +347,18 @@ __device__ __forceinline__ void mv(const WReg<KPL>& r, const float* x, int lk, A
     __builtin_amdgcn_sched_barrier(0);
   }
 }
+// The same over the weight registers [J0, J1) only (rows lk + LPC * j of x): the part of a mat-vec whose inputs are final early.
+template <int R, int KPL, int LPC, int J0, int J1>
+__device__ __forceinline__ void mv_part(const WReg<KPL>& r, const float* x, int lk, Acc<R>& a) {
+  static_assert(0 <= J0 && J0 <= J1 && J1 <= KPL, "weight-register range");
+  constexpr int N = J1 - J0;
+  if constexpr (N > 0) {
+    WReg<N> sub;
+#pragma unroll
+    for (int j = 0; j < N; ++j) sub.w[j] = r.w[J0 + j];   // (register renaming only)
+    mv<R, N, LPC>(sub, x + (LPC * J0) * R, lk, a);
+  }
+}
 // Sum over the LPC lanes of a column group; afterwards the LAST 16-lane row of the group holds the total in every lane.
 // In-row steps: bound_ctrl DPP moves, which hipcc folds into v_add_f32_dpp (one instruction per step).  Cross-row steps
 // (row_bcast with a row mask): written as the fused v_add_f32_dpp by hand -- rows outside the mask keep their value -- since the
@@ -311,11 +367,100 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
   return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
+// ---- column sums, round 4: REDUCE-SCATTER.  A lane holds R partial sums (one per batch row) of its column; the lanes of a
+// column group (LPC of them) must end up with the R totals.  Reducing the R values one by one (round 3: 6 DPP steps x R) makes
+// 24 dependent-issue VALU operations per mat-vec at R = 4 -- with two waves per SIMD in lock step that is a few hundred cycles
+// of pure issue per round.  Instead the R values are folded TOGETHER: each fold step halves the lanes that carry a given
+// row's partials and, in the same instruction pair, the number of values per lane -- v_permlane16_swap / v_permlane32_swap
+// (gfx950) exchange 16- / 32-lane rows of two registers, so `swap + add` reduces TWO rows' values at once:
+//   fold16(x, y): lane rows [x0 x1 x2 x3], [y0 y1 y2 y3] -> [x0+x1, y0+y1, x2+x3, y2+y3]
+//   fold32(x, y): halves    [xlo xhi], [ylo yhi]         -> [xlo+xhi, ylo+yhi]
+// followed by an all-reduce inside the remaining 16 / 8 / 4 lanes with in-row DPP adds.  10-11 operations instead of 24 (R = 4),
+// 6-8 instead of 10-12 (R = 2).  Afterwards the total of batch row rs_rho<R, LPC>(lk) sits in EVERY lane of its sub-group; the
+// lane with rs_rho >= 0 (the first of the sub-group) is the result lane that runs the epilogue and publishes.
+// -DTACO_NO_RS restores round 3's form (A/B builds).
+__device__ __forceinline__ float fold16(float x, float y) {
+  const v2u r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float fold32(float x, float y) {
+  const v2u r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// keep = bit ? hi : lo, and the partner (a lane whose `bit` differs, reached by DPP control CTRL) contributes its copy of it
+template <int CTRL>
+__device__ __forceinline__ float scatter_step(bool bit, float lo, float hi) {
+  const float keep = bit ? hi : lo, send = bit ? lo : hi;
+  return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), CTRL, 0xf, 0xf, true));
+}
+#if !defined(TACO_NO_RS)
+constexpr bool kRS = true;
+#else
+constexpr bool kRS = false;
+#endif
+// Batch row (0..R-1) whose column total lane `lk` of a column group holds as the RESULT lane, or -1.
+template <int R, int LPC>
+__device__ __forceinline__ int rs_rho(int lk) {
+  if constexpr (R == 1 || !kRS) {
+    const int rho = lk - (LPC - 16);
+    return (rho >= 0 && rho < R) ? rho : -1;
+  } else if constexpr (R == 4) {
+    if constexpr (LPC == 64) return (lk & 15) == 0 ? (lk >> 4) : -1;
+    else if constexpr (LPC == 32) return (lk & 7) == 0 ? ((lk >> 3) & 1) * 2 + (lk >> 4) : -1;
+    else return (lk & 3) == 0 ? (lk >> 2) : -1;
+  } else {
+    static_assert(R == 2, "R in {1, 2, 4}");
+    if constexpr (LPC == 64) return (lk & 31) == 0 ? (lk >> 5) : -1;
+    else if constexpr (LPC == 32) return (lk & 15) == 0 ? (lk >> 4) : -1;
+    else return (lk & 7) == 0 ? (lk >> 3) : -1;
+  }
+}
+template <int R, int LPC>
+__device__ __forceinline__ void col_sum_rs(Acc<R>& a) {
+  static_assert(LPC == 64 || LPC == 32 || LPC == 16, "column groups of 64, 32 or 16 lanes");
+  const int lane = opaque_tid() & 63;
+  float v;
+  if constexpr (R == 4) {
+    if constexpr (LPC == 64) {
+      v = fold32(fold16(a.v[0], a.v[1]), fold16(a.v[2], a.v[3]));          // lane row j: batch row j, 16 partials
+      v = dpp_add<0xb1>(v); v = dpp_add<0x4e>(v); v = dpp_add<0x124>(v); v = dpp_add<0x128>(v);
+    } else if constexpr (LPC == 32) {
+      const float s = fold16(a.v[0], a.v[1]), t = fold16(a.v[2], a.v[3]);  // lane row j of a group: batch rows j (s) and 2 + j (t)
+      v = scatter_step<0x128>((lane & 8) != 0, s, t);                       // row_ror:8 -- half h of a lane row: batch row 2 h + j
+      v = dpp_add<0xb1>(v); v = dpp_add<0x4e>(v); v = dpp_add<0x141>(v);    // quads, then row_half_mirror
+    } else {
+      const float s = scatter_step<0x128>((lane & 8) != 0, a.v[0], a.v[2]); // half h: batch rows 2 h (s) and 2 h + 1 (t)
+      const float t = scatter_step<0x128>((lane & 8) != 0, a.v[1], a.v[3]);
+      v = scatter_step<0x141>((lane & 4) != 0, s, t);                       // row_half_mirror -- quad g of a half: batch row 2 h + g
+      v = dpp_add<0xb1>(v); v = dpp_add<0x4e>(v);
+    }
+  } else {
+    static_assert(R == 2, "R in {2, 4}");
+    if constexpr (LPC == 64) {
+      v = fold32(a.v[0], a.v[1]);                                           // half h: batch row h, 32 partials
+      v = fold16(v, v);                                                     // lane rows 0|1 and 2|3 folded into each other
+      v = dpp_add<0xb1>(v); v = dpp_add<0x4e>(v); v = dpp_add<0x124>(v); v = dpp_add<0x128>(v);
+    } else if constexpr (LPC == 32) {
+      v = fold16(a.v[0], a.v[1]);                                           // lane row j of a group: batch row j
+      v = dpp_add<0xb1>(v); v = dpp_add<0x4e>(v); v = dpp_add<0x124>(v); v = dpp_add<0x128>(v);
+    } else {
+      v = scatter_step<0x128>((lane & 8) != 0, a.v[0], a.v[1]);             // half h: batch row h
+      v = dpp_add<0xb1>(v); v = dpp_add<0x4e>(v); v = dpp_add<0x141>(v);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < R; ++q) a.v[q] = v;   // pick<R>(a, rho) of the result lane: its own value, whatever rho
+}
+
 // The R row sums of a column are independent chains: every DPP step is applied to all of them before the next step, so the
 // two wait states a DPP read needs behind the VALU write of its source are filled by the other rows instead of s_nops (the
 // cross-row steps are ONE asm statement per step for the same reason).
 template <int R, int LPC>
 __device__ __forceinline__ void col_sum_all(Acc<R>& a) {
+  if constexpr (kRS && R > 1) {
+    col_sum_rs<R, LPC>(a);
+    return;
+  }
 #pragma unroll
   for (int q = 0; q < R; ++q) a.v[q] = dpp_add<0xb1>(a.v[q]);    // quad_perm [1,0,3,2]
 #pragma unroll
@@ -368,6 +513,9 @@ struct Dims {
   static constexpr int KPL_O = kDec / LPC_O;
   static constexpr int KPLX = KAP / 64;
   static constexpr int KPLG0 = KGP / 32;
+  // round E's shadow mode (kEShadow); r = 5 keeps only the gates' cell_output rows: with 9 + 25 weight registers of round G0
+  // resident, the x part on top of it spills
+  static constexpr int kES = RR == 2 ? kEShadow : (kEShadow & 4);
   // LDS (floats)
   static constexpr int o_u0 = 0;
   static constexpr int o_xs = o_u0 + U0R * R;
@@ -427,8 +575,8 @@ __device__ __forceinline__ void static_for(F f) {
   }
 }
 
-// What a round needs to know about "this lane": which column of the round's vector it works on, and -- if it is one of the
-// lanes that end up holding a column total (lane c*LPC + LPC-16 + rho of its column group) -- which batch row it finishes.
+// What a round needs to know about "this lane": which column of the round's vector it works on, and -- if it is the RESULT lane
+// of a batch row's column total (rs_rho above) -- which batch row it finishes.
 // Derived from an opaque thread id at the head of every round (see opaque_tid).
 template <int R, int LPC>
 struct Lane {
@@ -440,8 +588,8 @@ struct Lane {
     lane = tid & 63;
     wave = tid >> 6;
     lk = lane & (LPC - 1);
-    rho = lk - (LPC - 16);
-    res = rho >= 0 && rho < R;
+    rho = rs_rho<R, LPC>(lk);
+    res = rho >= 0;
     if (!res) rho = 0;
   }
 };
@@ -477,6 +625,7 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
   const DecComposite& cw = a.c;
   Xc X;
   X.base = (gu64*)(reinterpret_cast<u64*>(a.xchg) + (int64_t)cl * R * kX3Row);
+  X.rs = __builtin_amdgcn_make_buffer_rsrc((void*)X.base, 0, R * kX3Row * 8, 0x00020000);
   // ---- placement rendezvous: every workgroup publishes its XCC id; a cluster whose 32 ids agree exchanges through its L2 ----
   {
     gi32* tab = (gi32*)(reinterpret_cast<int*>(a.xchg) + a.xcc_table_ofs);
@@ -604,14 +753,14 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
   float* const stash = a.stash;
   const bool kNoStash = false;
 #endif
-  // Batch row this lane STORES for when it is the result lane (lane c*LPC + LPC-16 + rho) of a valid row, else -1; one value per
+  // Batch row this lane STORES for when it is the result lane (rs_rho) of a valid row, else -1; one value per
   // column-group width.  Launch constants: three registers for the whole kernel instead of two select chains per store site.
   int sb64, sb32, sbO;
   {
-    const int r64 = lane - 48, r32 = (lane & 31) - 16, rO = (lane & (D::LPC_O - 1)) - (D::LPC_O - 16);
-    sb64 = (r64 >= 0 && r64 < R && rsel<R>(valid, r64)) ? rsel<R>(brow, r64) : -1;
-    sb32 = (r32 >= 0 && r32 < R && rsel<R>(valid, r32)) ? rsel<R>(brow, r32) : -1;
-    sbO = (rO >= 0 && rO < R && rsel<R>(valid, rO)) ? rsel<R>(brow, rO) : -1;
+    const int r64 = rs_rho<R, 64>(lane), r32 = rs_rho<R, 32>(lane & 31), rO = rs_rho<R, D::LPC_O>(lane & (D::LPC_O - 1));
+    sb64 = (r64 >= 0 && rsel<R>(valid, r64)) ? rsel<R>(brow, r64) : -1;
+    sb32 = (r32 >= 0 && rsel<R>(valid, r32)) ? rsel<R>(brow, r32) : -1;
+    sbO = (rO >= 0 && rsel<R>(valid, rO)) ? rsel<R>(brow, rO) : -1;
     if (kNoStash) sb64 = sb32 = sbO = -1;   // timing probe: no stash / output stores at all (results are garbage)
   }
   const unsigned ldp2 = (unsigned)a.ldpre2;
@@ -669,8 +818,8 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
       const int n = tid / R, q = tid - n * R;
       pk_p2 = rsel<R>(brow, q) * Td * (int)ldp2 + n;
     }
-    const int r64 = lane - 48;
-    if (r64 >= 0 && r64 < R) {
+    const int r64 = rs_rho<R, 64>(lane);
+    if (r64 >= 0) {
       if (a.keep1) pk_k1 = rsel<R>(brow, r64) * Td * kPre1 + peer * 8 + wave;
       if (a.keep2 && wave < 4) pk_k2 = rsel<R>(brow, r64) * Td * kPre2 + peer * 4 + wave;
     }
@@ -704,6 +853,13 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), other counters untouched
   park_next(1);
 
+  // partial sums formed in poll shadows (NoShadow builds: they stay zero and the rounds compute everything themselves):
+  //   g0x / g0g  the [cell_output ; h1] rows of round G0's two mat-vecs of the NEXT step (round E's gather; step 0: those rows are zero)
+  //   ghp        the recurrent half of the next gate mat-vec (rounds C0 / C1 -> G1 / G2)
+  Acc<R> g0x, g0g, ghp;
+  g0x.zero();
+  g0g.zero();
+  ghp.zero();
   for (int t = 0; t < Td; ++t) {
     X.epoch = (unsigned)(t + 1);
     if (kProbes3) {
@@ -721,16 +877,18 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
     RV from_out;   // set in round OUT from the parked flags
 
     // ---- round G0: x = [p2 ; out'] Wx + al' VWx + bi ;  gates_1 = sigmoid([p2 ; out' ; h1] Wg0' + al' VWg + bg0') ----
-    float ukeep = 0.f;   // update gate of the wave's unit, in the lanes (48 + rho) that finish its candidate column
+    // (the update gate of the wave's unit travels from the result lane of its gate column to the result lane of its candidate
+    //  column through the LDS slot US[unit][rho]: with the reduce-scatter sums those are different lanes)
     {
       const Lane<R, 64> L;
       const Lane<R, 32> M;
       const int n8 = peer * 8 + L.wave;
       const int n16 = n8 + (M.lane >> 5) * kDec;
-      Acc<R> ax, ag;
-      ax.zero();
-      ag.zero();
-      mv<R, D::KPLX, 64>(wx, U0, L.lane, ax);
+      // (the [cell_output ; h1] rows of both mat-vecs were formed in the poll shadow of the previous step's round E: only the
+      //  pre-net rows [0, 128) and the alignment segment are left)
+      Acc<R> ax = g0x, ag = g0g;
+      if constexpr (D::kES & 1) mv_part<R, D::KPLX, 64, 0, 2>(wx, U0, L.lane, ax);
+      else mv<R, D::KPLX, 64>(wx, U0, L.lane, ax);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const XV<R> al = lds_rows<R>(ALS + (L.lane + 64 * j) * R);
@@ -738,7 +896,11 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
         for (int q = 0; q < R; ++q) ax.v[q] = fmaf(al.v[q], vwx[q][j], ax.v[q]);
       }
       __builtin_amdgcn_sched_barrier(0);
-      mv<R, D::KPLG0, 32>(wg0, U0, M.lk, ag);
+      {
+        typedef EShadowSplit<D::KPLG0, D::kES> ES_;
+        mv_part<R, D::KPLG0, 32, 0, ES_::lo>(wg0, U0, M.lk, ag);
+        mv_part<R, D::KPLG0, 32, ES_::hi, D::KPLG0>(wg0, U0, M.lk, ag);
+      }
       {
         const float* vwg = smem + D::o_vwg + M.tid * R;
 #pragma unroll
@@ -766,7 +928,7 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
           CATA[(kDec + n8) * R + M.rho] = gv;
           put_granule<R>(X, X3_G0, n8, M.rho, gv);
         } else {
-          ukeep = gg;
+          US[n8 * R + M.rho] = gg;
         }
       }
       tstamp(X);   // G0: computed + published
@@ -798,9 +960,9 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
         const Lane<R, 32> M;
         const int n8 = peer * 8 + M.wave;
         float* const CL = l == 1 ? CAT1 : CAT2;
-        Acc<R> ag;
-        ag.zero();
-        mv<R, 16, 32>(l == 1 ? wg1 : wg2, CL, M.lk, ag);
+        Acc<R> ag = ghp;   // recurrent half: formed in the shadow of round C_{l-1}'s gather
+        if constexpr (kShadow) mv_part<R, 16, 32, 0, 8>(l == 1 ? wg1 : wg2, CL, M.lk, ag);
+        else mv<R, 16, 32>(l == 1 ? wg1 : wg2, CL, M.lk, ag);
         col_sum_all<R, 32>(ag);
         float gg = 0.f, gv = 0.f;
         if (M.res) {
@@ -810,7 +972,7 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
             CIN[(kDec + n8) * R + M.rho] = gv;
             put_granule<R>(X, X3_G + (l - 1) * 512, n8, M.rho, gv);
           } else {
-            ukeep = gg;
+            US[n8 * R + M.rho] = gg;
           }
         }
         tstamp(X);
@@ -846,14 +1008,24 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
         float cc = 0.f, hn = 0.f, yy = 0.f;
         if (L.res) {
           cc = tanh_fast(pick<R>(ac, L.rho) + BIAS[D::b_c + l * 768 + n8]);
-          const float u = ukeep;
+          const float u = US[n8 * R + L.rho];
           hn = u * HL[n8 * R + L.rho] + (1.f - u) * cc;
           if (l == 2) yy = XS[n8 * R + L.rho] + hn;
           put_granule<R>(X, X3_C + l * 256, n8, L.rho, hn);
           hput(n8, L.rho, hn);
         }
         tstamp(X);
-        gather<R, (256 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(X, X3_C + l * 256, 256, [&](int n) { return (n >> 3) == peer; }, hput);
+        {
+          constexpr int MU = (256 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT;
+          auto S = gather_begin<R, MU>(X, OneRegion{X3_C + l * 256}, 256, [&](int n) { return (n >> 3) == peer; });
+          if (kShadow && l < 2) {   // h_{l+1}(t-1) . Wg_{l+1}[256:, :] -- rows [256, 512) of the next layer's [in | h] buffer
+            ghp.zero();
+            const int lk = opaque_tid() & 31;
+            if (l == 0) mv_part<R, 16, 32, 8, 16>(wg1, CAT1, lk, ghp);
+            else mv_part<R, 16, 32, 8, 16>(wg2, CAT2, lk, ghp);
+          }
+          gather_end<R, MU>(X, S, OneRegion{X3_C + l * 256}, hput);
+        }
         if (TR && sb64 >= 0) {
           float* st = stash + (unsigned)(sb64 * Td + t) * kStRec;
           st[kStC + l * kDec + n8] = cc;
@@ -938,8 +1110,8 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
       const Lane<R, 64> L;
       const int n4 = peer * 4 + (L.wave & 3);
       {
-        // the wave's four slots together: four independent partial sums per lane, ONE interleaved reduction (col_sum_all), and
-        // lane 48 + i publishes slot i -- instead of four dependent {score, wave sum, branch, publish} sequences
+        // the wave's four slots together: four independent partial sums per lane, ONE reduction of all four (col_sum_all), and
+        // the result lane of slot i publishes it -- instead of four dependent {score, wave sum, branch, publish} sequences
         Acc<4> e4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -950,8 +1122,8 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
                     v4.w * tanh_fast(k4.w + q4.w);
         }
         col_sum_all<4, 64>(e4);
-        const int i = L.lane - 48;
-        if (i >= 0 && i < 4) {
+        const int i = rs_rho<4, 64>(L.lane);   // result lane of slot i
+        if (i >= 0) {
           const int g = i * 256 + L.wave * 32 + peer;
           const int rho = g % R, sidx = g / R;
           if (sidx < rsel<R>(len, rho)) {
@@ -982,17 +1154,33 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
       tstamp(X);
       // one poll loop: pre-net layer 2 of step t+1 (columns [0, 128)) and the energies of every slot behind them (the owner's
       // own included: they are one L2 hit away).  Nobody scores -- or publishes -- positions past text_length.
-      gather2<R, ((kPre2 + TTP) * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(
-          X, X3_P2, kPre2, X3_E, kPre2 + TTP,
-          [&](int n) { return n < kPre2 && (!has_next || (n >> 2) == peer); },
-          [&](int n, int q, float v) {
-            if (n < kPre2) {
-              if (rsel<R>(from_out, q)) U0[n * R + q] = v;
-            } else {
-              ES[q * TTP + n - kPre2] = v;
-            }
-          },
-          [&](int n, int q) { return n < kPre2 || n - kPre2 < rsel<R>(len, q); });
+      {
+        constexpr int MU = ((kPre2 + TTP) * (R >= 2 ? R / 2 : 1) + NT - 1) / NT;
+        const TwoRegions regs{X3_P2, kPre2, X3_E};
+        auto S = gather_begin<R, MU>(X, regs, kPre2 + TTP, [&](int n) { return n < kPre2 && (!has_next || (n >> 2) == peer); });
+        if (D::kES != 0 && has_next) {   // rows [128, ...) of U0 = [cell_output ; h1] are final since rounds OUT / C0: the next step's G0 parts
+          const int tl = opaque_tid();
+          if constexpr (D::kES & 1) {
+            g0x.zero();
+            mv_part<R, D::KPLX, 64, 2, D::KPLX>(wx, U0, tl & 63, g0x);
+          }
+          if constexpr (D::kES & 6) {
+            typedef EShadowSplit<D::KPLG0, D::kES> ES_;
+            g0g.zero();
+            mv_part<R, D::KPLG0, 32, ES_::lo, ES_::hi>(wg0, U0, tl & 31, g0g);
+          }
+        }
+        gather_end<R, MU>(
+            X, S, regs,
+            [&](int n, int q, float v) {
+              if (n < kPre2) {
+                if (rsel<R>(from_out, q)) U0[n * R + q] = v;
+              } else {
+                ES[q * TTP + n - kPre2] = v;
+              }
+            },
+            [&](int n, int q) { return n < kPre2 || n - kPre2 < rsel<R>(len, q); });
+      }
       tstamp(X);   // E: gathered (before the deferred stores / next-step prefetch)
       if (TR && has_next) {
         if (sb64 >= 0 && L.wave < 4 && rsel<R>(from_out, L.rho))
@@ -1123,6 +1311,7 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
   const DecWeights& w = a.wT;
   Xc X;
   X.base = (gu64*)(reinterpret_cast<u64*>(a.xchg) + (int64_t)cl * R * kX3Row);
+  X.rs = __builtin_amdgcn_make_buffer_rsrc((void*)X.base, 0, R * kX3Row * 8, 0x00020000);
   {
     gi32* tab = (gi32*)(reinterpret_cast<int*>(a.xchg) + a.xcc_table_ofs);
     int* sflag = reinterpret_cast<int*>(smem);
@@ -1227,14 +1416,13 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
   const float km1c = a.keep1 ? 2.f : 1.f, km2c = a.keep2 ? 2.f : 1.f;
   const float* const stash = a.stash;
   // batch row this lane stores for as a result lane of a valid row (see the forward kernel), else -1
-  int sb64, sb32, sbq;
+  int sb64, sb32;
   {
-    const int r64 = lane - 48, r32 = (lane & 31) - 16;
-    sb64 = (r64 >= 0 && r64 < R && rsel<R>(valid, r64)) ? rsel<R>(brow, r64) : -1;
-    sb32 = (r32 >= 0 && r32 < R && rsel<R>(valid, r32)) ? rsel<R>(brow, r32) : -1;
-    sbq = (lane < R && rsel<R>(valid, lane)) ? rsel<R>(brow, lane) : -1;
+    const int r64 = rs_rho<R, 64>(lane), r32 = rs_rho<R, 32>(lane & 31);
+    sb64 = (r64 >= 0 && rsel<R>(valid, r64)) ? rsel<R>(brow, r64) : -1;
+    sb32 = (r32 >= 0 && rsel<R>(valid, r32)) ? rsel<R>(brow, r32) : -1;
 #ifdef TACO_P_NOSTASH
-    sb64 = sb32 = sbq = -1;   // timing probe: no gradient-stash stores at all (results are garbage)
+    sb64 = sb32 = -1;   // timing probe: no gradient-stash stores at all (results are garbage)
 #endif
   }
   float* const gst = a.gstash;
@@ -1340,6 +1528,8 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
   __builtin_amdgcn_s_waitcnt(0x0F70);   // prologue loads complete (see the forward kernel): no stray vmcnt(0) inside the loop
   if (loader) prefetch(Td - 1);
 
+  Acc<R> gdp;   // partial sum formed in a poll shadow (see the forward kernel)
+  gdp.zero();
   for (int t = Td - 1; t >= 0; --t) {
     X.epoch = (unsigned)(Td - t);
     if (kProbes3) {
@@ -1356,16 +1546,23 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
     // ---- 1. round FAN: d alignments[rho][s] = VWxc[s] . dx_{t+1}   (+ rider: d p2_{t+1} = mask (dx_{t+1} . Wi_p^T)) ----
     {
       const Lane<R, 64> L;
+      {
+        // the wave's four slots together (as round E of the forward kernel): four independent partial dots per lane, ONE
+        // reduce-scatter of all four, the result lane of slot i publishes it.  (Slots past text_length hold zero VWxc rows.)
+        Acc<4> d4;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int g = i * 256 + L.wave * 32 + peer;
-        const int rho = g % R, sidx = g / R;
-        if (sidx < rsel<R>(len, rho)) {
-          const float4 c4 = reinterpret_cast<const float4*>(DXR + rho * kDec)[L.lane];
+        for (int i = 0; i < 4; ++i) {
+          const int g = i * 256 + L.wave * 32 + peer;
+          const float4 c4 = reinterpret_cast<const float4*>(DXR + (g % R) * kDec)[L.lane];
           const float4 x4 = vres[i];
-          float dd = x4.x * c4.x + x4.y * c4.y + x4.z * c4.z + x4.w * c4.w;
-          dd = wave_sum(dd);
-          if (L.lane == 0) put_granule<R>(X, Y3_DAL, sidx, rho, dd);
+          d4.v[i] = x4.x * c4.x + x4.y * c4.y + x4.z * c4.z + x4.w * c4.w;
+        }
+        col_sum_all<4, 64>(d4);
+        const int i = rs_rho<4, 64>(L.lane);
+        if (i >= 0) {
+          const int g = i * 256 + L.wave * 32 + peer;
+          const int rho = g % R, sidx = g / R;
+          if (sidx < rsel<R>(len, rho)) put_granule<R>(X, Y3_DAL, sidx, rho, pick<4>(d4, i));
         }
       }
       if (has_next) {
@@ -1447,12 +1644,12 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
           else DKR[i * NT * R] = dk.v[0];
         }
       }
-#pragma unroll
-      for (int q = 0; q < R; ++q) dq.v[q] = wave_sum(dq.v[q]);
-      if (L.lane < R) {
-        const float v = pick<R>(dq, L.lane);
-        VO[(R80 + u) * R + L.lane] = v;
-        put_granule<R>(X, Y3_DQ, u, L.lane, v);
+      float dqv = 0.f;
+      col_sum_all<R, 64>(dq);   // (one reduce-scatter of the R row sums instead of R wave sums with a readlane broadcast each)
+      if (L.res) {
+        dqv = pick<R>(dq, L.rho);
+        VO[(R80 + u) * R + L.rho] = dqv;
+        put_granule<R>(X, Y3_DQ, u, L.rho, dqv);
       }
       float g1 = 0.f;
       if (has_next) {
@@ -1472,8 +1669,11 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
       gather<R, (512 * (R >= 2 ? R / 2 : 1) + NT / 2 - 1) / (NT / 2), NT / 2>(
           X, Y3_DQ, has_next ? 512 : 256, [&](int n) { return ((n & 255) >> 3) == peer; },
           [&](int n, int q, float v) { VO[(R80 + n) * R + q] = v; });
-      if (sbq >= 0) gst[(unsigned)(sbq * Td + t) * kGsRec + kGsQ + u] = pick<R>(dq, L.lane);
-      if (sb64 >= 0) gst[(unsigned)(sb64 * Td + t) * kGsRec + kGsP1S + u] = g1;
+      if (sb64 >= 0) {
+        float* gr = gst + (unsigned)(sb64 * Td + t) * kGsRec;
+        gr[kGsQ + u] = dqv;
+        gr[kGsP1S + u] = g1;
+      }
     }
     lds_barrier();
     tstamp(X);   // 4: DQ done
@@ -1542,8 +1742,18 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
             own(D::w_dhp, M.wave, M.rho) = own(D::w_dht, M.wave, M.rho) * uu + y * rr;   // partial new carry: dht u + d(rh) r
           }
         }
-        gather<R, (256 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(X, Y3_GR + l * 256, 256, [&](int n) { return (n >> 3) == peer; },
-                                                             [&](int n, int q, float v) { smem[o_dgp + n * R + q] = v; });
+        {
+          constexpr int MU = (256 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT;
+          auto S = gather_begin<R, MU>(X, OneRegion{Y3_GR + l * 256}, 256, [&](int n) { return (n >> 3) == peer; });
+          if (kShadow) {   // dup . Wg^T[256:, :]: rows [256, 512) of [d gates_r ; dup] are final since the previous round
+            gdp.zero();
+            const int lk = opaque_tid() & 31;
+            if (l == 0) mv_part<R, 16, 32, 8, 16>(wg0, smem + o_dgp, lk, gdp);
+            else if (l == 1) mv_part<R, 16, 32, 8, 16>(wg1, smem + o_dgp, lk, gdp);
+            else mv_part<R, 16, 32, 8, 16>(wg2, smem + o_dgp, lk, gdp);
+          }
+          gather_end<R, MU>(X, S, OneRegion{Y3_GR + l * 256}, [&](int n, int q, float v) { smem[o_dgp + n * R + q] = v; });
+        }
         if (sb32 >= 0 && M.lane >= 32) gst[(unsigned)(sb32 * Td + t) * kGsRec + kGsG + l * 512 + u] = gr;
       }
       lds_barrier();
@@ -1551,9 +1761,9 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
       {   // G_l: [d inp ; d h] += dgp . Wg^T
         const Lane<R, 32> M;
         const int u = peer * 8 + M.wave;
-        Acc<R> ag;
-        ag.zero();
-        mv<R, 16, 32>(l == 0 ? wg0 : (l == 1 ? wg1 : wg2), smem + o_dgp, M.lk, ag);
+        Acc<R> ag = gdp;   // dup half: formed in the shadow of round C_l's gather
+        if constexpr (kShadow) mv_part<R, 16, 32, 0, 8>(l == 0 ? wg0 : (l == 1 ? wg1 : wg2), smem + o_dgp, M.lk, ag);
+        else mv<R, 16, 32>(l == 0 ? wg0 : (l == 1 ? wg1 : wg2), smem + o_dgp, M.lk, ag);
         col_sum_all<R, 32>(ag);
         float dxv = 0.f;
         if (M.res) {

@@ -1,6 +1,6 @@
 # Round profile on the GPU box: bench line, rocprofv3 kernel stats + one-step timeline, PMC passes (FETCH / WRITE / MFMA), probes.
 # usage: bash tools/profile_round.sh r02   -> files under gpurun_out/<tag>_*
-TAG=${1:-r03}; export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out
+TAG=${1:-r04}; export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out
 H=$(python -c "import bench; print(bench.source_hash())")
 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 cd /tmp
@@ -14,6 +14,12 @@ python tools/rocpd_summary.py $(find /tmp/p1 -name "*.db" | head -1) > $O/${TAG}
 python tools/rocpd_timeline.py $(find /tmp/p1 -name "*.db" | head -1) 12 > $O/${TAG}_step_timeline.txt 2>&1
 python tools/pmc_to_json.py $(find /tmp/p2 -name "*.db" | head -1) $(find /tmp/p3 -name "*.db" | head -1) $O/${TAG}_pmc.json $H "round $TAG" > /dev/null 2> $O/${TAG}_pmc.err
 python tools/pmc_mfma.py $(find /tmp/p4 -name "*.db" | head -1) $H > $O/${TAG}_pmc_mfma.txt 2>&1
+python tools/pmc_step.py $(find /tmp/p2 -name "*.db" | head -1) $(find /tmp/p3 -name "*.db" | head -1) 3 $O/${TAG}_pmc_step.json $H > $O/${TAG}_pmc_step.txt 2>&1
+python - <<PY
+import json
+a = json.load(open('$O/${TAG}_pmc.json')); a['step'] = json.load(open('$O/${TAG}_pmc_step.json'))
+json.dump(a, open('$O/${TAG}_pmc.json', 'w'), indent=1)
+PY
 python tools/dec3_trace.py 32 > $O/${TAG}_dec_probes.txt 2>&1
 python tools/dec3_trace.py 1 infer >> $O/${TAG}_dec_probes.txt 2>&1
 (export TACO_LIB=$R/tacotron_amd/libtaco_probe.so; python tools/dec_quick.py --time-only; TACO_DEC_FAKEX=1 python tools/dec_quick.py --time-only; TACO_DEC_V3_AGENT=1 python tools/dec_quick.py --time-only) >> $O/${TAG}_dec_probes.txt 2>&1
