@@ -24,4 +24,7 @@ python tools/dec3_trace.py 32 > $O/${TAG}_dec_probes.txt 2>&1
 python tools/dec3_trace.py 1 infer >> $O/${TAG}_dec_probes.txt 2>&1
 (export TACO_LIB=$R/tacotron_amd/libtaco_probe.so; python tools/dec_quick.py --time-only; TACO_DEC_FAKEX=1 python tools/dec_quick.py --time-only; TACO_DEC_V3_AGENT=1 python tools/dec_quick.py --time-only) >> $O/${TAG}_dec_probes.txt 2>&1
 python tools/family_trace.py > $O/${TAG}_family_trace.txt 2>&1
+TACO_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --no-cpu-baseline --no-inference --no-extras > $O/${TAG}_bench_forced_dist.json 2> $O/${TAG}_bench_forced_dist.err
+python tools/dp_coresidency.py > $O/${TAG}_dp_coresidency.txt 2>&1
+python tools/soak.py > $O/${TAG}_soak.txt 2>&1
 tail -c 300 $O/${TAG}_bench.json; head -12 $O/${TAG}_pmc_mfma.txt
