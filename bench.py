@@ -366,6 +366,9 @@ def main():
                            'us_per_decoder_step_fwd': fa * 1e3 / Td, 'us_per_decoder_step_bwd': ba * 1e3 / Td,
                            'non_decoder_critical_path_ms': sec_per_step * 1e3 - fa - ba},
             'final_loss': loss, 'build': source_hash(),
+            # which box this was: the latency-bound kernels (decoder, bi-GRU: 58 % of the step) scale with the shader clock the chip
+            # sustains, and boxes of one pool differ by ~10 % (round 4: the same build ran 8.86 and 9.30 ms per step)
+            'box': {'shader_clock_ghz_latency_bound': lib.clock_probe()},
         }
         if allreduce:
             res['allreduce'] = allreduce

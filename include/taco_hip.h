@@ -23,7 +23,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default)
 
-#define TACO_VERSION 113
+#define TACO_VERSION 114
 
 #define TACO_OK 0
 #define TACO_EINVAL (-1)   /* bad argument / unsupported shape   */
@@ -179,6 +179,11 @@ int taco_wait_grad_segment(int seg, void* stream);
 /* Communication-kernel stand-in for the co-residency tests (tests/test_gpu_dist.py): `blocks` workgroups x `threads` threads, `lds_bytes` of LDS each, spinning
  * for `usec` microseconds.  Does no work. */
 int taco_debug_spin(int blocks, int threads, int lds_bytes, int usec, void* stream);
+
+/* Shader-clock probe: one wave runs `iters` dependent FMAs; out3[0] = elapsed shader cycles, out3[1] = elapsed ticks of the
+ * constant 100 MHz counter (device int64[3]).  cycles / (ticks * 10 ns) = the clock the chip sustains under a latency-bound load,
+ * which is what the persistent decoder / bi-GRU kernels scale with (boxes of one pool were measured ~10 % apart). */
+int taco_debug_clock_probe(long long* out3, int iters, void* stream);
 
 /* ---- spectrogram boundary ---------------------------------------------------------------------------- */
 /* test.py:64 `out * stft_std + stft_mean` followed by audio.reshape_frames(forward=False) (audio.py:29-35), on the device.

@@ -128,6 +128,16 @@ constexpr bool kShadow = false;
 #define TACO_ESHADOW 5
 #endif
 constexpr int kEShadow = kShadow ? TACO_ESHADOW : 0;
+#if !defined(TACO_NO_BWD_SHADOW)
+constexpr bool kBwdShadow = kShadow;   // the BPTT kernel's shadow (dup half of G_l in round C_l's gather); -DTACO_NO_BWD_SHADOW: A/B
+#else
+constexpr bool kBwdShadow = false;
+#endif
+#if !defined(TACO_NO_GROUPED_FANDQ)
+constexpr bool kGroupedFanDq = true;   // FAN / DQ rounds of the BPTT kernel: one reduce-scatter for all slots / rows; -DTACO_NO_GROUPED_FANDQ: round 3's wave sums
+#else
+constexpr bool kGroupedFanDq = false;
+#endif
 template <int KPLG0, int MODE>
 struct EShadowSplit {
   static constexpr int lo = 4;                                                   // first weight register behind the pre-net rows
@@ -1546,6 +1556,20 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
     // ---- 1. round FAN: d alignments[rho][s] = VWxc[s] . dx_{t+1}   (+ rider: d p2_{t+1} = mask (dx_{t+1} . Wi_p^T)) ----
     {
       const Lane<R, 64> L;
+      if constexpr (!kGroupedFanDq) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int g = i * 256 + L.wave * 32 + peer;
+          const int rho = g % R, sidx = g / R;
+          if (sidx < rsel<R>(len, rho)) {
+            const float4 c4 = reinterpret_cast<const float4*>(DXR + rho * kDec)[L.lane];
+            const float4 x4 = vres[i];
+            float dd = x4.x * c4.x + x4.y * c4.y + x4.z * c4.z + x4.w * c4.w;
+            dd = wave_sum(dd);
+            if (L.lane == 0) put_granule<R>(X, Y3_DAL, sidx, rho, dd);
+          }
+        }
+      } else
       {
         // the wave's four slots together (as round E of the forward kernel): four independent partial dots per lane, ONE
         // reduce-scatter of all four, the result lane of slot i publishes it.  (Slots past text_length hold zero VWxc rows.)
@@ -1645,7 +1669,12 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
         }
       }
       float dqv = 0.f;
-      col_sum_all<R, 64>(dq);   // (one reduce-scatter of the R row sums instead of R wave sums with a readlane broadcast each)
+      if constexpr (kGroupedFanDq) {
+        col_sum_all<R, 64>(dq);   // (one reduce-scatter of the R row sums instead of R wave sums with a readlane broadcast each)
+      } else {
+#pragma unroll
+        for (int q = 0; q < R; ++q) dq.v[q] = wave_sum(dq.v[q]);
+      }
       if (L.res) {
         dqv = pick<R>(dq, L.rho);
         VO[(R80 + u) * R + L.rho] = dqv;
@@ -1745,7 +1774,7 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
         {
           constexpr int MU = (256 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT;
           auto S = gather_begin<R, MU>(X, OneRegion{Y3_GR + l * 256}, 256, [&](int n) { return (n >> 3) == peer; });
-          if (kShadow) {   // dup . Wg^T[256:, :]: rows [256, 512) of [d gates_r ; dup] are final since the previous round
+          if (kBwdShadow) {   // dup . Wg^T[256:, :]: rows [256, 512) of [d gates_r ; dup] are final since the previous round
             gdp.zero();
             const int lk = opaque_tid() & 31;
             if (l == 0) mv_part<R, 16, 32, 8, 16>(wg0, smem + o_dgp, lk, gdp);
@@ -1762,7 +1791,7 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
         const Lane<R, 32> M;
         const int u = peer * 8 + M.wave;
         Acc<R> ag = gdp;   // dup half: formed in the shadow of round C_l's gather
-        if constexpr (kShadow) mv_part<R, 16, 32, 0, 8>(l == 0 ? wg0 : (l == 1 ? wg1 : wg2), smem + o_dgp, M.lk, ag);
+        if constexpr (kBwdShadow) mv_part<R, 16, 32, 0, 8>(l == 0 ? wg0 : (l == 1 ? wg1 : wg2), smem + o_dgp, M.lk, ag);
         else mv<R, 16, 32>(l == 0 ? wg0 : (l == 1 ? wg1 : wg2), smem + o_dgp, M.lk, ag);
         col_sum_all<R, 32>(ag);
         float dxv = 0.f;

@@ -766,6 +766,30 @@ int launch_spin(int blocks, int threads, int lds_bytes, int usec, hipStream_t s)
   return TACO_OK;
 }
 
+// ---- shader-clock probe (taco_debug_clock_probe): one wave runs a chain of `iters` dependent v_fma_f32 and reports the elapsed
+//      shader cycles (s_memtime) and constant-rate ticks (s_memrealtime, 100 MHz).  cycles / time = the clock this chip sustains
+//      under a LATENCY-BOUND load -- what the persistent decoder and bi-GRU kernels scale with; boxes of one pool differ by ~10 %.
+__global__ void clock_probe_kernel(long long* out, int iters, float a, float b) {
+  float x = (float)threadIdx.x;
+  const long long c0 = clock64(), w0 = wall_clock64();
+  for (int i = 0; i < iters; i += 16) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) x = fmaf(x, a, b);
+  }
+  const long long c1 = clock64(), w1 = wall_clock64();
+  if (threadIdx.x == 0) {
+    out[0] = c1 - c0;
+    out[1] = w1 - w0;
+  }
+  if (x == 12345.678f) out[2] = 1;   // keeps the chain alive
+}
+int launch_clock_probe(long long* out, int iters, hipStream_t s) {
+  TACO_REQUIRE(out && iters > 0, "clock_probe: bad arguments");
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, s, out, iters, 0.999f, 0.001f);
+  TACO_LAUNCH_CHECK("clock_probe");
+  return TACO_OK;
+}
+
 // ---- batched zero-fill / copy (InitBatch, kernels.h) ----
 __global__ __launch_bounds__(256) void init_batch_kernel(InitBatch b) {
   int ji = 0;

@@ -1363,6 +1363,10 @@ extern "C" int taco_debug_spin(int blocks, int threads, int lds_bytes, int usec,
   return launch_spin(blocks, threads, lds_bytes, usec, as_stream(stream));
 }
 
+extern "C" int taco_debug_clock_probe(long long* out3, int iters, void* stream) {
+  return launch_clock_probe(out3, iters, as_stream(stream));
+}
+
 extern "C" int taco_profile_enable(int mask) {
   g_prof_mask = mask & 31;
   return TACO_OK;

@@ -72,6 +72,7 @@ EXPORTS = {
     'taco_wait_grad_segment': (C.c_int, [_I, _P]),
     'taco_decoder_mode': (C.c_int, [_I]),
     'taco_debug_spin': (C.c_int, [_I, _I, _I, _I, _P]),
+    'taco_debug_clock_probe': (C.c_int, [_P, _I, _P]),
     'taco_denorm_unframe': (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'taco_griffinlim_workspace_bytes': (C.c_int64, [_I, _I]),
     'taco_griffinlim': (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
@@ -237,6 +238,16 @@ def decoder_mode(mode=-1) -> int:
     """Process-wide decoder mode (include/taco_hip.h): 0 decoder3 fast exchange, 1 decoder3 agent-scope exchange, 2 decoder.hip.
     Sets it when mode >= 0; returns the PREVIOUS mode."""
     return _lib.taco_decoder_mode(int(mode))
+
+
+def clock_probe(iters=1 << 20):
+    """GHz the chip sustains under a latency-bound load (one wave of dependent FMAs); host synchronisation."""
+    out = torch.zeros(3, dtype=torch.int64, device='cuda')
+    for _ in range(2):   # (first call: clocks ramping up)
+        _check(_lib.taco_debug_clock_probe(ptr(out), int(iters), stream_ptr()), 'taco_debug_clock_probe')
+    torch.cuda.synchronize()
+    cyc, ticks = out[0].item(), out[1].item()
+    return cyc / (ticks * 10.0) if ticks > 0 else 0.0
 
 
 def debug_spin(blocks, threads, lds_bytes, usec, stream=None):

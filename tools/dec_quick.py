@@ -23,6 +23,7 @@ if '--time-only' not in sys.argv:
 from tacotron_amd.config import Config
 from tacotron_amd.data import synthetic_batch
 from tacotron_amd.model import Tacotron
+print('box: %.2f GHz under a latency-bound load' % lib.clock_probe())
 c = Config(); c.r, c.vocab_size = 2, 60
 m = Tacotron(c, synthetic_batch(32, 200, 180, 2, 60), train=True, seed=0)
 for _ in range(3): m.step()

@@ -41,7 +41,13 @@ def main():
         d['fetch_bytes'] += f
         d['write_bytes'] += w
         d['launches_per_step'] += n
-        kern[name.split('(')[0][-60:]] = {'fetch_bytes': f, 'write_bytes': w, 'launches_per_step': n}
+        short = name.replace('(anonymous namespace)::', '').replace('void ', '')
+        cut = short.find('(')
+        short = (short[:cut] if cut > 0 else short)[:70]
+        e = kern.setdefault(short, {'fetch_bytes': 0.0, 'write_bytes': 0.0, 'launches_per_step': 0.0})
+        e['fetch_bytes'] += f
+        e['write_bytes'] += w
+        e['launches_per_step'] += n
     for d in fam.values():
         d['bytes'] = d['fetch_bytes'] + d['write_bytes']
     total = sum(d['bytes'] for d in fam.values())
