@@ -180,9 +180,10 @@ int taco_wait_grad_segment(int seg, void* stream);
  * for `usec` microseconds.  Does no work. */
 int taco_debug_spin(int blocks, int threads, int lds_bytes, int usec, void* stream);
 
-/* Shader-clock probe: one wave runs `iters` dependent FMAs; out3[0] = elapsed shader cycles, out3[1] = elapsed ticks of the
- * constant 100 MHz counter (device int64[3]).  cycles / (ticks * 10 ns) = the clock the chip sustains under a latency-bound load,
- * which is what the persistent decoder / bi-GRU kernels scale with (boxes of one pool were measured ~10 % apart). */
+/* Shader-clock probe: one 512-thread workgroup per CU, every wave a chain of `iters` dependent FMAs; out3[0] = elapsed shader
+ * cycles, out3[1] = elapsed ticks of the constant 100 MHz counter of workgroup 0 (device int64[3]).  cycles / (ticks * 10 ns) =
+ * the clock the chip sustains under a chip-wide latency-bound load, which is what the persistent decoder / bi-GRU kernels scale
+ * with (boxes of one pool were measured ~10 % apart on those kernels). */
 int taco_debug_clock_probe(long long* out3, int iters, void* stream);
 
 /* ---- spectrogram boundary ---------------------------------------------------------------------------- */

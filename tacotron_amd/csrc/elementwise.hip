@@ -766,10 +766,12 @@ int launch_spin(int blocks, int threads, int lds_bytes, int usec, hipStream_t s)
   return TACO_OK;
 }
 
-// ---- shader-clock probe (taco_debug_clock_probe): one wave runs a chain of `iters` dependent v_fma_f32 and reports the elapsed
-//      shader cycles (s_memtime) and constant-rate ticks (s_memrealtime, 100 MHz).  cycles / time = the clock this chip sustains
-//      under a LATENCY-BOUND load -- what the persistent decoder and bi-GRU kernels scale with; boxes of one pool differ by ~10 %.
-__global__ void clock_probe_kernel(long long* out, int iters, float a, float b) {
+// ---- shader-clock probe (taco_debug_clock_probe): every CU runs one 512-thread workgroup whose waves each walk a chain of
+//      `iters` dependent v_fma_f32 -- the occupancy and issue pattern of the persistent decoder kernels, without their memory
+//      traffic -- and workgroup 0 reports the elapsed shader cycles (s_memtime) and constant-rate ticks (s_memrealtime, 100 MHz).
+//      cycles / time = the clock this chip sustains under a chip-wide LATENCY-BOUND load, which is what the decoder and bi-GRU
+//      kernels scale with; boxes of one pool differ (round 4: the same build ran 8.86 and 9.30 ms per step).
+__global__ __launch_bounds__(512) void clock_probe_kernel(long long* out, int iters, float a, float b) {
   float x = (float)threadIdx.x;
   const long long c0 = clock64(), w0 = wall_clock64();
   for (int i = 0; i < iters; i += 16) {
@@ -777,7 +779,7 @@ __global__ void clock_probe_kernel(long long* out, int iters, float a, float b) 
     for (int j = 0; j < 16; ++j) x = fmaf(x, a, b);
   }
   const long long c1 = clock64(), w1 = wall_clock64();
-  if (threadIdx.x == 0) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     out[0] = c1 - c0;
     out[1] = w1 - w0;
   }
@@ -785,7 +787,9 @@ __global__ void clock_probe_kernel(long long* out, int iters, float a, float b) 
 }
 int launch_clock_probe(long long* out, int iters, hipStream_t s) {
   TACO_REQUIRE(out && iters > 0, "clock_probe: bad arguments");
-  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, s, out, iters, 0.999f, 0.001f);
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(cus > 0 ? cus : 256), dim3(512), 0, s, out, iters, 0.999f, 0.001f);
   TACO_LAUNCH_CHECK("clock_probe");
   return TACO_OK;
 }

@@ -241,7 +241,7 @@ def decoder_mode(mode=-1) -> int:
 
 
 def clock_probe(iters=1 << 20):
-    """GHz the chip sustains under a latency-bound load (one wave of dependent FMAs); host synchronisation."""
+    """GHz the chip sustains under a chip-wide latency-bound load (every CU: 8 waves of dependent FMAs); host synchronisation."""
     out = torch.zeros(3, dtype=torch.int64, device='cuda')
     for _ in range(2):   # (first call: clocks ramping up)
         _check(_lib.taco_debug_clock_probe(ptr(out), int(iters), stream_ptr()), 'taco_debug_clock_probe')
