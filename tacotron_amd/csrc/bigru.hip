@@ -24,6 +24,11 @@ __device__ __forceinline__ void dma64(const float* gsrc_lane, float* lds_wave_ba
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
 }
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Vector-memory operations of a wave retire in issue order (gfx9 has one counter for loads and stores), so "at most N
+// outstanding" = "everything older than the N youngest has landed".  The chunk waits below name the number of STORES the wave
+// has issued since the chunk's DMA loads: the loads are then complete while the stores' write acknowledgements (~1 us behind)
+// stay in flight -- waiting vmcnt(0) there cost ~150 cycles per step.
+template <int N> __device__ __forceinline__ void wait_vm_older_than() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // sum over the 4 lanes of a quad (every lane gets the total): two DPP quad_perm swaps, no LDS
 __device__ __forceinline__ float quad_sum(float v) {
@@ -37,13 +42,33 @@ constexpr int NTG = 512;
 // bases are 128 B (32-float vectors) or 256 B (64-float) apart and fall on the same banks (PMC: LDS_BANK_CONFLICT on 12 % /
 // 25 % of the forward / backward wave cycles).  Each quarter therefore gets 4 floats of padding: base = q * (len + 4).
 __device__ __forceinline__ int pad32(int c) { return c + 4 * (c >> 5); }   // 32-float quarters (128-wide vectors)
-__device__ __forceinline__ int pad64(int c) { return c + 4 * (c >> 6); }   // 64-float quarters (256-wide vectors)
 constexpr int HP = H + 16;         // padded 128-vector
-constexpr int H2P = 2 * H + 16;    // padded 256-vector
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }   // v_pk_fma_f32
 __device__ __forceinline__ float hsum(f2 v) { return v.x + v.y; }      // 8 waves = 2 per SIMD: a lone wave per SIMD only issues ~1 instruction per 4 cycles
 constexpr int CH = 8;         // time steps per DMA chunk
+
+// Issue-time stamps of wave 0 for tools/micro/gru_trace.hip (compiled out of the library)
+#ifdef TACO_GRU_TRACE
+#define GRU_STAMP_DECL long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stp_ = 0
+#define GRU_STAMP(i)                                                  \
+  do {                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                \
+    const long long n_ = clock64();                                   \
+    st_[i] += n_ - stp_;                                              \
+    stp_ = n_;                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                \
+  } while (0)
+#define GRU_STAMP_FLUSH(tr)                                                           \
+  do {                                                                                \
+    if ((tr) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)               \
+      for (int i_ = 0; i_ < 8; ++i_) (tr)[i_] = st_[i_];                              \
+  } while (0)
+#else
+#define GRU_STAMP_DECL
+#define GRU_STAMP(i)
+#define GRU_STAMP_FLUSH(tr)
+#endif
 
 // Forward.  grid = (B, 2 directions); block = 512.
 //  gates    : thread (cp = t>>2, kq = t&3) owns gate columns {cp, cp+128} (= r_cp and u_cp) over k in [32kq, 32kq+32):
@@ -51,12 +76,14 @@ constexpr int CH = 8;         // time steps per DMA chunk
 //  candidate: thread (cc = t>>2, kq) owns candidate column cc over the same k-quarter (32 weights); lane kq==0 of each
 //             quad finishes c, h' and issues the stores.  Two workgroup barriers per step.
 //  inputs   : the hoisted x-projections arrive by LDS-DMA in chunks of CH steps, issued by wave 7 one chunk ahead.
-__global__ __launch_bounds__(NTG, 2) void bigru_fwd_kernel(const float* __restrict__ xg, BiGruWeights w,
+__global__ __launch_bounds__(NTG, 1) void bigru_fwd_kernel(const float* __restrict__ xg, BiGruWeights w,
                                                            const float* __restrict__ h0, float* __restrict__ out,
                                                            float* __restrict__ ruc, int B, int T, long long* trace) {
   (void)trace;
+  GRU_STAMP_DECL;
   const int b = blockIdx.x, d = blockIdx.y, t_ = threadIdx.x;
-  const int cp = t_ >> 2, kq = t_ & 3, lane = t_ & 63, wv = t_ >> 6;
+  const int cp = t_ >> 2, kq = t_ & 3, lane = t_ & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t_ >> 6);   // wave-uniform: the DMA addresses below stay on the scalar unit
   __shared__ __attribute__((aligned(16))) float hs[HP];
   __shared__ __attribute__((aligned(16))) float rhs[HP];
   __shared__ __attribute__((aligned(16))) float xgs[2][CH][3 * H];
@@ -73,6 +100,7 @@ __global__ __launch_bounds__(NTG, 2) void bigru_fwd_kernel(const float* __restri
       wcand[k] = f2{wc[(int64_t)(2 * k) * H], wc[(int64_t)(2 * k + 1) * H]};
     }
   }
+  const float act_g = kq == 1 ? -1.4426950408889634f : 2.f * 1.4426950408889634f, act_a = kq == 1 ? 0.f : 1.f, act_b = kq == 1 ? 1.f : -2.f;
   if (t_ < H) hs[pad32(t_)] = h0 ? h0[(int64_t)b * H + t_] : 0.f;   // initial_state_fw = initial_state_bw = s (ops.py:123-124)
 
   const int64_t row0 = (int64_t)b * T;
@@ -90,40 +118,61 @@ __global__ __launch_bounds__(NTG, 2) void bigru_fwd_kernel(const float* __restri
   dma_chunk(0);
   wait_vm0();
   lds_barrier();
+  GRU_STAMP(7);   // (prologue)
 
   for (int s = 0, t = tstart; s < T; ++s, t += tstep) {
     const int c = s / CH, i = s - c * CH;
     if (i == 0 && (c + 1) * CH < T) dma_chunk(c + 1);
     const float* xrow = &xgs[c & 1][i][0];
-    // ---- gates ----
-    f2 a0 = {0.f, 0.f}, a1 = a0, b0 = a0, b1 = a0;
+    GRU_STAMP(0);   // [0] barrier 2 of the previous step .. loop top
+    // ---- reset gate (the only product the candidate waits for) ----
+    float4 hv[H / 16];
+#pragma unroll
+    for (int k4 = 0; k4 < H / 16; ++k4) hv[k4] = reinterpret_cast<const float4*>(hs + kq * (H / 4 + 4))[k4];
+    f2 a0 = {0.f, 0.f}, a1 = a0;
 #pragma unroll
     for (int k4 = 0; k4 < H / 16; ++k4) {
-      const float4 hv = reinterpret_cast<const float4*>(hs + kq * (H / 4 + 4))[k4];
-      const f2 h01 = {hv.x, hv.y}, h23 = {hv.z, hv.w};
-      a0 = pk_fma(h01, wr[2 * k4], a0); b0 = pk_fma(h01, wu[2 * k4], b0);
-      a1 = pk_fma(h23, wr[2 * k4 + 1], a1); b1 = pk_fma(h23, wu[2 * k4 + 1], b1);
+      a0 = pk_fma(f2{hv[k4].x, hv[k4].y}, wr[2 * k4], a0);
+      a1 = pk_fma(f2{hv[k4].z, hv[k4].w}, wr[2 * k4 + 1], a1);
     }
+    GRU_STAMP(1);   // [1] h reads + reset-gate products issued
     const float rg = sigmoid_fast(quad_sum(hsum(a0 + a1)) + xrow[cp]);
-    const float ug = sigmoid_fast(quad_sum(hsum(b0 + b1)) + xrow[H + cp]);
     const float hprev = hs[pad32(cp)];
     if (kq == 0) {
       rhs[pad32(cp)] = rg * hprev;
     }
+    GRU_STAMP(2);   // [2] quad sum, sigmoid, r*h written
     lds_barrier();
-    // ---- candidate ----
+    GRU_STAMP(3);   // [3] barrier 1
+    // ---- candidate; the update gate's products (h is still in registers) fill the wait for r*h ----
+    float4 rv[H / 16];
+#pragma unroll
+    for (int k4 = 0; k4 < H / 16; ++k4) rv[k4] = reinterpret_cast<const float4*>(rhs + kq * (H / 4 + 4))[k4];
+    f2 b0 = {0.f, 0.f}, b1 = b0;
+#pragma unroll
+    for (int k4 = 0; k4 < H / 16; ++k4) {
+      b0 = pk_fma(f2{hv[k4].x, hv[k4].y}, wu[2 * k4], b0);
+      b1 = pk_fma(f2{hv[k4].z, hv[k4].w}, wu[2 * k4 + 1], b1);
+    }
+    const float upre = quad_sum(hsum(b0 + b1)) + xrow[H + cp];
     f2 p0 = {0.f, 0.f}, p1 = p0;
 #pragma unroll
     for (int k4 = 0; k4 < H / 16; ++k4) {
-      const float4 rv = reinterpret_cast<const float4*>(rhs + kq * (H / 4 + 4))[k4];
-      p0 = pk_fma(f2{rv.x, rv.y}, wcand[2 * k4], p0);
-      p1 = pk_fma(f2{rv.z, rv.w}, wcand[2 * k4 + 1], p1);
+      p0 = pk_fma(f2{rv[k4].x, rv[k4].y}, wcand[2 * k4], p0);
+      p1 = pk_fma(f2{rv[k4].z, rv[k4].w}, wcand[2 * k4 + 1], p1);
     }
+    GRU_STAMP(4);   // [4] r*h reads, update-gate and candidate products issued
     const float cpre = quad_sum(hsum(p0 + p1)) + xrow[2 * H + cp];
-    // every wave's share of the next chunk has had CH-1 steps to land; wait before this step's (younger) stores are issued
-    if (i == CH - 1) wait_vm0();
+    // every wave's share of the next chunk has had CH-1 steps to land; younger than its loads are the stores of CH-1 steps
+    if (i == CH - 1) {
+      if (ruc) wait_vm_older_than<4 * (CH - 1)>(); else wait_vm_older_than<CH - 1>();
+    }
+    // sigmoid(u) and tanh(c) share one exp/rcp sequence: lane 1 of the quad takes u, the others c
+    //   sigmoid(x) = 0 + 1 * rcp(1 + exp2(-log2e * x));   tanh(x) = 1 - 2 * rcp(1 + exp2(2 log2e * x))     (sigmoid_fast / tanh_fast)
+    const float act = fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(act_g * (kq == 1 ? upre : cpre))), act_b, act_a);
+    const float ug = dpp_move<0xb1>(0.f, act);   // lane 0 <- lane 1
     if (kq == 0) {
-      const float cc = tanh_fast(cpre);
+      const float cc = act;
       const float hn = ug * hprev + (1.f - ug) * cc;
       hs[pad32(cp)] = hn;
       out[(row0 + t) * (2 * H) + d * H + cp] = hn;
@@ -134,8 +183,11 @@ __global__ __launch_bounds__(NTG, 2) void bigru_fwd_kernel(const float* __restri
         rp[2 * H + cp] = cc;
       }
     }
+    GRU_STAMP(5);   // [5] quad sum, tanh, h' written, stores issued
     lds_barrier();
+    GRU_STAMP(6);   // [6] barrier 2
   }
+  GRU_STAMP_FLUSH(trace);
 }
 
 // Backward recurrence.  grid = (B, 2); block = 512.
@@ -144,29 +196,35 @@ __global__ __launch_bounds__(NTG, 2) void bigru_fwd_kernel(const float* __restri
 //   dr = d(rh)*h_prev; dgp = [dr*r(1-r), du*u(1-u)]; dh = dht*u + d(rh)*r + dgp . Wg_h^T
 // Thread (cp = t>>2, kq = t&3) owns hidden unit cp; every reduction is split over the quad's four lanes (k-quarters) and
 // combined with quad_sum.  Inputs {r,u,c,dout,h_prev} arrive by LDS-DMA in chunks of CH steps (wave 7).
-__global__ __launch_bounds__(NTG, 2) void bigru_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+__global__ __launch_bounds__(NTG, 1) void bigru_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                            const float* __restrict__ ruc, BiGruBwdWeights w,
                                                            const float* __restrict__ h0, float* __restrict__ dxg,
                                                            float* __restrict__ rh_out, float* __restrict__ dh0, int B,
                                                            int T) {
   const int b = blockIdx.x, d = blockIdx.y, t_ = threadIdx.x;
-  const int cp = t_ >> 2, kq = t_ & 3, lane = t_ & 63, wv = t_ >> 6;
+  const int cp = t_ >> 2, kq = t_ & 3, lane = t_ & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t_ >> 6);   // wave-uniform: the DMA addresses below stay on the scalar unit
   // double buffered by step parity: the next step's writes never race with this step's reads, so a step needs only the two
   // barriers its own dependences require
   __shared__ __attribute__((aligned(16))) float dcp_s2[2][HP];
-  __shared__ __attribute__((aligned(16))) float dgp_s2[2][H2P];
+  __shared__ __attribute__((aligned(16))) float dgr_s2[2][HP];   // dgp, reset half   (published after d(rh))
+  __shared__ __attribute__((aligned(16))) float dgu_s2[2][HP];   // dgp, update half  (known before d(rh))
   __shared__ __attribute__((aligned(16))) float in_s[2][CH][5 * H];   // [r | u | c | dout | h_prev]
 
   // wchT (128 [c], 128 [k]): d(rh)[cp] = sum_c dcp[c] * wchT[c][cp]      -> this lane: c in [32kq, 32kq+32)
-  // wghT (256 [j], 128 [k]): dh[cp]   += sum_j dgp[j] * wghT[j][cp]      -> this lane: j in [64kq, 64kq+64)
-  f2 wc_r[H / 8], wg_r[H / 4];   // row pairs, for v_pk_fma_f32
+  // wghT (256 [j], 128 [k]): dh[cp]   += sum_j dgp[j] * wghT[j][cp]      -> this lane: j in [32kq, 32kq+32) (reset half)
+  //                                                                        and [128+32kq, 128+32kq+32) (update half)
+  f2 wc_r[H / 8], wgr_r[H / 8], wgu_r[H / 8];   // row pairs, for v_pk_fma_f32
   {
     const float* p = w.wchT[d] + (int64_t)(kq * (H / 4)) * H + cp;
 #pragma unroll
     for (int i = 0; i < H / 8; ++i) wc_r[i] = f2{p[(int64_t)(2 * i) * H], p[(int64_t)(2 * i + 1) * H]};
-    const float* q = w.wghT[d] + (int64_t)(kq * (H / 2)) * H + cp;
+    const float* q = w.wghT[d] + (int64_t)(kq * (H / 4)) * H + cp;
 #pragma unroll
-    for (int i = 0; i < H / 4; ++i) wg_r[i] = f2{q[(int64_t)(2 * i) * H], q[(int64_t)(2 * i + 1) * H]};
+    for (int i = 0; i < H / 8; ++i) {
+      wgr_r[i] = f2{q[(int64_t)(2 * i) * H], q[(int64_t)(2 * i + 1) * H]};
+      wgu_r[i] = f2{q[(int64_t)(H + 2 * i) * H], q[(int64_t)(H + 2 * i + 1) * H]};
+    }
   }
 
   const int64_t row0 = (int64_t)b * T;
@@ -206,7 +264,8 @@ __global__ __launch_bounds__(NTG, 2) void bigru_bwd_kernel(const float* __restri
     const int c = s / CH, i = s - c * CH;
     if (i == 0 && (c + 1) * CH < T) dma_chunk(c + 1);
     float* dcp_s = dcp_s2[s & 1];
-    float* dgp_s = dgp_s2[s & 1];
+    float* dgr_s = dgr_s2[s & 1];
+    float* dgu_s = dgu_s2[s & 1];
     const float* in = &in_s[c & 1][i][0];
     const float r = in[cp], u = in[H + cp], cc = in[2 * H + cp], hp = in[4 * H + cp];
     const float dht = dh + in[3 * H + cp];
@@ -216,38 +275,49 @@ __global__ __launch_bounds__(NTG, 2) void bigru_bwd_kernel(const float* __restri
     const float dup = du * u * (1.f - u);
     if (kq == 0) {
       dcp_s[pad32(cp)] = dcp;
-      dgp_s[pad64(H + cp)] = dup;
+      dgu_s[pad32(cp)] = dup;
       float* xo = dxg + (row0 + t) * (6 * H) + d * 3 * H;
       xo[2 * H + cp] = dcp;
       xo[H + cp] = dup;
       rh_out[(row0 + t) * (2 * H) + d * H + cp] = r * hp;
     }
     lds_barrier();
-    // d(rh)[cp]
+    // d(rh)[cp]; the update half of dgp is fetched beside dcp and multiplied while the reset half is still in flight
+    float4 dv[H / 16], uv[H / 16];
+#pragma unroll
+    for (int i4 = 0; i4 < H / 16; ++i4) dv[i4] = reinterpret_cast<const float4*>(dcp_s + kq * (H / 4 + 4))[i4];
+#pragma unroll
+    for (int i4 = 0; i4 < H / 16; ++i4) uv[i4] = reinterpret_cast<const float4*>(dgu_s + kq * (H / 4 + 4))[i4];
     f2 p0 = {0.f, 0.f}, p1 = p0;
 #pragma unroll
     for (int i4 = 0; i4 < H / 16; ++i4) {
-      const float4 v = reinterpret_cast<const float4*>(dcp_s + kq * (H / 4 + 4))[i4];
-      p0 = pk_fma(f2{v.x, v.y}, wc_r[2 * i4], p0);
-      p1 = pk_fma(f2{v.z, v.w}, wc_r[2 * i4 + 1], p1);
+      p0 = pk_fma(f2{dv[i4].x, dv[i4].y}, wc_r[2 * i4], p0);
+      p1 = pk_fma(f2{dv[i4].z, dv[i4].w}, wc_r[2 * i4 + 1], p1);
     }
     const float drh = quad_sum(hsum(p0 + p1));
     const float drp = drh * hp * r * (1.f - r);
     if (kq == 0) {
-      dgp_s[pad64(cp)] = drp;
+      dgr_s[pad32(cp)] = drp;
       dxg[(row0 + t) * (6 * H) + d * 3 * H + cp] = drp;
     }
     lds_barrier();
+    float4 gv[H / 16];
+#pragma unroll
+    for (int i4 = 0; i4 < H / 16; ++i4) gv[i4] = reinterpret_cast<const float4*>(dgr_s + kq * (H / 4 + 4))[i4];
     f2 q0 = {0.f, 0.f}, q1 = q0;
 #pragma unroll
-    for (int i4 = 0; i4 < H / 8; ++i4) {
-      const float4 v = reinterpret_cast<const float4*>(dgp_s + kq * (H / 2 + 4))[i4];
-      q0 = pk_fma(f2{v.x, v.y}, wg_r[2 * i4], q0);
-      q1 = pk_fma(f2{v.z, v.w}, wg_r[2 * i4 + 1], q1);
+    for (int i4 = 0; i4 < H / 16; ++i4) {
+      q0 = pk_fma(f2{uv[i4].x, uv[i4].y}, wgu_r[2 * i4], q0);
+      q1 = pk_fma(f2{uv[i4].z, uv[i4].w}, wgu_r[2 * i4 + 1], q1);
+    }
+#pragma unroll
+    for (int i4 = 0; i4 < H / 16; ++i4) {
+      q0 = pk_fma(f2{gv[i4].x, gv[i4].y}, wgr_r[2 * i4], q0);
+      q1 = pk_fma(f2{gv[i4].z, gv[i4].w}, wgr_r[2 * i4 + 1], q1);
     }
     dh = dht * u + drh * r + quad_sum(hsum(q0 + q1));
-    if (i == CH - 1) {   // chunk boundary: the next chunk has landed (one store-latency wait per CH steps) and is published
-      wait_vm0();
+    if (i == CH - 1) {   // chunk boundary: the next chunk has landed (younger than its loads: 4 stores per step) and is published
+      wait_vm_older_than<4 * CH>();
       lds_barrier();
     }
   }
