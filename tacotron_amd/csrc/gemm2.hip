@@ -3,9 +3,12 @@
 //
 // What changed against gemm.hip (47 % matrix-pipe utilisation, one barrier per 16-deep k-tile, register-staged
 // loads, transposing ds_write_b32 stores):
-//   * both operands travel HBM/L2 -> LDS by direct DMA (global_load_lds_dwordx4, 1 KiB per wave instruction): no staging
-//     registers, no ds_write pass, no VALU selects.  Masked elements (rows outside the sequence for a shifted tap, the K / N /
-//     M tails) are redirected PER LANE to a 16-byte zero word, so the DMA image is always complete.
+//   * both operands travel HBM/L2 -> LDS by direct DMA (buffer_load_dwordx4 ... lds, 1 KiB per wave instruction): no staging
+//     registers, no ds_write pass.  Round 4: through a buffer descriptor per operand -- per-lane byte offsets are set up once
+//     (per tap for the shifted rows), the k-tile / tap advance is the instruction's SGPR offset, and masked elements (rows
+//     outside the sequence for a shifted tap, the K / N / M tails) carry an out-of-range offset, for which the hardware
+//     deposits zeros: a piece costs ~2 VALU + 3 SALU instead of ~14 VALU + a readfirstlane (the DMA issue was 13 % of a
+//     4096^3 launch, profiles/r04_gemm_lab.txt).
 //   * k-tiles are 32 deep (one barrier per 64 MFMAs per wave instead of per 32) in an NS-stage LDS ring with a COUNTED
 //     s_waitcnt vmcnt (the DMA of the next tile(s) stays in flight across the raw s_barrier).
 //   * A tile image = the global rows themselves (128 B per row, full cache lines); the 16-byte slots of a row are XOR-swizzled
@@ -29,6 +32,16 @@ __device__ __attribute__((aligned(16))) float g_zero4[4];   // zero-initialised 
 __device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+// The same DMA through a buffer descriptor: the address is  base + voffset (per lane) + soffset (SGPR), and a lane whose
+// voffset + soffset reaches num_records deposits ZEROS (tools/micro/bufload_lds.hip checks both on gfx950).  Everything that
+// changes from k-tile to k-tile goes into soffset, so a piece costs a scalar add instead of a 64-bit per-lane address.
+constexpr int kOOB = (int)0x80000000;   // >= num_records (0x7fffffff) whatever soffset is
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dma_rsrc(const float* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rs, int voffset, int soffset, float* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voffset, soffset, 0, 0);
 }
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -104,12 +117,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
   const int tnn = rel / mtiles, tmm = rel - tnn * mtiles;
   const int m0 = tmm * (P.pool ? TM - 1 : TM), n0 = tnn * TN;   // pooled epilogue: tiles overlap by their halo row
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: LDS destinations (M0) stay on the scalar unit
   const int T = P.T, K = P.K, lda = P.lda, ldw = P.ldw;
+  const int pad_l = P.pad_l;
 
-  // ---- DMA source setup: each thread serves the same A rows / B slots for every k-tile ----
-  const float* a_ptr[A_INSTR];
-  int a_t[A_INSTR], a_k[A_INSTR];
+  // ---- DMA source setup: each thread serves the same A rows / B slots for every k-tile.  Byte offsets against
+  //      A - pad_l rows (so that the tap shift is a non-negative scalar) and W; the launcher bounds both below 2 GiB ----
+  const __amdgpu_buffer_rsrc_t rsA = dma_rsrc(P.A - (int64_t)pad_l * lda), rsW = dma_rsrc(P.W);
+  int a_vo[A_INSTR], a_cur[A_INSTR], a_t[A_INSTR], a_klim[A_INSTR];
 #pragma unroll
   for (int i = 0; i < A_INSTR; ++i) {
     const int row = (wave * A_INSTR + i) * A_RPI + lane / SLOTS;
@@ -117,45 +133,41 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
     const int m = m0 + row;
     const bool ok = m < P.M;
     a_t[i] = ok ? m % T : -(1 << 28);
-    a_k[i] = 4 * q;
-    a_ptr[i] = P.A + (int64_t)(ok ? m : 0) * lda + 4 * q;
+    a_klim[i] = K - 4 * q;                       // the slot is inside the row while k0 < a_klim
+    a_vo[i] = ((ok ? m : 0) * lda + 4 * q) * 4;
   }
   const int b_c = n0 + 4 * (lane & 31);
   const bool b_ok = b_c < P.Nld;
   const int b_r0 = wave * B_INSTR * 2 + (lane >> 5);
-  const float* b_ptr = P.W + (int64_t)b_r0 * ldw + (b_ok ? b_c : 0);
+  const int b_klim = K - b_r0;                   // row k0 + 2 i + b_r0 exists while k0 + 2 i < b_klim
+  const int b_vo = b_ok ? (b_r0 * ldw + b_c) * 4 : kOOB;
 
   // k-tiles per tap, counted so that a tap always spans whole 32-deep units (a k-split chunk [it0, it1) is given in those
   // units whatever BK is; with BK = 16 an odd tail tile is all-masked zeros)
   const int ktiles = ((K + 31) / 32) * (32 / BK);
   const int it_begin = P.it0 * (32 / BK), it_end = (P.it1 > 0 ? P.it1 * (32 / BK) : P.taps * ktiles);
   const int nit = it_end - it_begin;
-  const int pad_l = P.pad_l;
-  // the zero word's address, kept in a VGPR pair (opaque to the optimiser: otherwise it is re-fetched from the GOT with an
-  // s_load + s_waitcnt lgkmcnt(0) in front of every DMA instruction, and lgkmcnt also counts the LDS fragment reads)
-  const float* zero = g_zero4;
-  asm volatile("" : "+v"(zero));
 
   // next tile to issue: (tap, k0) advance incrementally (no division on the loop path)
   int n_tap = it_begin / ktiles, n_k0 = (it_begin - n_tap * ktiles) * BK;
-  // one DMA instruction of the next tile (g < A_INSTR: A rows, else B rows) -- interleaved between the MFMA groups below
-  // (the lane select is written as mask arithmetic so that it stays ONE basic block: a branch around the address computation
-  //  would stop the scheduler from spreading these instructions over the MFMA shadows of the surrounding step)
-  auto pick = [&](const float* p, bool ok) {
-    const uint64_t m = ok ? ~0ull : 0ull;
-    return reinterpret_cast<const float*>((reinterpret_cast<uint64_t>(p) & m) | (reinterpret_cast<uint64_t>(zero) & ~m));
-  };
-  auto issue_piece = [&](int g, int stage) {
+  // rows a shifted tap pulls from outside their sequence are masked for the whole tap: recomputed when the tap changes
+  auto retap = [&]() {
     const int sh = n_tap - pad_l;
-    const int k0 = n_k0;
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) a_cur[i] = (unsigned)(a_t[i] + sh) < (unsigned)T ? a_vo[i] : kOOB;
+  };
+  retap();
+  // one DMA instruction of the next tile (g < A_INSTR: A rows, else B rows) -- interleaved between the MFMA groups below.
+  // Per piece: one compare + select for the K tail (never taken when K is a multiple of BK), scalar offsets, the load.
+  auto issue_piece = [&](int g, int stage) {
     float* As = smem + stage * STAGE;
     if (g < A_INSTR) {
-      const bool ok = (unsigned)(a_t[g] + sh) < (unsigned)T && k0 + a_k[g] < K;
-      glds16(pick(a_ptr[g] + ((int64_t)sh * lda + k0), ok), As + (wave * A_INSTR + g) * A_RPI * BK);
+      const int vo = n_k0 < a_klim[g] ? a_cur[g] : kOOB;
+      blds16(rsA, vo, (n_tap * lda + n_k0) * 4, As + (wave * A_INSTR + g) * A_RPI * BK);
     } else {
       const int i = g - A_INSTR;
-      const bool ok = b_ok && k0 + b_r0 + 2 * i < K;
-      glds16(pick(b_ptr + (((int64_t)n_tap * K + k0 + 2 * i) * ldw), ok), As + A_FLOATS + (wave * B_INSTR + i) * 2 * TN);
+      const int vo = n_k0 + 2 * i < b_klim ? b_vo : kOOB;
+      blds16(rsW, vo, ((n_tap * K + n_k0 + 2 * i) * ldw) * 4, As + A_FLOATS + (wave * B_INSTR + i) * 2 * TN);
     }
   };
   auto advance = [&]() {
@@ -163,6 +175,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
     if (n_k0 >= ktiles * BK) {
       n_k0 = 0;
       ++n_tap;
+      retap();
     }
   };
 
@@ -208,7 +221,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
       //  the only fixed point is the wait + sched_barrier at the head of the next step -- guide rule 18)
       if (s + 2 < NSTEP) b4[(s + 2) % 3] = dsr128<(8 * ((s + 2) >> 2) + ((s + 2) & 3)) * TN * 4>(bb);
       if (c == 1 && p + 1 < NP) a4[(p + 1) & 1] = dsr128<0>(sb + a_off[p + 1]);
+#ifndef GEMM2_LAB_NODMA
       if (s < NLD && fill) issue_piece(s, fill_stage);
+#endif
     });
   };
 
@@ -229,7 +244,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
   for (; it + NS - 1 < nit; ++it) {   // steady state: tile it + NS - 1 refills the stage tile it - 1 just vacated
     // this wave's share of tile `it` has landed once at most the younger tiles' DMA instructions are outstanding
     wait_vm<NLD*(NS - 2)>();
+#ifndef GEMM2_LAB_NOBAR
     __builtin_amdgcn_s_barrier();   // every wave's share has landed AND every wave has finished reading tile it - 1
+#endif
     asm volatile("" ::: "memory");
     compute(it % NS, (it + NS - 1) % NS, std::true_type{});
     advance();
@@ -689,13 +706,18 @@ static bool pool_contract(const ConvGemmProblem& p) {
            p.act == TACO_ACT_NONE;
   return common;
 }
+// the kernel addresses both operands with 32-bit byte offsets against one buffer descriptor each (range 2 GiB)
+static bool dma_contract(const ConvGemmProblem& p) {
+  const int64_t lim = (int64_t)1 << 31;
+  return ((int64_t)p.M + p.taps + 1) * p.lda * 4 + (int64_t)p.K * 4 < lim && ((int64_t)p.taps * p.K + 32) * p.ldw * 4 < lim;
+}
 bool conv_gemm2_would_launch(const ConvGemmBatch& batch) {
   const int min_tiles = gemm2_min_tiles();
   if (min_tiles <= 0) return false;
   int tiles = 0;
   for (int i = 0; i < batch.n; ++i) {
     const ConvGemmProblem& p = batch.p[i];
-    if ((p.flags & 3) != 3 || (p.pool && !pool_contract(p))) return false;
+    if ((p.flags & 3) != 3 || !dma_contract(p) || (p.pool && !pool_contract(p))) return false;
     tiles += m_tiles(p) * cdiv(p.N, TN);
   }
   return tiles >= min_tiles;
@@ -710,7 +732,7 @@ int launch_conv_gemm2(ConvGemmBatch& batch, hipStream_t stream, bool force) {
   bool any_pool = false;
   for (int i = 0; i < batch.n; ++i) {
     ConvGemmProblem& p = batch.p[i];
-    if ((p.flags & 3) != 3) return TACO_ENOTFOUND;   // both operands: 16-byte aligned rows, K / Nld multiples of 4
+    if ((p.flags & 3) != 3 || !dma_contract(p)) return TACO_ENOTFOUND;   // both operands: 16-byte aligned rows, K / Nld multiples of 4, < 2 GiB
     if (p.pool) {
       TACO_REQUIRE(pool_contract(p), "conv_gemm2: pooled epilogue needs float4 rows and no keep / residual / row bias / atomics / k-split");
       any_pool = true;
