@@ -23,7 +23,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default)
 
-#define TACO_VERSION 114
+#define TACO_VERSION 115
 
 #define TACO_OK 0
 #define TACO_EINVAL (-1)   /* bad argument / unsupported shape   */
@@ -83,6 +83,12 @@ int taco_conv_gemm(const float* A, int lda, const float* W, int ldw, const float
 /* Same contract (without the post() part), run the way the library runs the tall-skinny CBHG projections: the (tap, k) sum is
  * cut into chunks that become independent workgroups writing partial slabs (scratch `slabs`, `slab_floats` floats), summed in a
  * fixed order by a second pass -- deterministic, no atomics.  Exposed for parity tests and tuning. */
+/* debug: only the eligible NN launches whose running index falls in [lo, hi) use gemm2.hip's kernel (bisecting a divergence);
+ * returns the number of eligible (non-pooled) launches seen since the previous call and restarts the count */
+int taco_debug_gemm2_window(int lo, int hi);
+/* debug / test aid: dense layer with weight rows zero-padded to nld loadable columns (the final 256 -> 1025 layer's form) */
+int taco_debug_conv_gemm_nld(const float* A, int lda, const float* W, int ldw, int nld, const float* bias, float* C, int ldc, int M,
+                             int N, int K, int act, void* stream);
 int taco_debug_conv_gemm_ksplit(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M,
                                 int N, int K, int taps, int T, int pad_l, int act, float* slabs, int64_t slab_floats,
                                 void* stream);

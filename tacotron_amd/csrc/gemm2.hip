@@ -95,6 +95,7 @@ struct Gemm2Args {
   ConvGemmBatch batch;
   int first[kMaxGemmBatch];   // first linear tile of each problem
   int mt[kMaxGemmBatch];      // m-tiles of each problem (m runs fastest inside a problem)
+  int xcd_map;                // 1: XCD-aware tile order (below)
 };
 
 template <int BK, int NS>
@@ -108,13 +109,33 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
   constexpr int SWZ_SH = BK == 32 ? 1 : 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];   // NS * STAGE floats, the ONLY LDS object of the kernel
 
+  // Tile order.  The dispatcher deals workgroups to the 8 XCDs round-robin (workgroup id % 8), each XCD with its own L2.
+  //  * xcd_map (batches whose tiles all run equally long): XCD x takes a CONTIGUOUS eighth of the linear tile list, in which
+  //    the n-tiles of one m-tile are neighbours -- they are resident together in ONE L2: the A rows they share are fetched from
+  //    the fabric once (not once per XCD the old order spread them over), and the partial cache lines two neighbouring
+  //    n-tiles write at their seam (row pitch 1025) merge in that L2.
+  //  * otherwise (conv banks: problems of different depth, longest first) the list is dealt in order so that every XCD gets
+  //    the same mix of long and short tiles.
+  int lin = blockIdx.x;
+  if (G.xcd_map) {
+    const int tiles = gridDim.x, q = tiles >> 3, rem = tiles & 7, x = lin & 7, j = lin >> 3;
+    lin = x * q + (x < rem ? x : rem) + j;
+  }
   int pi = 0;
   for (int i = 1; i < G.batch.n; ++i)
-    if ((int)blockIdx.x >= G.first[i]) pi = i;
+    if (lin >= G.first[i]) pi = i;
   const ConvGemmProblem& P = G.batch.p[pi];
-  const int rel = blockIdx.x - G.first[pi];
+  const int rel = lin - G.first[pi];
   const int mtiles = G.mt[pi];
-  const int tnn = rel / mtiles, tmm = rel - tnn * mtiles;
+  int tnn, tmm;
+  if (G.xcd_map) {
+    const int ntiles = (P.N + TN - 1) / TN;
+    tmm = rel / ntiles;
+    tnn = rel - tmm * ntiles;
+  } else {
+    tnn = rel / mtiles;
+    tmm = rel - tnn * mtiles;
+  }
   const int m0 = tmm * (P.pool ? TM - 1 : TM), n0 = tnn * TN;   // pooled epilogue: tiles overlap by their halo row
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -441,6 +462,54 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
     }
   }
   const bool affine = P.scale || P.shift;
+  if (P.flags & 8) {
+    // ---- rows whose pitch is not a multiple of 4 floats (the final dense layer: 1025 columns, tacotron.py:148).  Element
+    //      (m, c) of a 16-byte aligned C sits at float index m * ldc + c, so the aligned float4 groups of row m start at
+    //      columns c = s (mod 4) with s = (-m * ldc) mod 4 -- the same for every lane of the wave (rows differ by multiples of 4
+    //      between lanes).  A lane owns columns n .. n+3; it stores the ALIGNED group n+s .. n+s+3 = its own elements s..3 and the
+    //      first s elements of the lane to its right (DPP wave_shl:1), lane 0 adds the s head columns of the tile as scalars and
+    //      lane 31 its last 4-s (the group beyond belongs to the next tile): 16 float4 stores per lane instead of 64 scalar ones.
+    //      Launcher contract (bit 3): bias / activation / affine only.
+    const int ldm = P.ldc & 3;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = m0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+      float v[4], nx[3];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float x = apply_act(acc[j][e] + bias0[j], P.act);
+        if (affine) x = x * sc[j] + sf[j];
+        v[j] = x;
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) nx[j] = dpp_move<0x130>(0.f, v[j]);   // wave_shl:1 -- lane i <- lane i + 1
+      if (m >= P.M) continue;
+      // rows e, e+4, ... of the two halves share m mod 4; the shift is wave-uniform per e
+      const int sft = (4 - (((m0 + (e & 3)) & 3) * ldm & 3)) & 3;
+      float* crow = P.C + (int64_t)m * P.ldc;
+      float o[4];
+      switch (sft) {
+        case 0: o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; break;
+        case 1: o[0] = v[1]; o[1] = v[2]; o[2] = v[3]; o[3] = nx[0]; break;
+        case 2: o[0] = v[2]; o[1] = v[3]; o[2] = nx[0]; o[3] = nx[1]; break;
+        default: o[0] = v[3]; o[1] = nx[0]; o[2] = nx[1]; o[3] = nx[2]; break;
+      }
+      const int c0 = n + sft;
+      if (li < 31 && c0 + 3 < P.N) {
+        *reinterpret_cast<float4*>(crow + c0) = make_float4(o[0], o[1], o[2], o[3]);
+      } else {   // the tile's last lane / the N tail: only this lane's own elements, one by one
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j >= sft && n + j < P.N) crow[n + j] = v[j];
+      }
+      if (li == 0) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          if (j < sft && n + j < P.N) crow[n + j] = v[j];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int m = m0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
@@ -660,10 +729,10 @@ struct Variant {
   int bk, ns;
 };
 Variant env_variant() {   // read on every launch (tests and the tuning harness switch variants inside one process)
-  Variant r{32, 2};
-  if (const char* e = getenv("TACO_GEMM2_VARIANT")) {   // "<BK>x<stages>": 32x2 (default), 32x3, 16x3, 16x4
+  Variant r{16, 4};
+  if (const char* e = getenv("TACO_GEMM2_VARIANT")) {   // "<BK>x<stages>": 16x4 (default), 32x2 (forward conv banks), 32x3, 16x3, 16x5
     int bk = 0, ns = 0;
-    if (sscanf(e, "%dx%d", &bk, &ns) == 2 && (bk == 16 || bk == 32) && ns >= 2 && ns <= 4) r = Variant{bk, ns};
+    if (sscanf(e, "%dx%d", &bk, &ns) == 2 && (bk == 16 || bk == 32) && ns >= 2 && ns <= 5) r = Variant{bk, ns};
   }
   return r;
 }
@@ -763,23 +832,42 @@ int launch_conv_gemm2(ConvGemmBatch& batch, hipStream_t stream, bool force) {
     const bool vec = p.N % 4 == 0 && p.ldc % 4 == 0 && al16(p.C) && (!p.Cpre || al16(p.Cpre)) &&
                      (!p.residual || (p.ldr % 4 == 0 && al16(p.residual))) &&
                      (!p.keep || (reinterpret_cast<uintptr_t>(p.keep) & 3) == 0);
-    p.flags = (p.flags & 3) | (vec ? 4 : 0);
+    // bit 3: shifted float4 epilogue for row pitches that are not multiples of 4 (plain bias / activation / affine outputs only)
+    const bool shifted = !vec && !p.pool && al16(p.C) && p.ldc % 4 != 0 && !p.Cpre && !p.residual && !p.keep && !p.atomic_out &&
+                         p.bias_stride == 0 && p.it0 == 0 && p.it1 == 0;
+    p.flags = (p.flags & 3) | (vec ? 4 : 0) | (shifted ? 8 : 0);
     g.batch.p[i] = p;
     g.first[i] = first;
     g.mt[i] = m_tiles(p);
     first += g.mt[i] * cdiv(p.N, TN);
   }
+  // XCD-aware order when every tile of the grid runs the same number of k-tiles (TACO_GEMM2_XCD=0: the old order, A/B runs)
+  {
+    bool same = true;
+    auto depth = [](const ConvGemmProblem& p) {
+      return p.it1 > 0 ? (int64_t)(p.it1 - p.it0) : (int64_t)p.taps * ((p.K + 31) / 32);
+    };
+    for (int i = 1; i < batch.n; ++i) same = same && depth(g.batch.p[i]) == depth(g.batch.p[0]);
+    const char* e = getenv("TACO_GEMM2_XCD");
+    g.xcd_map = (same && !(e && atoi(e) == 0)) ? 1 : 0;
+  }
   Variant v = env_variant();
   if (!getenv("TACO_GEMM2_VARIANT")) {
-    // K = 80 (post-net conv bank: 80 mel channels) is 2.5 tiles of 32 -- the 16-deep instantiation wastes nothing there
-    bool k16 = true;
-    for (int i = 0; i < batch.n; ++i) k16 = k16 && batch.p[i].K % 32 != 0 && batch.p[i].K % 16 == 0;
-    if (k16) v = Variant{16, 3};
+    // Both forms hold 64 KB of LDS (two workgroups per CU).  Four 16-deep stages keep 48 k-columns in flight instead of 32:
+    // inside a train step the operands come from HBM / the Infinity Cache, not from a warm L2, and the deeper ring is what
+    // the launches with long rows wait less with (same-box family traces, profiles/r04_gemm_variants.txt: post-net proj1
+    // input gradient 221 -> 186 us, proj1 k-split 210-230 -> 202; everything else within 2 %).  K = 80 (post-net conv bank) is 2.5
+    // tiles of 32 and needs the 16-deep form anyway.  The forward conv bank of the encoder (K = 128 per tap, L2-resident
+    // working set) stays on the 32-deep form: 258 vs 265 us.
+    bool bank32 = true;
+    for (int i = 0; i < batch.n; ++i) bank32 = bank32 && batch.p[i].pool == 1 && batch.p[i].K % 32 == 0;
+    v = bank32 ? Variant{32, 2} : Variant{16, 4};
   }
   if (v.bk == 32 && v.ns == 2) return launch_variant<32, 2>(g, tiles, stream);
   if (v.bk == 32 && v.ns == 3) return launch_variant<32, 3>(g, tiles, stream);
   if (v.bk == 16 && v.ns == 3) return launch_variant<16, 3>(g, tiles, stream);
   if (v.bk == 16 && v.ns == 4) return launch_variant<16, 4>(g, tiles, stream);
+  if (v.bk == 16 && v.ns == 5) return launch_variant<16, 5>(g, tiles, stream);
   return launch_variant<32, 2>(g, tiles, stream);
 }
 

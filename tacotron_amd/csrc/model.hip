@@ -536,6 +536,7 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
   pb.tapsplit_floats = W.tapsplit_floats;
   TACO_TRY(cbhg_fwd(P, PL.post, s2s, B, Td * r, pb, train, s));
   {
+    // output rows are 1025 floats apart: gemm2.hip writes them with its shifted float4 epilogue (92 vs 105 us with scalar stores)
     ConvGemmProblem p = dense_problem(pb.out, 2 * kCb, ws + W.wd_pad, 1028, P + PL.post_dense.b, output, kFft, M2, kFft,
                                       2 * kCb, TACO_ACT_NONE);
     p.Nld = 1028;
@@ -1257,6 +1258,17 @@ extern "C" int taco_conv_gemm(const float* A, int lda, const float* W, int ldw, 
   p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.bias = bias; p.scale = scale; p.shift = shift; p.residual = residual;
   p.ldr = ldr; p.keep = keep; p.C = C; p.ldc = ldc; p.Cpre = Cpre; p.M = M; p.N = N; p.K = K; p.taps = taps; p.T = T;
   p.pad_l = pad_l; p.act = act;
+  return launch_conv_gemm(p, as_stream(stream));
+}
+
+// debug / test aid: a dense layer whose weight rows are stored zero-padded to `nld` loadable columns (nld >= N, multiple of 4,
+// <= ldw) -- how taco_forward runs the final 256 -> 1025 layer (padded weight copy, output pitch 1025)
+extern "C" int taco_debug_conv_gemm_nld(const float* A, int lda, const float* W, int ldw, int nld, const float* bias, float* C,
+                                        int ldc, int M, int N, int K, int act, void* stream) {
+  TACO_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0 && nld >= N && nld <= ldw, "conv_gemm_nld: bad arguments");
+  ConvGemmProblem p;
+  p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.Nld = nld; p.bias = bias; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
+  p.taps = 1; p.T = M; p.pad_l = 0; p.act = act;
   return launch_conv_gemm(p, as_stream(stream));
 }
 

@@ -58,6 +58,8 @@ EXPORTS = {
     'taco_workspace_bytes': (C.c_int64, [_SH, _I]),
     'taco_workspace_table': (C.c_int, [_SH, _I, C.POINTER(TacoTensorInfo), _I]),
     'taco_conv_gemm': (C.c_int, [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'taco_debug_gemm2_window': (C.c_int, [_I, _I]),
+    'taco_debug_conv_gemm_nld': (C.c_int, [_P, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     'taco_debug_conv_gemm_ksplit': (C.c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, C.c_int64, _P]),
     'taco_gemm_tn': (C.c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'taco_debug_gemm_naive': (C.c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -157,6 +159,15 @@ def conv_gemm(A, W, C_out, M, N, K, taps=1, T=None, pad_l=0, act=0, bias=None, s
     _check(_lib.taco_conv_gemm(ptr(A), lda or K, ptr(W), ldw or N, ptr(bias), ptr(scale), ptr(shift), ptr(residual),
                                ldr or N, ptr(keep), ptr(C_out), ldc or N, ptr(Cpre), M, N, K, taps, T, pad_l, act,
                                stream_ptr()), 'taco_conv_gemm')
+
+
+def debug_gemm2_window(lo, hi):
+    return int(_lib.taco_debug_gemm2_window(lo, hi))
+
+
+def conv_gemm_nld(A, W, C_out, M, N, K, nld, ldw, ldc, act=0, bias=None):
+    _check(_lib.taco_debug_conv_gemm_nld(ptr(A), K, ptr(W), ldw, nld, ptr(bias), ptr(C_out), ldc, M, N, K, act, stream_ptr()),
+           'taco_debug_conv_gemm_nld')
 
 
 def conv_gemm_ksplit(A, W, C_out, M, N, K, slabs, taps=1, T=None, pad_l=0, act=0, bias=None):

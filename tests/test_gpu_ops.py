@@ -107,11 +107,11 @@ V2_CASES = [c for c in CASES if c[2] % 4 == 0 and c[3] % 4 == 0] + [
 ]
 
 
-@pytest.mark.parametrize('variant', ['32x2', '32x3', '16x3', '16x4'])
+@pytest.mark.parametrize('variant', ['32x2', '32x3', '16x3', '16x4', '16x5'])
 @pytest.mark.parametrize('case', V2_CASES, ids=[str(c[:6]) for c in V2_CASES])
 def test_conv_gemm_v2(built_lib, case, variant, monkeypatch):
-    """gemm2.hip (DMA-staged, swizzled, 4-MFMAs-per-read kernel) forced for every shape that meets its contract, in all four
-    (k-tile depth x ring stages) instantiations: K / N / M tails redirected to the zero word, tap shifts across sequence
+    """gemm2.hip (DMA-staged, swizzled, 4-MFMAs-per-read kernel) forced for every shape that meets its contract, in all five
+    (k-tile depth x ring stages) instantiations: K / N / M tails as out-of-range buffer offsets (zeros), tap shifts across sequence
     boundaries, the float4 and the scalar epilogue."""
     monkeypatch.setenv('TACO_GEMM2_MIN_TILES', '1')
     monkeypatch.setenv('TACO_GEMM2_VARIANT', variant)
@@ -137,6 +137,33 @@ def test_conv_gemm_ksplit(built_lib, case):
     ref, _ = conv_ref(A, W, bias, T, pad_l, act)
     assert report('conv_gemm_ksplit %s' % (case,), outs[0].cpu().numpy(), ref)[0] < 5e-6
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize('variant', ['16x4', '32x2'])
+@pytest.mark.parametrize('N,ldc,act', [(1025, 1025, 0), (1025, 1027, 1), (514, 518, 0), (131, 133, 3), (1024, 1025, 0), (1025, 1030, 0)],
+                         ids=['dense-1025', 'pitch-3mod4', 'pitch-2mod4', 'narrow', 'full-tiles', 'pitch-2mod4-odd-N'])
+def test_conv_gemm_v2_shifted_rows(built_lib, N, ldc, act, variant, monkeypatch):
+    """gemm2.hip's shifted float4 epilogue: output rows whose pitch is not a multiple of 4 floats (the final dense layer writes
+    (B*F, 1025) from a weight copy padded to 1028 columns, tacotron.py:148 / model.hip).  Every pitch residue, the N tail inside
+    a tile, an M tail; nothing may land outside the N columns of a row (sentinel in the pitch padding and behind the last row),
+    and the kernel must really be the DMA one (the old kernel is switched off for the call)."""
+    monkeypatch.setenv('TACO_GEMM2_MIN_TILES', '1')
+    monkeypatch.setenv('TACO_GEMM2_VARIANT', variant)
+    rng = np.random.default_rng(N * 7 + ldc)
+    M, K = 333, 96
+    nld = (N + 3) // 4 * 4
+    A = rng.standard_normal((M, K))
+    W = rng.standard_normal((1, K, N)) / np.sqrt(K)
+    Wp = np.zeros((K, nld)); Wp[:, :N] = W[0]
+    bias = rng.standard_normal(N)
+    flat = torch.full((M * ldc + 64,), 7.5, device='cuda')
+    before = built_lib.debug_gemm2_window(0, 1 << 30)
+    built_lib.conv_gemm_nld(dev(A), dev(Wp), flat, M, N, K, nld, nld, ldc, act=act, bias=dev(bias))
+    assert built_lib.debug_gemm2_window(0, 1 << 30) == 1, 'the launch did not go to gemm2.hip'
+    ref, _ = conv_ref(A, W, bias, M, 0, act)
+    C = flat[:M * ldc].view(M, ldc)
+    assert report('shifted rows N=%d ldc=%d %s' % (N, ldc, variant), C[:, :N].cpu().numpy(), ref)[0] < 5e-6
+    assert bool((C[:, N:] == 7.5).all()) and bool((flat[M * ldc:] == 7.5).all())
 
 
 def test_conv_gemm_strided_unaligned(built_lib):

@@ -21,11 +21,11 @@ def run(name, M, N, K, lda=None, ldw=None, ldc=None, blas=False):
     A = torch.randn(M, lda, device='cuda'); W = torch.randn(K, ldw, device='cuda') * 0.05; C = torch.empty(M, ldc, device='cuda')
     us = steady(lambda: lib.conv_gemm(A, W, C, M, N, K, taps=1, T=M, pad_l=0, act=0, lda=lda, ldw=ldw, ldc=ldc))
     gf = 2.0 * M * N * K / 1e9
-    line = '%-58s %7.1f us %6.1f TF' % (name, us, gf / us * 1e-3)
+    line = '%-58s %7.1f us %6.1f TF' % (name, us, gf / us * 1e3)
     if blas:
         Av, Wv = A[:, :K], W[:, :N]
         ub = steady(lambda: torch.mm(Av, Wv))
-        line += '   | vendor BLAS %7.1f us %6.1f TF' % (ub, gf / ub * 1e-3)
+        line += '   | vendor BLAS %7.1f us %6.1f TF' % (ub, gf / ub * 1e3)
     print(line, flush=True)
 
 

@@ -22,6 +22,6 @@ for (M, N, K) in [(4096, 4096, 4096), (11520, 1024, 256), (11520, 256, 1024), (1
     for v in sys.argv[1:] or ['32x2', '32x3', '16x3', '16x4']:
         os.environ['TACO_GEMM2_VARIANT'] = v
         us = steady(lambda: lib.conv_gemm(A, W, C, M, N, K, taps=1, T=M, pad_l=0, act=0))
-        out.append('%s %.1f us %.1f TF' % (v, us, gf / us * 1e-3))
+        out.append('%s %.1f us %.1f TF' % (v, us, gf / us * 1e3))
     ub = steady(lambda: torch.mm(A, W))
-    print('M=%d N=%d K=%d: %s | BLAS %.1f us %.1f TF' % (M, N, K, ' | '.join(out), ub, gf / ub * 1e-3), flush=True)
+    print('M=%d N=%d K=%d: %s | BLAS %.1f us %.1f TF' % (M, N, K, ' | '.join(out), ub, gf / ub * 1e3), flush=True)
