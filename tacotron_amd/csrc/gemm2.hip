@@ -497,10 +497,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
       const int c0 = n + sft;
       if (li < 31 && c0 + 3 < P.N) {
         *reinterpret_cast<float4*>(crow + c0) = make_float4(o[0], o[1], o[2], o[3]);
-      } else {   // the tile's last lane / the N tail: only this lane's own elements, one by one
+      } else {   // the tile's last lane / the N tail: this lane's own elements one by one, and (inside the tile) the elements of
+                 // the lane to the right that its own group would have carried
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (j >= sft && n + j < P.N) crow[n + j] = v[j];
+        if (li < 31) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+            if (j < sft && n + 4 + j < P.N) crow[n + 4 + j] = nx[j];
+        }
       }
       if (li == 0) {
 #pragma unroll

@@ -140,8 +140,10 @@ def test_conv_gemm_ksplit(built_lib, case):
 
 
 @pytest.mark.parametrize('variant', ['16x4', '32x2'])
-@pytest.mark.parametrize('N,ldc,act', [(1025, 1025, 0), (1025, 1027, 1), (514, 518, 0), (131, 133, 3), (1024, 1025, 0), (1025, 1030, 0)],
-                         ids=['dense-1025', 'pitch-3mod4', 'pitch-2mod4', 'narrow', 'full-tiles', 'pitch-2mod4-odd-N'])
+@pytest.mark.parametrize('N,ldc,act', [(1025, 1025, 0), (1025, 1027, 1), (514, 518, 0), (131, 133, 3), (1024, 1025, 0), (1025, 1030, 0), (133, 135, 0),
+                                       (262, 263, 0)],
+                         ids=['dense-1025', 'pitch-3mod4', 'pitch-2mod4', 'narrow', 'full-tiles', 'pitch-2mod4-odd-N', 'tail-5-of-a-tile',
+                              'tail-6-of-a-tile'])
 def test_conv_gemm_v2_shifted_rows(built_lib, N, ldc, act, variant, monkeypatch):
     """gemm2.hip's shifted float4 epilogue: output rows whose pitch is not a multiple of 4 floats (the final dense layer writes
     (B*F, 1025) from a weight copy padded to 1028 columns, tacotron.py:148 / model.hip).  Every pitch residue, the N tail inside
