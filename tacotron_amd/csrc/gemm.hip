@@ -313,12 +313,37 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTnArgs& P, const int bx, 
   if (nit <= 0) return;
 
   float4 ra[A_PER], rb[B_PER];
-  bool oka[A_PER], okb[B_PER];
   const bool do_bias = P.dbias != nullptr && bx == 0 && tap == 0;
   float4 bsum[B_PER];
 #pragma unroll
   for (int i = 0; i < B_PER; ++i) bsum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto load_tile = [&](int it) {
+  // Vector paths (round 4): both operands through buffer descriptors.  A lane's byte offset is fixed for the launch, the row
+  // advance of a tile is the instruction's SGPR offset, a masked lane (rows outside the chunk / outside their sequence for a
+  // shifted tap, the K / N tails) carries an out-of-range offset and receives zeros, and the row-in-sequence index is carried
+  // from tile to tile instead of a modulo per load (the modulo alone was 5-9 % of the big launches, profiles/r04_tn_lab.txt).
+  // The launcher only sets the vector flags when both operands are addressable with 31 bits.
+  constexpr int kOOB = (int)0x80000000;
+  __amdgpu_buffer_rsrc_t rsA, rsY;
+  int a_vo[A_PER], a_t[A_PER], b_vo[B_PER];
+  if constexpr (VA) {
+    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + (int64_t)sh * P.lda), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      const int r = a_r + i * A_RSTEP, k = k0 + a_c4 * 4;
+      a_vo[i] = (r < BK && k < P.K) ? ((m_begin + r) * P.lda + k) * 4 : kOOB;
+      a_t[i] = (m_begin + r) % P.T;
+    }
+  }
+  if constexpr (VB) {
+    rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Y), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      const int r = b_r + i * B_RSTEP, n = n0 + b_c4 * 4;
+      b_vo[i] = (r < BK && n < P.Nld) ? ((m_begin + r) * P.ldy + n) * 4 : kOOB;
+    }
+  }
+  auto as_f4 = [](auto v) { return __builtin_bit_cast(float4, v); };
+  auto load_tile = [&](int it) {   // called with it = 0, 1, 2, ... in order (a_t is carried)
     const int mm0 = m_begin + it * BK;
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
@@ -327,11 +352,11 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTnArgs& P, const int bx, 
       const int m = mm0 + r;
       const int k = k0 + a_c4 * 4;
       if constexpr (VA) {
-        const int st = (m % P.T) + sh;
-        const bool ok = r < BK && m < m_end && (unsigned)st < (unsigned)P.T && k < P.K;
-        const int64_t off = (int64_t)ok * ((int64_t)(m + sh) * P.lda + k);
-        v = *reinterpret_cast<const float4*>(A + off);
-        oka[i] = ok;
+        const bool ok = m < m_end && (unsigned)(a_t[i] + sh) < (unsigned)P.T;
+        v = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? a_vo[i] : kOOB, it * (BK * 4) * P.lda, 0));
+        a_t[i] += BK;
+        if (P.T >= BK) a_t[i] = a_t[i] >= P.T ? a_t[i] - P.T : a_t[i];
+        else a_t[i] %= P.T;
       } else if (r < BK && m < m_end) {
         const int st = (m % P.T) + sh;
         if (st >= 0 && st < P.T) {
@@ -351,10 +376,7 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTnArgs& P, const int bx, 
       const int m = mm0 + r;
       const int n = n0 + b_c4 * 4;
       if constexpr (VB) {
-        const bool ok = r < BK && m < m_end && n < P.Nld;
-        const int64_t off = (int64_t)ok * ((int64_t)m * P.ldy + n);
-        v = *reinterpret_cast<const float4*>(Y + off);
-        okb[i] = ok;
+        v = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rsY, m < m_end ? b_vo[i] : kOOB, it * (BK * 4) * P.ldy, 0));
       } else if (r < BK && m < m_end) {
         const float* p = Y + (int64_t)m * P.ldy + n;
         if (n < P.N) v.x = p[0];
@@ -369,12 +391,12 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTnArgs& P, const int bx, 
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
       const int r = a_r + i * A_RSTEP;
-      if (r < BK) *reinterpret_cast<float4*>(&As[buf][r][a_c4 * 4]) = VA ? sel4(oka[i], ra[i]) : ra[i];
+      if (r < BK) *reinterpret_cast<float4*>(&As[buf][r][a_c4 * 4]) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
       const int r = b_r + i * B_RSTEP;
-      const float4 v = VB ? sel4(okb[i], rb[i]) : rb[i];
+      const float4 v = rb[i];
       if (r < BK) *reinterpret_cast<float4*>(&Bs[buf][r][b_c4 * 4]) = v;
       if (do_bias) { bsum[i].x += v.x; bsum[i].y += v.y; bsum[i].z += v.z; bsum[i].w += v.w; }
     }
@@ -682,8 +704,13 @@ static int tn_block_target() {
 static int plan_gemm_tn(GemmTnArgs& a, bool force_small, dim3& grid, int64_t group_tiles = 0) {
   a.flags = 0;
   if (a.Nld <= 0) a.Nld = (a.N % 4 == 0) ? a.N : 0;
-  if (a.lda % 4 == 0 && aligned16(a.A) && a.strideA % 4 == 0 && a.K % 4 == 0) a.flags |= 1;
-  if (a.ldy % 4 == 0 && aligned16(a.Y) && a.strideY % 4 == 0 && a.Nld > 0 && a.Nld % 4 == 0 && a.Nld <= a.ldy) a.flags |= 2;
+  // (the vector paths address an operand with 32-bit byte offsets against one buffer descriptor: its extent must stay below 2 GiB)
+  const int64_t lim31 = (int64_t)1 << 31;
+  if (a.lda % 4 == 0 && aligned16(a.A) && a.strideA % 4 == 0 && a.K % 4 == 0 && ((int64_t)a.M + a.taps + 16) * a.lda * 4 < lim31)
+    a.flags |= 1;
+  if (a.ldy % 4 == 0 && aligned16(a.Y) && a.strideY % 4 == 0 && a.Nld > 0 && a.Nld % 4 == 0 && a.Nld <= a.ldy &&
+      ((int64_t)a.M + 16) * a.ldy * 4 < lim31)
+    a.flags |= 2;
   const bool big = !force_small && (int64_t)cdiv(a.K, 128) * cdiv(a.N, 128) * a.taps * a.batch >= 128 && a.K >= 128 && a.N >= 128;
   const int bm = big ? 128 : 64;
   const int64_t tiles = (int64_t)cdiv(a.K, bm) * cdiv(a.N, bm) * a.taps * a.batch;
