@@ -716,7 +716,10 @@ static int plan_gemm_tn(GemmTnArgs& a, bool force_small, dim3& grid, int64_t gro
   const int64_t tiles = (int64_t)cdiv(a.K, bm) * cdiv(a.N, bm) * a.taps * a.batch;
   const int64_t fill = group_tiles > tiles ? group_tiles : tiles;
   int splits = taco_deterministic() ? 1 : (int)((tn_block_target() + fill - 1) / fill);   // deterministic: one workgroup owns the whole row range
-  const int max_splits = cdiv(a.M, 64);
+  // at least 20 tiles of 16 rows per workgroup on the long row ranges: a 64 x 64 epilogue is 4096 atomics, and with the loads
+  // as cheap as they are now short row ranges spend more time in it than in their MFMAs (profiles/r04_tn_lab.txt: no-atomics
+  // build -35..-45 % on the launches that used to be cut into 64-100-row pieces; TACO_TN_BLOCKS sweep in the same file)
+  const int max_splits = a.M >= 1280 ? cdiv(a.M, 320) : cdiv(a.M, 64);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   int chunk = cdiv(a.M, splits);
