@@ -274,7 +274,8 @@ __global__ void conv_gemm_tapsum_kernel(ConvGemmProblem P, const float* __restri
       if (P.Cpre) P.Cpre[(int64_t)m * P.ldc + n] = v;
       if (P.scale || P.shift) v = v * (P.scale ? P.scale[n] * P.scale_mul : 1.f) + (P.shift ? P.shift[n] : 0.f);
       if (P.residual) v += P.residual[(int64_t)m * P.ldr + n];
-      P.C[(int64_t)m * P.ldc + n] = v;
+      if (P.atomic_out) P.C[(int64_t)m * P.ldc + n] += v;   // "C += result": one thread owns the element, no atomic needed
+      else P.C[(int64_t)m * P.ldc + n] = v;
     }
   }
 }
@@ -588,6 +589,17 @@ int launch_conv_gemm_batch(ConvGemmBatch& batch, hipStream_t stream) {
   }
   taco_prof_end(2, pslot, stream, flops);
   TACO_LAUNCH_CHECK("conv_gemm");
+  return TACO_OK;
+}
+
+// C = epilogue(slab_0 + ... + slab_{n-1}) for partial results written by the caller's own chunked launch (slabs: n x M x N floats,
+// row pitch N); p describes the epilogue (bias / activation / affine / residual / C, ldc) and M, N, T.
+int launch_conv_gemm_slab_sum(const ConvGemmProblem& p, const float* slabs, int n, hipStream_t stream) {
+  TACO_REQUIRE(slabs && n >= 1 && p.M > 0 && p.N > 0 && p.N % 4 == 0 && p.C, "conv_gemm_slab_sum: bad arguments");
+  const int64_t total4 = (int64_t)p.M * p.N / 4;
+  const int grid = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
+  hipLaunchKernelGGL(conv_gemm_tapsum_kernel, dim3(grid), dim3(256), 0, stream, p, slabs, n);
+  TACO_LAUNCH_CHECK("conv_gemm_slab_sum");
   return TACO_OK;
 }
 

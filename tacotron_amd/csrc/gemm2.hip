@@ -171,11 +171,22 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
 
   // next tile to issue: (tap, k0) advance incrementally (no division on the loop path)
   int n_tap = it_begin / ktiles, n_k0 = (it_begin - n_tap * ktiles) * BK;
+  // row shift of the tap (t_sh) and, in the conv bank's gather mode (ConvGemmProblem::bank_filters), the filter it belongs to
+  // (bf, tap bj of it) with the column block of A that filter reads (t_col)
+  const int bankF = P.bank_filters;
+  int bf = 1, bj = n_tap, t_sh = n_tap - pad_l, t_col = 0;
+  if (bankF) {
+    while (bj >= bf) {
+      bj -= bf;
+      ++bf;
+    }
+    t_sh = bj - ((bf - 1) - (bf - 1) / 2);
+    t_col = (bf - 1) * K;
+  }
   // rows a shifted tap pulls from outside their sequence are masked for the whole tap: recomputed when the tap changes
   auto retap = [&]() {
-    const int sh = n_tap - pad_l;
 #pragma unroll
-    for (int i = 0; i < A_INSTR; ++i) a_cur[i] = (unsigned)(a_t[i] + sh) < (unsigned)T ? a_vo[i] : kOOB;
+    for (int i = 0; i < A_INSTR; ++i) a_cur[i] = (unsigned)(a_t[i] + t_sh) < (unsigned)T ? a_vo[i] : kOOB;
   };
   retap();
   // one DMA instruction of the next tile (g < A_INSTR: A rows, else B rows) -- interleaved between the MFMA groups below.
@@ -184,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
     float* As = smem + stage * STAGE;
     if (g < A_INSTR) {
       const int vo = n_k0 < a_klim[g] ? a_cur[g] : kOOB;
-      blds16(rsA, vo, (n_tap * lda + n_k0) * 4, As + (wave * A_INSTR + g) * A_RPI * BK);
+      blds16(rsA, vo, ((t_sh + pad_l) * lda + t_col + n_k0) * 4, As + (wave * A_INSTR + g) * A_RPI * BK);
     } else {
       const int i = g - A_INSTR;
       const int vo = n_k0 + 2 * i < b_klim ? b_vo : kOOB;
@@ -196,6 +207,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
     if (n_k0 >= ktiles * BK) {
       n_k0 = 0;
       ++n_tap;
+      if (bankF) {
+        if (++bj == bf) {
+          bj = 0;
+          ++bf;
+        }
+        t_sh = bj - ((bf - 1) - (bf - 1) / 2);
+        t_col = (bf - 1) * K;
+      } else {
+        t_sh = n_tap - pad_l;
+      }
       retap();
     }
   };
@@ -784,7 +805,9 @@ static bool pool_contract(const ConvGemmProblem& p) {
 // the kernel addresses both operands with 32-bit byte offsets against one buffer descriptor each (range 2 GiB)
 static bool dma_contract(const ConvGemmProblem& p) {
   const int64_t lim = (int64_t)1 << 31;
-  return ((int64_t)p.M + p.taps + 1) * p.lda * 4 + (int64_t)p.K * 4 < lim && ((int64_t)p.taps * p.K + 32) * p.ldw * 4 < lim;
+  return ((int64_t)p.M + p.taps + 1) * p.lda * 4 + (int64_t)p.K * 4 < lim && ((int64_t)p.taps * p.K + 32) * p.ldw * 4 < lim &&
+         (p.bank_filters == 0 || (p.taps == p.bank_filters * (p.bank_filters + 1) / 2 && p.K % 32 == 0 &&
+                                  p.pad_l == (p.bank_filters - 1) - (p.bank_filters - 1) / 2 && p.lda >= p.bank_filters * p.K));
 }
 bool conv_gemm2_would_launch(const ConvGemmBatch& batch) {
   const int min_tiles = gemm2_min_tiles();

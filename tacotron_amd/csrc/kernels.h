@@ -29,6 +29,11 @@ struct ConvGemmProblem {
   int atomic_out = 0;  // C += result with fp32 atomics (C pre-zeroed by the caller); several problems may share C
   float scale_mul = 1.f;   // scale[n] is multiplied by this (BN inference: scale = gamma, scale_mul = 1/sqrt(1+eps))
   int it0 = 0, it1 = 0;    // gemm2.hip only: restrict the (tap, 32-deep k-tile) sequence to [it0, it1) (k-split chunk); it1 = 0: all
+  // gemm2.hip only: the conv BANK's input gradient as ONE reduction (ops.py:54-62 backwards): `taps` = F (F + 1) / 2 counts the taps
+  // of all F = bank_filters 'same' convolutions of width f = 1..F in order; global tap g = f (f - 1) / 2 + j reads the rows shifted
+  // by j - ((f - 1) - (f - 1) / 2) from the 128-column block f - 1 of A (A = d bank, lda = F * 128) and the weights W + g * K * ldw
+  // (the transposed kernels of all widths, contiguous).  pad_l must be the largest backward pad, (F - 1) - (F - 1) / 2.
+  int bank_filters = 0;
   // gemm2.hip only: max_pool1d(2, stride 1, 'same') along the sequence in the epilogue (ops.py:64-71).  C[m] receives
   // max(z[m], z[m + 1]) (z[m] alone on the last row of a sequence) of the affine'd activation z; Cpre, if given, the
   // activation before the affine.  m-tiles overlap by one row (stride 127) so every pooled row has its successor in the tile.
@@ -62,6 +67,8 @@ struct GemmTnArgs {
 int launch_conv_gemm_batch(ConvGemmBatch& batch, hipStream_t stream);
 // gemm2.hip: DMA-staged NN kernel for batches that meet the vector contract (flags == 3 on every problem) and have at least
 // TACO_GEMM2_MIN_TILES (default 96) 128 x 128 tiles; returns TACO_ENOTFOUND without launching otherwise.
+int launch_conv_gemm_slab_sum(const ConvGemmProblem& p, const float* slabs, int n, hipStream_t stream);   // C = epilogue(sum of n (M,N) slabs)
+void conv_gemm_set_flags(ConvGemmProblem& p);   // derives the vector-contract bits (flags & 3) and Nld
 int launch_conv_gemm2(ConvGemmBatch& batch, hipStream_t stream, bool force = false);
 // true when launch_conv_gemm2 would take this batch (flags already set): callers that want the pooled epilogue ask first and
 // run conv + bn_maxpool as two launches otherwise

@@ -889,7 +889,51 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
         TACO_TRY(launch_conv_gemm(q, s));
       }
     } else {
-      TACO_TRY(launch_conv_gemm_batch(batch, s));
+      // Default: ONE reduction over the taps of all K widths (ConvGemmProblem::bank_filters), cut into S equal chunks of the
+      // (tap, k-tile) sequence = S x m-tiles workgroups that fill the chip once, equal work each.  Every chunk writes its
+      // partial tile to its own slab (the forward pass's proj1 slabs are free here) and a second pass sums the slabs in
+      // order and adds the residual: no atomics -- 13 M / 8 M of them cost 80 / 35 us of these two launches
+      // (profiles/r04_bank_gather.txt) -- and a deterministic result.  Falls back to the K-problem atomic batch when the
+      // transposed kernels are not contiguous, the slabs do not fit or the DMA kernel does not take the shape
+      // (TACO_NO_BANK_GATHER=1: always).
+      bool contiguous = true;
+      for (int k = 2; k <= c.K; ++k) contiguous = contiguous && t.bank[k - 1] == t.bank[k - 2] + (int64_t)(k - 1) * kCb * c.cin;
+      int rc = TACO_ENOTFOUND;
+      const int64_t mn = (int64_t)M * c.cin;
+      if (contiguous && w.tapsplit && c.cin % 4 == 0 && getenv("TACO_NO_BANK_GATHER") == nullptr) {
+        const int taps = c.K * (c.K + 1) / 2, nit = taps * (kCb / 32);
+        const int mtiles = cdiv(M, 128) * cdiv(c.cin, 128);
+        int64_t S = 512 / mtiles;
+        S = std::min<int64_t>(std::min<int64_t>(S, kMaxGemmBatch), w.tapsplit_floats / mn);
+        if (S >= 2) {
+          const int per = cdiv(nit, (int)S);
+          ConvGemmBatch g;
+          g.n = cdiv(nit, per);
+          for (int ch = 0; ch < g.n; ++ch) {
+            ConvGemmProblem& p = g.p[ch];
+            p = ConvGemmProblem();
+            p.A = dbank; p.lda = KC; p.W = PT + t.bank[0]; p.ldw = c.cin; p.C = w.tapsplit + ch * mn; p.ldc = c.cin; p.M = M;
+            p.N = c.cin; p.K = kCb; p.taps = taps; p.T = T; p.pad_l = (c.K - 1) - (c.K - 1) / 2; p.act = TACO_ACT_NONE;
+            p.bank_filters = c.K;
+            p.it0 = ch * per;
+            p.it1 = std::min(nit, (ch + 1) * per);
+            conv_gemm_set_flags(p);
+          }
+          const int pslot = taco_prof_begin(2, s);
+          taco_prof_label(2, pslot, "nn bank-gather F=%d S=%d M=%d N=%d K=%d taps=%d + slab sum", c.K, g.n, M, c.cin, kCb, taps);
+          rc = launch_conv_gemm2(g, s, /*force=*/true);
+          if (rc == TACO_OK) {
+            ConvGemmProblem fin;
+            fin.M = M; fin.N = c.cin; fin.T = T; fin.C = dx_out; fin.ldc = c.cin; fin.act = TACO_ACT_NONE;
+            fin.residual = dres; fin.ldr = c.c2;   // the residual connection (d res / d x = identity, c2 == cin)
+            fin.atomic_out = 1;                    // dx_out += ...: zeroed above or pre-loaded by the caller with another term
+            rc = launch_conv_gemm_slab_sum(fin, w.tapsplit, g.n, s);
+            taco_prof_end(2, pslot, s, 2.0 * M * c.cin * kCb * taps);
+          }
+        }
+      }
+      if (rc == TACO_ENOTFOUND) rc = launch_conv_gemm_batch(batch, s);
+      TACO_TRY(rc);
     }
   }
   return TACO_OK;
@@ -1031,6 +1075,8 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     scp.dx_zeroed = own_dx;
     g_tn_side = side;
   }
+  pb.tapsplit = ws + W.tapsplit;   // (free in the backward pass: the conv-bank input gradient's partial tiles)
+  pb.tapsplit_floats = W.tapsplit_floats;
   const int rc_post = cbhg_bwd(P, PT, G, PL.post, TL.post, seq2seq_output, dPostOut, B, F, pb, scp, dPostIn, -1, s);
   g_tn_side = nullptr;
   TACO_TRY(rc_post);
@@ -1192,6 +1238,8 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     pre_dz2 = ws + W.pre_dz2; pre_dz1 = ws + W.pre_dz1; pre_demb = ws + W.pre_demb;
     g_tn_side = side_stream().side;
   }
+  eb.tapsplit = ws + W.tapsplit;
+  eb.tapsplit_floats = W.tapsplit_floats;
   int rc_enc = cbhg_bwd(P, PT, G, PL.enc, TL.enc, ws + W.p2, dEnc, B, Tt, eb, sce, dP2, 1, s);
   if (rc_enc != TACO_OK) {
     g_tn_side = nullptr;
