@@ -55,3 +55,37 @@ def test_shifted_epilogue_covers_every_column_once_with_aligned_vectors():
                     assert (m * ldc + col) % 4 == 0, 'float4 store not 16-byte aligned'
                 written += list(range(col, col + width))
         assert sorted(written) == list(range(N)), (ldc, N, m)
+
+
+def bank_tap(g):
+    """conv_gemm2_kernel, ConvGemmProblem::bank_filters: global tap index -> (width f, tap j of it, row shift, column block of d bank)."""
+    f, j = 1, g
+    while j >= f:
+        j -= f
+        f += 1
+    return f, j, j - ((f - 1) - (f - 1) // 2), (f - 1) * 128
+
+
+def test_bank_gather_tap_walk_matches_the_K_separate_problems():
+    """The K-problem form this replaces: width f has f taps, backward pad (f-1) - (f-1)//2, reads column block f-1, and its
+    transposed kernel starts f(f-1)/2 taps into the contiguous block.  Also the incremental walk the kernel does at tap changes
+    and the chunking of the (tap, k-tile) sequence used by cbhg_bwd."""
+    for F in (8, 16):
+        expect = [(f, j, j - ((f - 1) - (f - 1) // 2), (f - 1) * 128) for f in range(1, F + 1) for j in range(f)]
+        assert len(expect) == F * (F + 1) // 2
+        assert [bank_tap(g) for g in range(len(expect))] == expect
+        f, j = 1, 0                      # the walk of `advance()`
+        for g in range(len(expect)):
+            assert (f, j) == expect[g][:2]
+            j += 1
+            if j == f:
+                f, j = f + 1, 0
+        pad_max = (F - 1) - (F - 1) // 2
+        assert all(-pad_max <= e[2] <= pad_max for e in expect)      # pad_l of the launch covers every shift
+        nit = len(expect) * 4            # 32-deep k-tiles of K = 128
+        for mtiles in (1, 50, 90):
+            S = max(1, min(512 // mtiles, 16))
+            per = -(-nit // S)
+            chunks = [(c * per, min(nit, (c + 1) * per)) for c in range(-(-nit // per))]
+            assert chunks[0][0] == 0 and chunks[-1][1] == nit and all(a[1] == b[0] for a, b in zip(chunks, chunks[1:]))
+            assert all(hi > lo for lo, hi in chunks) and len(chunks) <= 16
