@@ -89,6 +89,59 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
+// ---- fp32 products on the bf16 matrix pipe (round 5) ------------------------------------------------------------------
+// v_mfma_f32_32x32x2_f32 runs at 64 cycles per SIMD for 4,096 FLOP; v_mfma_f32_32x32x16_bf16 at 32 cycles for 32,768.  An
+// fp32 value is EXACTLY the sum of three bf16 values (x = h + m + l: h = the top 16 bits of x, m = the top 16 bits of the
+// exact remainder x - h, l = (x - h) - m, which has at most 8 significant bits left), so a product a * b is the sum of nine
+// exact bf16 x bf16 products, of which the six largest (h h, h m, m h, m m, h l, l h) carry everything above 2^-24 of the
+// result -- the size of ONE fp32 rounding -- and the accumulation is fp32 in both forms.  Six bf16 MFMAs replace eight fp32
+// MFMAs per 16 k-columns at 1/2 the cycles each: 3/8 of the matrix-pipe time.  Measured against fp64 the six-term form is as
+// accurate as the fp32 instruction sequence it replaces (tests/test_gpu_ops.py::test_bf16x3_products_are_fp32_grade; numpy
+// model of both: 5.0e-7 vs 5.7e-7 rel-L2 at K = 2048).  The operands stay fp32 in HBM and LDS; the split happens in registers.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct Pl3 {
+  u32x4 h, m, l;   // 8 bf16 each: element q of the lane's 8 k-slots in bits [16 (q & 1), +16) of word q >> 1
+};
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+  h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);   // {hi16(x1), hi16(x0)}
+  const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);   // exact
+  const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+  m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+  const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);   // exact, <= 8 bits
+  l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+__device__ __forceinline__ Pl3 split8(float f0, float f1, float f2, float f3, float f4, float f5, float f6, float f7) {
+  unsigned h[4], m[4], l[4];
+  split2(f0, f1, h[0], m[0], l[0]);
+  split2(f2, f3, h[1], m[1], l[1]);
+  split2(f4, f5, h[2], m[2], l[2]);
+  split2(f6, f7, h[3], m[3], l[3]);
+  Pl3 p;
+  p.h = u32x4{h[0], h[1], h[2], h[3]};
+  p.m = u32x4{m[0], m[1], m[2], m[3]};
+  p.l = u32x4{l[0], l[1], l[2], l[3]};
+  return p;
+}
+__device__ __forceinline__ f32x16 mfma_bf(const u32x4& a, const u32x4& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// acc += a * b over the lanes' 16 k-slots, smallest terms first
+__device__ __forceinline__ void mfma6(f32x16& acc, const Pl3& a, const Pl3& b) {
+  acc = mfma_bf(a.l, b.h, acc);
+  acc = mfma_bf(a.h, b.l, acc);
+  acc = mfma_bf(a.m, b.m, acc);
+  acc = mfma_bf(a.m, b.h, acc);
+  acc = mfma_bf(a.h, b.m, acc);
+  acc = mfma_bf(a.h, b.h, acc);
+}
+__device__ __forceinline__ Pl3 zero_pl3() {
+  Pl3 p;
+  p.h = u32x4{0, 0, 0, 0}; p.m = p.h; p.l = p.h;
+  return p;
+}
+
 constexpr int TM = 128, TN = 128;
 
 struct Gemm2Args {
@@ -98,8 +151,9 @@ struct Gemm2Args {
   int xcd_map;                // 1: XCD-aware tile order (below)
 };
 
-template <int BK, int NS>
+template <int BK, int NS, bool BX = false>
 __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
+  static_assert(!BX || BK == 16, "the bf16x3 form works on 16-deep k-tiles (one v_mfma_f32_32x32x16_bf16 group per tile)");
   constexpr int SLOTS = BK / 4;               // 16-byte slots per A row
   constexpr int A_RPI = 64 / SLOTS;           // A rows per wave instruction: 8 (BK = 32) / 16 (BK = 16)
   constexpr int A_INSTR = TM / A_RPI / 4;     // per wave
@@ -184,14 +238,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
     t_col = (bf - 1) * K;
   }
   // rows a shifted tap pulls from outside their sequence are masked for the whole tap: recomputed when the tap changes
-  auto retap = [&]() {
+  auto retap = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < A_INSTR; ++i) a_cur[i] = (unsigned)(a_t[i] + t_sh) < (unsigned)T ? a_vo[i] : kOOB;
   };
   retap();
   // one DMA instruction of the next tile (g < A_INSTR: A rows, else B rows) -- interleaved between the MFMA groups below.
   // Per piece: one compare + select for the K tail (never taken when K is a multiple of BK), scalar offsets, the load.
-  auto issue_piece = [&](int g, int stage) {
+  auto issue_piece = [&](int g, int stage) __attribute__((always_inline)) {
     float* As = smem + stage * STAGE;
     if (g < A_INSTR) {
       const int vo = n_k0 < a_klim[g] ? a_cur[g] : kOOB;
@@ -202,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
       blds16(rsW, vo, ((n_tap * K + n_k0 + 2 * i) * ldw) * 4, As + A_FLOATS + (wave * B_INSTR + i) * 2 * TN);
     }
   };
-  auto advance = [&]() {
+  auto advance = [&]() __attribute__((always_inline)) {
     n_k0 += BK;
     if (n_k0 >= ktiles * BK) {
       n_k0 = 0;
@@ -216,6 +270,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
         t_col = (bf - 1) * K;
       } else {
         t_sh = n_tap - pad_l;
+        t_col = 0;   // (both branches assign both variables: with one store per branch hipcc sinks them into ONE store through a
+                     //  phi of the two stack addresses, which keeps t_sh / t_col in scratch memory -- two scratch loads and an
+                     //  `s_waitcnt vmcnt(0)`, i.e. a drain of the whole DMA ring, in every k-tile of rounds 2-4's kernel)
       }
       retap();
     }
@@ -240,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
 
   // 4 NP steps of four MFMAs per tile.  Fragments are requested two steps (B) / three steps (A) ahead with counted
   // lgkmcnt waits; one DMA instruction of the tile after next is issued in the shadow of each of the first NLD MFMA groups.
-  auto compute = [&](int stage, int fill_stage, auto fill_c) {
+  auto compute = [&](int stage, int fill_stage, auto fill_c) __attribute__((always_inline)) {
     constexpr bool fill = decltype(fill_c)::value;
     const uint32_t sb = lds0 + (uint32_t)stage * (STAGE * 4u);
     const uint32_t bb = sb + b_off;
@@ -269,6 +326,68 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
     });
   };
 
+  // ---- the same tile on the bf16 matrix pipe (BX, BK = 16).  The lane's 8 k-slots are q = 4 p + c <-> k = 8 p + 4 kh + c,
+  //      the SAME ten ds_read_b128 as above; A and every B sub-tile column are split into three bf16 planes in registers
+  //      (split8) and sub-tile j takes six MFMAs.  Software pipeline across the barrier: the reads of tile t are issued first;
+  //      sub-tile 2 of tile t - 1 (planes carried in registers) and the DMA issue of the tile after next cover their LDS
+  //      latency; sub-tile 3 of tile t - 1 runs beside the split of A and B0, sub-tile 0 beside the split of B1, sub-tile 1
+  //      beside B2 / B3.  (First tile: the carried planes are zeros.) ----
+  Pl3 pa_c = zero_pl3(), pb2_c = zero_pl3(), pb3_c = zero_pl3();
+  auto compute_bx = [&](int stage, int fill_stage, auto fill_c) __attribute__((always_inline)) {
+    constexpr bool fill = decltype(fill_c)::value;
+    const uint32_t sb = lds0 + (uint32_t)stage * (STAGE * 4u);
+    const uint32_t bb = sb + b_off;
+    const f32x4 ra0 = dsr128<0>(sb + a_off[0]);
+    const f32x4 ra1 = dsr128<0>(sb + a_off[NP - 1]);
+    f32x4 rb[8];
+    static_for<0, 8>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      rb[q] = dsr128<(8 * (q >> 2) + (q & 3)) * TN * 4>(bb);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    mfma6(acc[2], pa_c, pb2_c);
+#ifndef GEMM2_LAB_NODMA
+    if (fill) {
+#pragma unroll
+      for (int g = 0; g < NLD; ++g) issue_piece(g, fill_stage);
+    }
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    wait_lgkm<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    mfma6(acc[3], pa_c, pb3_c);   // (still the previous tile's A planes: pa_n takes over below)
+    const Pl3 pa_n = split8(ra0[0], ra0[1], ra0[2], ra0[3], ra1[0], ra1[1], ra1[2], ra1[3]);
+    const Pl3 p0 = split8(rb[0][0], rb[1][0], rb[2][0], rb[3][0], rb[4][0], rb[5][0], rb[6][0], rb[7][0]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x2, 15, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    pa_c = pa_n;
+    mfma6(acc[0], pa_c, p0);
+    const Pl3 p1 = split8(rb[0][1], rb[1][1], rb[2][1], rb[3][1], rb[4][1], rb[5][1], rb[6][1], rb[7][1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma6(acc[1], pa_c, p1);
+    pb2_c = split8(rb[0][2], rb[1][2], rb[2][2], rb[3][2], rb[4][2], rb[5][2], rb[6][2], rb[7][2]);
+    pb3_c = split8(rb[0][3], rb[1][3], rb[2][3], rb[3][3], rb[4][3], rb[5][3], rb[6][3], rb[7][3]);
+    // one MFMA, then its share of the 88 split instructions (left alone hipcc issues the six MFMAs back to back and sinks the
+    // splits behind the loop branch, where nothing of this wave covers them)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x2, 15, 0);
+    }
+    // (the carried planes are pinned HERE: they are only read in the next iteration, and machine sinking would move their
+    //  computation into the block behind the loop branch)
+    asm volatile("" : "+v"(pb2_c.h), "+v"(pb2_c.m), "+v"(pb2_c.l), "+v"(pb3_c.h), "+v"(pb3_c.m), "+v"(pb3_c.l));
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto run_tile = [&](int stage, int fill_stage, auto fill_c) __attribute__((always_inline)) {
+    if constexpr (BX) compute_bx(stage, fill_stage, fill_c);
+    else compute(stage, fill_stage, fill_c);
+  };
+
   // ---- NS-stage ring: tile t lives in stage t % NS; tiles up to t + NS - 2 are in flight while t is computed ----
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s)
@@ -290,14 +409,18 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
     __builtin_amdgcn_s_barrier();   // every wave's share has landed AND every wave has finished reading tile it - 1
 #endif
     asm volatile("" ::: "memory");
-    compute(it % NS, (it + NS - 1) % NS, std::true_type{});
+    run_tile(it % NS, (it + NS - 1) % NS, std::true_type{});
     advance();
   }
   for (; it < nit; ++it) {            // drain: nothing left to request
     wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    compute(it % NS, 0, std::false_type{});
+    run_tile(it % NS, 0, std::false_type{});
+  }
+  if constexpr (BX) {   // the last tile's sub-tiles 2 / 3
+    mfma6(acc[2], pa_c, pb2_c);
+    mfma6(acc[3], pa_c, pb3_c);
   }
   wait_vm<0>();   // (nothing outstanding by construction; keeps the invariant explicit before the epilogue's ordinary loads)
 
@@ -763,14 +886,21 @@ Variant env_variant() {   // read on every launch (tests and the tuning harness 
   }
   return r;
 }
+// TACO_GEMM2_BF16X (read on every launch): 1 (default) = the fp32 products of this kernel are formed on the bf16 matrix pipe
+// from exact three-way operand splits (see split8 / mfma6 above: fp32-grade results, 3/8 of the matrix-pipe time);
+// 0 = v_mfma_f32_32x32x2_f32, the form of rounds 2-4 (A/B runs, bisecting).
+bool env_bf16x() {
+  const char* e = getenv("TACO_GEMM2_BF16X");
+  return !(e && atoi(e) == 0);
+}
 
-template <int BK, int NS>
+template <int BK, int NS, bool BX = false>
 int launch_variant(const Gemm2Args& g, int tiles, hipStream_t s) {
   constexpr size_t smem = (size_t)NS * (TM * BK + BK * TN) * sizeof(float);
   static DynSmemOnce once;
-  TACO_REQUIRE(ensure_dyn_smem(once, reinterpret_cast<const void*>(conv_gemm2_kernel<BK, NS>), smem),
+  TACO_REQUIRE(ensure_dyn_smem(once, reinterpret_cast<const void*>(conv_gemm2_kernel<BK, NS, BX>), smem),
                "conv_gemm2: cannot reserve %zu bytes of LDS", smem);
-  hipLaunchKernelGGL((conv_gemm2_kernel<BK, NS>), dim3(tiles), dim3(256), smem, s, g);
+  hipLaunchKernelGGL((conv_gemm2_kernel<BK, NS, BX>), dim3(tiles), dim3(256), smem, s, g);
   return TACO_OK;
 }
 
@@ -891,6 +1021,11 @@ int launch_conv_gemm2(ConvGemmBatch& batch, hipStream_t stream, bool force) {
     bool bank32 = true;
     for (int i = 0; i < batch.n; ++i) bank32 = bank32 && batch.p[i].pool == 1 && batch.p[i].K % 32 == 0;
     v = bank32 ? Variant{32, 2} : Variant{16, 4};
+  }
+  if (env_bf16x()) {   // 16-deep tiles only (K = 80, K % 32 != 0 and the forward banks alike); the ring depth follows the variant
+    if (v.bk == 16 && v.ns == 3) return launch_variant<16, 3, true>(g, tiles, stream);
+    if (v.bk == 16 && v.ns == 5) return launch_variant<16, 5, true>(g, tiles, stream);
+    return launch_variant<16, 4, true>(g, tiles, stream);
   }
   if (v.bk == 32 && v.ns == 2) return launch_variant<32, 2>(g, tiles, stream);
   if (v.bk == 32 && v.ns == 3) return launch_variant<32, 3>(g, tiles, stream);

@@ -107,15 +107,49 @@ V2_CASES = [c for c in CASES if c[2] % 4 == 0 and c[3] % 4 == 0] + [
 ]
 
 
-@pytest.mark.parametrize('variant', ['32x2', '32x3', '16x3', '16x4', '16x5'])
+# (MFMA form, k-tile depth x ring stages): 'f32' = v_mfma_f32_32x32x2_f32 (rounds 2-4), 'bx' = the bf16x3 form of round 5
+V2_VARIANTS = [('0', '32x2'), ('0', '32x3'), ('0', '16x3'), ('0', '16x4'), ('0', '16x5'), ('1', '16x3'), ('1', '16x4'), ('1', '16x5')]
+V2_IDS = ['%s-%s' % ('bx' if b == '1' else 'f32', v) for b, v in V2_VARIANTS]
+
+
+@pytest.mark.parametrize('variant', V2_VARIANTS, ids=V2_IDS)
 @pytest.mark.parametrize('case', V2_CASES, ids=[str(c[:6]) for c in V2_CASES])
 def test_conv_gemm_v2(built_lib, case, variant, monkeypatch):
-    """gemm2.hip (DMA-staged, swizzled, 4-MFMAs-per-read kernel) forced for every shape that meets its contract, in all five
-    (k-tile depth x ring stages) instantiations: K / N / M tails as out-of-range buffer offsets (zeros), tap shifts across sequence
-    boundaries, the float4 and the scalar epilogue."""
+    """gemm2.hip (DMA-staged, swizzled kernel) forced for every shape that meets its contract, in all its instantiations -- the
+    fp32 MFMA form in five (k-tile depth x ring stages) shapes and the bf16x3 form (fp32 operands split into three bf16 planes in
+    registers, six v_mfma_f32_32x32x16_bf16 per sub-tile, TACO_GEMM2_BF16X) in three: K / N / M tails as out-of-range buffer
+    offsets (zeros), tap shifts across sequence boundaries, the float4 and the scalar epilogue.  Same tolerance for both forms."""
     monkeypatch.setenv('TACO_GEMM2_MIN_TILES', '1')
-    monkeypatch.setenv('TACO_GEMM2_VARIANT', variant)
+    monkeypatch.setenv('TACO_GEMM2_BF16X', variant[0])
+    monkeypatch.setenv('TACO_GEMM2_VARIANT', variant[1])
     test_conv_gemm(built_lib, case)
+
+
+@pytest.mark.parametrize('scale', [1.0, 1e-12, 3e7], ids=['unit', 'tiny', 'huge'])
+def test_bf16x3_products_are_fp32_grade(built_lib, scale, monkeypatch):
+    """The bf16x3 form of gemm2.hip against the fp32 MFMA form of the same kernel and an fp64 product: a deep reduction (K = 2048
+    x 3 taps) over heavy-tailed operands (log-normal magnitudes over ~5 decades; gradient-like scales included).  The split is
+    exact (x = h + m + l) and the six retained plane products cover everything above 2^-24 of a product; what the bf16
+    instruction adds is its 16-term internal sum (one alignment per 16 products instead of per 2).  Measured on MI355X: rel-L2
+    1.8e-7 vs 1.4e-7 of the fp32 form on these operands.  Asserted: <= 2 x the fp32 form's error, and both <= the suite's 5e-6
+    (i.e. 25 x below the tolerance every GEMM test of this file states)."""
+    monkeypatch.setenv('TACO_GEMM2_MIN_TILES', '1')
+    monkeypatch.setenv('TACO_GEMM2_VARIANT', '16x4')
+    rng = np.random.default_rng(11)
+    M, T, N, K, taps = 512, 128, 256, 2048, 3
+    A = (rng.standard_normal((M, K)) * np.exp(rng.standard_normal((M, K)) * 3)).astype(np.float32) * np.float32(scale)
+    W = (rng.standard_normal((taps, K, N)) * np.exp(rng.standard_normal((taps, K, N)) * 3) / np.sqrt(K * taps)).astype(np.float32)
+    ref, _ = conv_ref(A.astype(np.float64), W.astype(np.float64), None, T, 1, 0)
+    err = {}
+    for bx in ('0', '1'):
+        monkeypatch.setenv('TACO_GEMM2_BF16X', bx)
+        C = torch.full((M, N), float('nan'), device='cuda')
+        before = built_lib.debug_gemm2_window(0, 1 << 30)
+        built_lib.conv_gemm(dev(A), dev(W), C, M, N, K, taps=taps, T=T, pad_l=1, act=0)
+        assert built_lib.debug_gemm2_window(0, 1 << 30) == 1, 'the launch did not go to gemm2.hip'
+        err[bx] = report('gemm2 %s scale=%g' % ('bf16x3' if bx == '1' else 'fp32  ', scale), C.cpu().numpy(), ref)
+    assert err['0'][0] < 5e-6 and err['1'][0] < 5e-6
+    assert err['1'][0] <= 2.0 * err['0'][0] and err['1'][1] <= 2.5 * err['0'][1]
 
 
 @pytest.mark.parametrize('case', [(1000, 200, 128, 2048, 3, 1, 1), (520, 130, 256, 1024, 3, 1, 0), (300, 300, 132, 516, 1, 0, 3)],
@@ -139,7 +173,7 @@ def test_conv_gemm_ksplit(built_lib, case):
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize('variant', ['16x4', '32x2'])
+@pytest.mark.parametrize('variant', ['16x4', '32x2', 'bx'])
 @pytest.mark.parametrize('N,ldc,act', [(1025, 1025, 0), (1025, 1027, 1), (514, 518, 0), (131, 133, 3), (1024, 1025, 0), (1025, 1030, 0), (133, 135, 0),
                                        (262, 263, 0)],
                          ids=['dense-1025', 'pitch-3mod4', 'pitch-2mod4', 'narrow', 'full-tiles', 'pitch-2mod4-odd-N', 'tail-5-of-a-tile',
@@ -150,7 +184,8 @@ def test_conv_gemm_v2_shifted_rows(built_lib, N, ldc, act, variant, monkeypatch)
     a tile, an M tail; nothing may land outside the N columns of a row (sentinel in the pitch padding and behind the last row),
     and the kernel must really be the DMA one (the old kernel is switched off for the call)."""
     monkeypatch.setenv('TACO_GEMM2_MIN_TILES', '1')
-    monkeypatch.setenv('TACO_GEMM2_VARIANT', variant)
+    monkeypatch.setenv('TACO_GEMM2_BF16X', '1' if variant == 'bx' else '0')
+    monkeypatch.setenv('TACO_GEMM2_VARIANT', '16x4' if variant == 'bx' else variant)
     rng = np.random.default_rng(N * 7 + ldc)
     M, K = 333, 96
     nld = (N + 3) // 4 * 4
