@@ -11,6 +11,7 @@
 // scalar fallback for unaligned leading dimensions (e.g. 1025-wide linear frames).
 #include <algorithm>
 
+#include "bf16x3.h"
 #include "common.h"
 #include "kernels.h"
 
@@ -281,7 +282,10 @@ __global__ void conv_gemm_tapsum_kernel(ConvGemmProblem P, const float* __restri
 }
 
 // dW[z][tap][k][n] += sum_m A[z][row(m,tap)][k] * dY[z][m][n]; reduction over m split across blockIdx.z slices.
-template <int WM, int WN, bool VA, bool VB>
+// BX: the products on the bf16 matrix pipe (bf16x3.h): the lane's 8 row slots of a 16-row tile are m = 2 q + lk, the same sixteen
+// ds_read_b32 per operand sub-tile as the fp32 form; every operand sub-tile is split into three bf16 planes in registers and a
+// 32 x 32 output sub-tile takes six v_mfma_f32_32x32x16_bf16 per tile instead of eight v_mfma_f32_32x32x2_f32.
+template <int WM, int WN, bool VA, bool VB, bool BX = false>
 __device__ __forceinline__ void gemm_tn_body(const GemmTnArgs& P, const int bx, const int by, const int bz_) {
   constexpr int BM = 64 * WM, BN = 64 * WN;   // BM tiles the k (output row) dimension
   constexpr int LDS_A = BM + 4, LDS_B = BN + 4;
@@ -418,6 +422,31 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTnArgs& P, const int bx, 
   for (int it = 0; it < nit; ++it) {
     const int buf = it & 1;
     if (it + 1 < nit) load_tile(it + 1);
+    if constexpr (BX) {
+      static_assert(BK == 16, "one v_mfma_f32_32x32x16_bf16 group per 16-row tile");
+      Pl3 pa[WM], pb[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        float f[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) f[q] = As[buf][2 * q + lk][wm * (32 * WM) + i * 32 + li];
+        pa[i] = split8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+      }
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        float f[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) f[q] = Bs[buf][2 * q + lk][wn * (32 * WN) + j * 32 + li];
+        pb[j] = split8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+      }
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) mfma6(acc[i][j], pa[i], pb[j]);
+      if (it + 1 < nit) store_tile(buf ^ 1);
+      __syncthreads();
+      continue;
+    }
     // LDS operands are fetched one k-pair ahead of the MFMAs that consume them
     float a[2][WM], b[2][WN];
 #pragma unroll
@@ -476,13 +505,14 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTnArgs& P, const int bx, 
   }
 }
 
-template <int WM, int WN, bool VA, bool VB>
+template <int WM, int WN, bool VA, bool VB, bool BX = false>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs P) {
-  gemm_tn_body<WM, WN, VA, VB>(P, blockIdx.x, blockIdx.y, blockIdx.z);
+  gemm_tn_body<WM, WN, VA, VB, BX>(P, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Grouped launch: independent weight-gradient GEMMs (all 64x64 tiles, vector contract) share ONE grid; block -> problem
 // by a prefix table of block counts, so ~20 launch-latency-sized GEMMs run concurrently instead of back to back.
+template <bool BX>
 __global__ __launch_bounds__(256) void gemm_tn_batch_kernel(GemmTnBatch B) {
   int pi = 0;
   for (int i = 1; i < B.n; ++i)
@@ -493,7 +523,7 @@ __global__ __launch_bounds__(256) void gemm_tn_batch_kernel(GemmTnBatch B) {
   const int bz = rel / (gx * gy);
   rel -= bz * gx * gy;
   const int by = rel / gx, bx = rel - by * gx;
-  gemm_tn_body<1, 1, true, true>(P, bx, by, bz);
+  gemm_tn_body<1, 1, true, true, BX>(P, bx, by, bz);
 }
 
 __global__ void gemm_naive_kernel(ConvGemmProblem P) {
@@ -692,7 +722,10 @@ int launch_conv_gemm(const ConvGemmProblem& p, hipStream_t stream) {
 template <int WM, int WN>
 static void dispatch_tn(int flags, dim3 grid, hipStream_t s, const GemmTnArgs& a) {
   switch (flags & 3) {
-    case 3: hipLaunchKernelGGL((gemm_tn_kernel<WM, WN, true, true>), grid, dim3(256), 0, s, a); break;
+    case 3:
+      if (env_bf16x()) hipLaunchKernelGGL((gemm_tn_kernel<WM, WN, true, true, true>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((gemm_tn_kernel<WM, WN, true, true>), grid, dim3(256), 0, s, a);
+      break;
     case 1: hipLaunchKernelGGL((gemm_tn_kernel<WM, WN, true, false>), grid, dim3(256), 0, s, a); break;
     case 2: hipLaunchKernelGGL((gemm_tn_kernel<WM, WN, false, true>), grid, dim3(256), 0, s, a); break;
     default: hipLaunchKernelGGL((gemm_tn_kernel<WM, WN, false, false>), grid, dim3(256), 0, s, a); break;
@@ -723,7 +756,12 @@ static int plan_gemm_tn(GemmTnArgs& a, bool force_small, dim3& grid, int64_t gro
   if (a.ldy % 4 == 0 && aligned16(a.Y) && a.strideY % 4 == 0 && a.Nld > 0 && a.Nld % 4 == 0 && a.Nld <= a.ldy &&
       ((int64_t)a.M + 16) * a.ldy * 4 < lim31)
     a.flags |= 2;
-  const bool big = !force_small && (int64_t)cdiv(a.K, 128) * cdiv(a.N, 128) * a.taps * a.batch >= 128 && a.K >= 128 && a.N >= 128;
+  // TACO_TN_BM=64|128 forces the tile (tuning harness); TACO_TN_BIG_TILES = least number of 128 x 128 tiles for the big tile
+  static const int force_bm = [] { const char* e = getenv("TACO_TN_BM"); return e ? atoi(e) : 0; }();
+  static const int big_tiles = [] { const char* e = getenv("TACO_TN_BIG_TILES"); return e ? atoi(e) : 128; }();
+  bool big = !force_small && (int64_t)cdiv(a.K, 128) * cdiv(a.N, 128) * a.taps * a.batch >= big_tiles && a.K >= 128 && a.N >= 128;
+  if (!force_small && force_bm == 128 && a.K >= 128 && a.N >= 128) big = true;
+  if (force_bm == 64) big = false;
   const int bm = big ? 128 : 64;
   const int64_t tiles = (int64_t)cdiv(a.K, bm) * cdiv(a.N, bm) * a.taps * a.batch;
   const int64_t fill = group_tiles > tiles ? group_tiles : tiles;
@@ -830,7 +868,8 @@ int launch_gemm_tn_batch(GemmTnBatch& b, hipStream_t stream) {
     const int pslot = taco_prof_begin(2, stream);
     taco_prof_label(2, pslot, "tn-batch n=%d blocks=%d first: M=%d N=%d K=%d taps=%d", grouped.n, blocks, grouped.p[0].M, grouped.p[0].N, grouped.p[0].K,
                     grouped.p[0].taps);
-    hipLaunchKernelGGL(gemm_tn_batch_kernel, dim3(blocks), dim3(256), 0, stream, grouped);
+    if (env_bf16x()) hipLaunchKernelGGL(gemm_tn_batch_kernel<true>, dim3(blocks), dim3(256), 0, stream, grouped);
+    else hipLaunchKernelGGL(gemm_tn_batch_kernel<false>, dim3(blocks), dim3(256), 0, stream, grouped);
     taco_prof_end(2, pslot, stream, flops);
     TACO_LAUNCH_CHECK("gemm_tn_batch");
   }
