@@ -16,6 +16,9 @@ Extra objects on the JSON line:
   rooflines    -- the same per family: dominant kernel, MFMA GEMM family (events around every launch, separate untimed
                   pass), whole step (SURVEY 8d FLOPs / ms_per_step), bi-GRU recurrences, inference B=1.
   s2 / vctk    -- the S2 envelope (Td=500 = 1000 mel frames) and the 109-speaker configuration, same step, 1 GPU.
+  box / ab     -- `box`: what this box's fabric measures (granule hop latency same-XCD / cross-XCD, L2-hit and all-miss load latency,
+                  one CU's stream bandwidth, latency-bound shader clock); `ab`: same-box, same-run A/B of the big-GEMM arithmetic
+                  (bf16x3 vs fp32 MFMA) and of the decoder build (product vs previous form, libtaco_prevdec.so).
   cpu_baseline -- the CPU restatement (oracle/taco_torch.py, fp32, torch-CPU GEMMs; NOT TensorFlow -- TF 1.2 cannot
                   be installed) timed on this box's host cores on the same workload, rank 0, N=1 only.
 """
@@ -169,6 +172,63 @@ def fp32_gemm_4096():
     return ours, blas
 
 
+def ab_gemm(model, rounds=3, steps=8):
+    """In-run A/B of the big-GEMM arithmetic: the bf16x3 form (three-way exact operand split on the bf16 matrix
+    pipe, the default) against the fp32 MFMA form of rounds 2-4, alternated `rounds` times in THIS process on THIS box -- the switch
+    is read at every launch (TACO_GEMM2_BF16X)."""
+    out = {'bf16x3': [], 'fp32_mfma': []}
+    prev = os.environ.get('TACO_GEMM2_BF16X')
+    try:
+        for _ in range(rounds):
+            for name, v in (('bf16x3', '1'), ('fp32_mfma', '0')):
+                os.environ['TACO_GEMM2_BF16X'] = v
+                for _ in range(2):
+                    model.step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    model.step()
+                torch.cuda.synchronize()
+                out[name].append((time.perf_counter() - t0) / steps * 1e3)
+    finally:
+        if prev is None:
+            os.environ.pop('TACO_GEMM2_BF16X', None)
+        else:
+            os.environ['TACO_GEMM2_BF16X'] = prev
+    med = lambda x: sorted(x)[len(x) // 2]   # noqa: E731
+    return {'what': 'S1 train step, ms: big GEMMs on the bf16x3 form (default) vs the fp32 MFMA form of rounds 2-4, alternated in this run',
+            'ms_per_step': {k: [round(x, 3) for x in v] for k, v in out.items()},
+            'median_ms': {k: med(v) for k, v in out.items()}, 'gain_ms': med(out['fp32_mfma']) - med(out['bf16x3'])}
+
+
+def ab_decoder(rounds=3):
+    """In-run A/B of decoder builds: the product library against libtaco_prevdec.so (the same sources with the previous decoder
+    form: -DTACO_NO_RS -DTACO_NO_POLL128 -DTACO_NO_SHADOW -DTACO_NO_GROUPED_FANDQ), alternated `rounds` times on this box
+    (one short subprocess each: tools/dec_quick.py --json, S1 shape)."""
+    import subprocess
+    libs = {'current': os.path.join(ROOT, 'tacotron_amd', 'libtaco_hip.so'), 'previous_form': os.path.join(ROOT, 'tacotron_amd', 'libtaco_prevdec.so')}
+    if not all(os.path.exists(p) for p in libs.values()):
+        return None
+    runs = {k: [] for k in libs}
+    for _ in range(rounds):
+        for k, path in libs.items():
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'dec_quick.py'), '--time-only', '--json'],
+                                   env=dict(os.environ, TACO_LIB=path), capture_output=True, text=True, timeout=120)
+                line = [x for x in r.stdout.splitlines() if x.startswith('{')]
+                if line:
+                    runs[k].append(json.loads(line[-1]))
+            except Exception:   # noqa: BLE001 -- a diagnostic, never fatal for the bench line
+                pass
+    if not all(runs.values()):
+        return None
+    med = lambda k, f: sorted(x[f] for x in runs[k])[len(runs[k]) // 2]   # noqa: E731
+    return {'what': 'S1 train step: product build vs the previous decoder form (round 3 column sums / 8-byte polls / no poll-shadow '
+                    'work), %d alternations on this box' % rounds,
+            **{k: {'ms_per_step': med(k, 'ms_per_step'), 'us_per_decoder_step_fwd': med(k, 'us_per_decoder_step_fwd'),
+                   'us_per_decoder_step_bwd': med(k, 'us_per_decoder_step_bwd'), 'runs': len(runs[k])} for k in libs}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -239,9 +299,10 @@ def main():
     elif reducer is not None:
         for _ in range(3):
             model.step()   # (collectives need every rank)
-    fam = None
+    fam = ab = None
     if rank == 0 and world == 1 and not args.no_extras:
         fam = family_profile(model)
+        ab = {'gemm': ab_gemm(model)}
     del model
     torch.cuda.empty_cache()
 
@@ -376,8 +437,13 @@ def main():
             'final_loss': loss, 'build': source_hash(),
             # which box this was: the latency-bound kernels (decoder, bi-GRU: 58 % of the step) scale with the shader clock the chip
             # sustains, and boxes of one pool differ by ~10 % (round 4: the same build ran 8.86 and 9.30 ms per step)
-            'box': {'shader_clock_ghz_latency_bound': lib.clock_probe()},
+            'box': dict({'shader_clock_ghz_latency_bound': lib.clock_probe()}, **(lib.fabric_probe() if world == 1 else {})),
         }
+        if ab is not None:
+            dec_ab = ab_decoder()
+            if dec_ab:
+                ab['decoder'] = dec_ab
+            res['ab'] = ab
         if allreduce:
             res['allreduce'] = allreduce
         if s2:

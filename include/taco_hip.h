@@ -23,7 +23,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default)
 
-#define TACO_VERSION 115
+#define TACO_VERSION 116
 
 #define TACO_OK 0
 #define TACO_EINVAL (-1)   /* bad argument / unsupported shape   */
@@ -191,6 +191,15 @@ int taco_debug_spin(int blocks, int threads, int lds_bytes, int usec, void* stre
  * the clock the chip sustains under a chip-wide latency-bound load, which is what the persistent decoder / bi-GRU kernels scale
  * with (boxes of one pool were measured ~10 % apart on those kernels). */
 int taco_debug_clock_probe(long long* out3, int iters, void* stream);
+
+/* Fabric probe: the latencies the persistent decoder / bi-GRU kernels wait on, measured on the box at hand (bench.py `box`).
+ * One launch of 64 small workgroups; out32 (device int64[32], zeroed by the caller) receives, in ticks of the 100 MHz counter,
+ * the total of `iters` round trips of a granule ping-pong between two workgroups of ONE XCD with workgroup-scope stores [0]
+ * (decoder3.hip's exchange) and agent-scope stores [1], between two XCDs [2] (decoder.hip's exchange), of `iters` dependent loads
+ * that hit the L2 [3] / that miss every cache (walk over the whole scratch buffer, which should exceed 256 MB) [4], and the time
+ * one workgroup needs to stream 8 MB [5]; [6] = iters, [7] = ok bits, [8 + b] = XCC id of workgroup b < 24.
+ * gran4k: 4 KiB of zeroed device memory; scratch: zeroed device memory, scratch_bytes >= 32 MiB.  No counterpart in the reference. */
+int taco_debug_fabric_probe(long long* out32, void* gran4k, const void* scratch, long long scratch_bytes, int iters, void* stream);
 
 /* ---- spectrogram boundary ---------------------------------------------------------------------------- */
 /* test.py:64 `out * stft_std + stft_mean` followed by audio.reshape_frames(forward=False) (audio.py:29-35), on the device.

@@ -163,10 +163,11 @@ __global__ __launch_bounds__(NTG, 1) void bigru_fwd_kernel(const float* __restri
     }
     GRU_STAMP(4);   // [4] r*h reads, update-gate and candidate products issued
     const float cpre = quad_sum(hsum(p0 + p1)) + xrow[2 * H + cp];
-    // every wave's share of the next chunk has had CH-1 steps to land; younger than its loads are the stores of CH-1 steps
-    if (i == CH - 1) {
-      if (ruc) wait_vm_older_than<4 * (CH - 1)>(); else wait_vm_older_than<CH - 1>();
-    }
+    // every wave's share of the next chunk has had CH-1 steps to land.  A full vmcnt(0): round 4 waited with a COUNT of the stores
+    // younger than the chunk's loads (4 or 1 per step), which measured no faster (profiles/r04_gru_lab.txt) and silently depends
+    // on how many store instructions the compiler emits per step -- one merged or dropped store and the next chunk
+    // would be read before it lands.
+    if (i == CH - 1) wait_vm_older_than<0>();
     // sigmoid(u) and tanh(c) share one exp/rcp sequence: lane 1 of the quad takes u, the others c
     //   sigmoid(x) = 0 + 1 * rcp(1 + exp2(-log2e * x));   tanh(x) = 1 - 2 * rcp(1 + exp2(2 log2e * x))     (sigmoid_fast / tanh_fast)
     const float act = fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(act_g * (kq == 1 ? upre : cpre))), act_b, act_a);
@@ -316,8 +317,8 @@ __global__ __launch_bounds__(NTG, 1) void bigru_bwd_kernel(const float* __restri
       q1 = pk_fma(f2{gv[i4].z, gv[i4].w}, wgr_r[2 * i4 + 1], q1);
     }
     dh = dht * u + drh * r + quad_sum(hsum(q0 + q1));
-    if (i == CH - 1) {   // chunk boundary: the next chunk has landed (younger than its loads: 4 stores per step) and is published
-      wait_vm_older_than<4 * CH>();
+    if (i == CH - 1) {   // chunk boundary: the next chunk has landed (vmcnt(0), not a store count: see the forward kernel) and is published
+      wait_vm_older_than<0>();
       lds_barrier();
     }
   }

@@ -794,6 +794,104 @@ int launch_clock_probe(long long* out, int iters, hipStream_t s) {
   return TACO_OK;
 }
 
+// ---- fabric probe (taco_debug_fabric_probe): what the latency-bound kernels of this library actually wait on, measured on THIS
+//      box (the shader clock does not tell a 12.4 us BPTT box from a 14.0 us one).  One launch, 64 workgroups of 64
+//      threads (workgroup b runs on XCD b % 8 with the dispatcher's round-robin; the XCC ids are recorded, not assumed):
+//        blocks 0 <-> 8   ping-pong through an 8-byte {epoch, value} granule in decoder3's fast form: workgroup-scope store
+//                         (stays in the XCD's L2) + agent-scope load (bypasses L1)                     -> out[0] ticks / hop pair
+//        blocks 1 <-> 9   the same with agent-scope stores (written through; decoder3's fallback form) -> out[1]
+//        blocks 2 <-> 3   agent scope, two DIFFERENT XCDs (decoder.hip's exchange)                     -> out[2]
+//        block  20        a chain of dependent loads over a warm 64 KB region (L2 hits)                 -> out[3]
+//        block  21        a chain of dependent loads over the whole scratch buffer (>= 512 MB: beyond the 256 MB Infinity
+//                         Cache, i.e. HBM round trips as the stash / prefetch traffic of the BPTT kernel pays them) -> out[4]
+//        block  22        64 lanes streaming 8 MB of the scratch buffer with 16-byte loads (one CU's stream bandwidth) -> out[5]
+//      Ticks are the constant 100 MHz counter; out[8 + b] = XCC id of block b (b < 24); out[6] = iterations, out[7] = ok flags.
+typedef unsigned long long fp_u64;
+typedef __attribute__((address_space(1))) fp_u64 fp_gu64;
+template <int LSCOPE, int SSCOPE>
+__device__ __forceinline__ long long fabric_pingpong(fp_u64* mine, fp_u64* theirs, bool first, int iters, bool* ok_out) {
+  bool ok = true;
+  const long long t0 = wall_clock64();
+  for (int i = 1; i <= iters && ok; ++i) {
+    if (first) __hip_atomic_store((fp_gu64*)mine, ((fp_u64)i << 32) | (fp_u64)i, __ATOMIC_RELAXED, SSCOPE);
+    ok = false;
+    for (unsigned spin = 0; spin < (1u << 20); ++spin) {
+      const fp_u64 x = __hip_atomic_load((fp_gu64*)theirs, __ATOMIC_RELAXED, LSCOPE);
+      if ((unsigned)(x >> 32) == (unsigned)i) { ok = true; break; }
+    }
+    if (!first) __hip_atomic_store((fp_gu64*)mine, ((fp_u64)i << 32) | (fp_u64)i, __ATOMIC_RELAXED, SSCOPE);
+  }
+  *ok_out = ok;
+  return wall_clock64() - t0;
+}
+__global__ __launch_bounds__(64) void fabric_probe_kernel(long long* out, fp_u64* gran, const unsigned* scratch, long long scratch_words, int iters) {
+  const int b = blockIdx.x;
+  if (threadIdx.x == 0 && b < 24) {
+    unsigned id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+    out[8 + b] = id & 0xf;
+  }
+  if (b == 22) {   // one CU streaming: 8 MB, 16 bytes per lane and load, 8 loads in flight per lane
+    typedef unsigned fp_u32x4 __attribute__((ext_vector_type(4)));
+    const fp_u32x4* src = reinterpret_cast<const fp_u32x4*>(scratch);
+    const long long n16 = (8ll << 20) / 16;
+    unsigned acc = 0;
+    const long long t0 = wall_clock64();
+    for (long long i = threadIdx.x; i + 7 * 64 < n16; i += 8 * 64) {
+      fp_u32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(src + i + j * 64);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += v[j][0] ^ v[j][3];
+    }
+    const long long t1 = wall_clock64();
+    if (threadIdx.x == 0) out[5] = t1 - t0;
+    if (acc == 0x12345678u) out[7] |= 1ll << 40;
+    return;
+  }
+  if (threadIdx.x != 0) return;
+  bool ok = true;
+  if (b == 0 || b == 8) {
+    const long long t = fabric_pingpong<__HIP_MEMORY_SCOPE_AGENT, __HIP_MEMORY_SCOPE_WORKGROUP>(gran + (b == 0 ? 0 : 64), gran + (b == 0 ? 64 : 0), b == 0, iters, &ok);
+    if (b == 0) { out[0] = t; if (ok) atomicOr((unsigned long long*)&out[7], 1ull); }
+  } else if (b == 1 || b == 9) {
+    const long long t = fabric_pingpong<__HIP_MEMORY_SCOPE_AGENT, __HIP_MEMORY_SCOPE_AGENT>(gran + (b == 1 ? 128 : 192), gran + (b == 1 ? 192 : 128), b == 1, iters, &ok);
+    if (b == 1) { out[1] = t; if (ok) atomicOr((unsigned long long*)&out[7], 2ull); }
+  } else if (b == 2 || b == 3) {
+    const long long t = fabric_pingpong<__HIP_MEMORY_SCOPE_AGENT, __HIP_MEMORY_SCOPE_AGENT>(gran + (b == 2 ? 256 : 320), gran + (b == 2 ? 320 : 256), b == 2, iters, &ok);
+    if (b == 2) { out[2] = t; if (ok) atomicOr((unsigned long long*)&out[7], 4ull); }
+  } else if (b == 20 || b == 21) {
+    // dependent loads: the next index is a multiplicative walk over the region PLUS the loaded word (the buffer holds zeros, which
+    // the compiler cannot know), 32 words = one 128-byte line apart.  The L2-hit walk covers 64 KB and touches every line once
+    // before the clock starts; the loads are agent scope (they bypass the L1, as every poll of the decoder kernels does)
+    const long long lines = (b == 20 ? (64ll << 10) : scratch_words * 4) / 128;
+    unsigned long long idx = 1;
+    if (b == 20) {
+      unsigned w = 0;
+      for (long long l = 0; l < lines; ++l)
+        w += __hip_atomic_load((const __attribute__((address_space(1))) unsigned*)(scratch + (16ll << 20) / 4 + l * 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      idx += w;
+    }
+    const unsigned* base = b == 20 ? scratch + (16ll << 20) / 4 : scratch;   // (the streaming block reads the first 8 MB)
+    const long long t0 = wall_clock64();
+    for (int i = 0; i < iters; ++i) {
+      const unsigned v = __hip_atomic_load((const __attribute__((address_space(1))) unsigned*)(base + idx * 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      idx = (idx * 2654435761ull + 12345ull + v) % (unsigned long long)lines;
+    }
+    const long long t1 = wall_clock64();
+    out[b == 20 ? 3 : 4] = t1 - t0;
+    if (idx == 0xfffffffffull) out[7] |= 1ll << 41;
+  }
+  if (b == 0) out[6] = iters;
+}
+int launch_fabric_probe(long long* out32, void* gran4k, const void* scratch, int64_t scratch_bytes, int iters, hipStream_t s) {
+  TACO_REQUIRE(out32 && gran4k && scratch && scratch_bytes >= (32 << 20) && iters > 0, "fabric_probe: bad arguments");
+  hipLaunchKernelGGL(fabric_probe_kernel, dim3(64), dim3(64), 0, s, out32, reinterpret_cast<fp_u64*>(gran4k),
+                     reinterpret_cast<const unsigned*>(scratch), (long long)(scratch_bytes / 4), iters);
+  TACO_LAUNCH_CHECK("fabric_probe");
+  return TACO_OK;
+}
+
 // ---- batched zero-fill / copy (InitBatch, kernels.h) ----
 __global__ __launch_bounds__(256) void init_batch_kernel(InitBatch b) {
   int ji = 0;

@@ -188,6 +188,7 @@ int launch_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, fl
 int launch_bernoulli(uint8_t* out, int64_t n, float p_one, uint64_t seed, hipStream_t s);
 int launch_spin(int blocks, int threads, int lds_bytes, int usec, hipStream_t s);
 int launch_clock_probe(long long* out, int iters, hipStream_t s);   // out[0] = shader cycles, out[1] = 100 MHz ticks of `iters` dependent FMAs
+int launch_fabric_probe(long long* out32, void* gran4k, const void* scratch, int64_t scratch_bytes, int iters, hipStream_t s);
 // Batched buffer initialisation: up to kMaxInitJobs zero-fills / (strided) copies of fp32 blocks in ONE launch instead of one
 // runtime memset / memcpy launch each (~5 us apiece, serialised on their stream).  Jobs of a batch must not overlap.
 constexpr int kMaxInitJobs = 16;

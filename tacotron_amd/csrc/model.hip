@@ -1427,6 +1427,10 @@ extern "C" int taco_debug_clock_probe(long long* out3, int iters, void* stream) 
   return launch_clock_probe(out3, iters, as_stream(stream));
 }
 
+extern "C" int taco_debug_fabric_probe(long long* out32, void* gran4k, const void* scratch, long long scratch_bytes, int iters, void* stream) {
+  return launch_fabric_probe(out32, gran4k, scratch, scratch_bytes, iters, as_stream(stream));
+}
+
 extern "C" int taco_profile_enable(int mask) {
   g_prof_mask = mask & 31;
   return TACO_OK;

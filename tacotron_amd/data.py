@@ -29,6 +29,112 @@ def synthetic_batch(B=32, Tt=200, Td=180, r=2, V=60, seed=1234, rank=0, min_len=
     return out
 
 
+def synthetic_corpus(n=256, Tt=200, Td=180, r=2, V=60, seed=1234, rank=0, num_speakers=1):
+    """A pool of `n` synthetic utterances with the statistics of synthetic_batch, generated ONCE: the stand-in for
+    the preprocessed npy corpus (data_input.py:43-85) when none is on disk.  Minibatches are index draws from the pool, as
+    the reference's `slice_input_producer(shuffle=True)` draws from its arrays -- generating 51 MB of normal deviates per step
+    on the host (synthetic_batch, ~150 ms) would be 18 x the 8.4 ms train step."""
+    b = synthetic_batch(n, Tt, Td, r, V, seed=seed, rank=rank, num_speakers=num_speakers)
+    b.pop('speech_length')
+    return b
+
+
+class DeviceFeeder:
+    """Feeds a train loop whose step is shorter than one pageable host-to-device copy of its batch (51 MB at the Nancy shape:
+    ~20 ms pageable, ~2 ms pinned): the replacement for the reference's queue runners (train.py:44-45, data_input.py:67-72).
+
+    A worker thread draws the indices of batch s + depth, gathers the rows into PINNED staging buffers (torch.index_select:
+    multi-threaded, releases the GIL) and enqueues the copy into one of depth + 1 device buffer sets on a copy stream; `next()`
+    makes the caller's stream wait for that copy's event (no host block) and hands out the device tensors -- `Tacotron.set_inputs`
+    on them is a pointer swap.  A buffer set is overwritten only after the consumer's stream has passed the event recorded by the
+    `next()` call that retired it.  With device='cpu' (tests) the same rotation runs synchronously without pinning."""
+
+    def __init__(self, data, batch_size, device='cuda', depth=2, seed=1000, draw=None):
+        import queue
+        import threading
+        self.data = {k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v))) for k, v in data.items()}
+        self.n = len(next(iter(self.data.values())))
+        self.B, self.depth = int(batch_size), int(depth)
+        self.device = torch.device(device)
+        self.cuda = self.device.type == 'cuda'
+        self._rng = np.random.default_rng(seed)
+        self._draw = draw if draw is not None else (lambda step: self._rng.integers(self.n, size=self.B))
+        nslots = self.depth + 1
+        shp = {k: (self.B,) + tuple(v.shape[1:]) for k, v in self.data.items()}
+        self._pinned = [{k: torch.empty(shp[k], dtype=v.dtype, pin_memory=self.cuda) for k, v in self.data.items()} for _ in range(nslots)]
+        self._dev = [{k: torch.empty(shp[k], dtype=v.dtype, device=self.device) for k, v in self.data.items()} for _ in range(nslots)]
+        self._ready = [None] * nslots          # copy-stream event: the slot's H2D copy is complete
+        self._free = [None] * nslots           # consumer-stream event: the consumer no longer reads the slot
+        self._copy = torch.cuda.Stream(self.device) if self.cuda else None
+        self._q = queue.Queue()
+        # a slot may be (re)filled once the batch that used it last has been retired by next() -- which is also when its
+        # `_free` event exists; without this gate the worker would run one batch further and overwrite the set in use
+        self._slots = threading.Semaphore(nslots)
+        self._step = 0
+        self._stop = False
+        self._last = None
+        self._lock = threading.Lock()
+        self._thread = threading.Thread(target=self._work, daemon=True)
+        self._thread.start()
+
+    def _fill(self, step):
+        slot = step % (self.depth + 1)
+        idx = torch.as_tensor(np.asarray(self._draw(step), dtype=np.int64))
+        for k, v in self.data.items():
+            torch.index_select(v, 0, idx, out=self._pinned[slot][k])
+        if self.cuda:
+            with torch.cuda.stream(self._copy):
+                if self._free[slot] is not None:
+                    self._copy.wait_event(self._free[slot])
+                for k in self.data:
+                    self._dev[slot][k].copy_(self._pinned[slot][k], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self._copy)
+            self._ready[slot] = ev
+            ev.synchronize()   # (worker thread only: the pinned slot may be refilled once its copy has left the host)
+        else:
+            for k in self.data:
+                self._dev[slot][k].copy_(self._pinned[slot][k])
+        return slot
+
+    def _work(self):
+        step = 0
+        while True:
+            self._slots.acquire()
+            if self._stop:
+                return
+            try:
+                slot = self._fill(step)
+            except Exception as e:   # surfaces in next()
+                self._q.put(e)
+                return
+            self._q.put(slot)
+            step += 1
+
+    def next(self):
+        """Device tensors of the next batch.  Valid until the next call: kernels already enqueued on the caller's stream keep reading
+        them safely (the refill waits for an event recorded on that stream), host-side readers must copy first."""
+        item = self._q.get()
+        if isinstance(item, Exception):
+            raise item
+        if self.cuda:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(self._ready[item])
+        if self._last is not None:          # the slot handed out by the previous call is free once the consumer's stream gets here
+            if self.cuda:
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                self._free[self._last] = ev
+            self._slots.release()
+        self._last = item
+        self._step += 1
+        return self._dev[item]
+
+    def close(self):
+        self._stop = True
+        self._slots.release()
+
+
 def pad(text, max_len, pad_val):
     """data_input.pad (data_input.py:87-90)."""
     return np.array([np.pad(np.asarray(t, dtype=np.int64), (0, max_len - len(t)), 'constant', constant_values=pad_val)

@@ -44,13 +44,17 @@ def init_from_env(backend=None, force=None):
 def _comm_priority():
     """-1 (high) for the communication stream and RCCL's streams, unless TACO_COMM_PRIORITY=0 -- or the process runs with fewer
     than 8 hardware queues: a high-priority stream then displaces one of the step's own streams onto a shared queue, which was
-    measured to cost 1.3 ms per step (round 4, GPU_MAX_HW_QUEUES=4), far more than the priority buys."""
+    measured to cost 1.3 ms per step (round 4, GPU_MAX_HW_QUEUES=4), far more than the priority buys.  The variable only counts if it was
+    in the environment when the HIP runtime initialised (lib.HW_QUEUES_LATE)."""
     if os.environ.get('TACO_COMM_PRIORITY', '1') in ('', '0'):
         return 0
-    try:
-        return -1 if int(os.environ.get('GPU_MAX_HW_QUEUES', '4')) >= 8 else 0
-    except ValueError:
-        return 0
+    from . import lib
+    if lib.HW_QUEUES_LATE:
+        import warnings
+        warnings.warn('tacotron_amd was imported after the HIP runtime had initialised: GPU_MAX_HW_QUEUES=8 did not take effect, the '
+                      'communication streams stay at normal priority (import tacotron_amd -- or set the variable -- before the first '
+                      'torch.cuda call; INTEGRATION.md 4)')
+    return -1 if lib.effective_hw_queues() >= 8 else 0
 
 
 SEGMENT_NAMES = {3: 'post-net', 2: 'decoder', 1: 'encoder projections+highways+bi-GRU', 0: 'embedding+encoder pre_net+conv bank'}

@@ -14,9 +14,25 @@ import os
 # with 4 queues two of them share a queue and one's kernels sit behind a millisecond of the other's already-enqueued launches
 # (measured in round 4: the post-net segment's collective finished 1.47 ms after it became eligible, 30 us with 8 queues).
 # The variable is read when the HIP runtime initialises, i.e. at the first device call -- set it before anything touches the GPU.
+_QUEUES_SET_BY_USER = 'GPU_MAX_HW_QUEUES' in os.environ
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 import torch  # noqa: E402
+
+# If the process touched the GPU before importing this package (and did not set the variable itself) the runtime is already up
+# with its default of 4 queues: the setdefault above came too late, and high-priority communication streams would then cost 1.3 ms
+# per step instead of saving one (dist._comm_priority asks here).
+HW_QUEUES_LATE = (not _QUEUES_SET_BY_USER) and torch.cuda.is_available() and torch.cuda.is_initialized()
+
+
+def effective_hw_queues() -> int:
+    """Hardware queues the HIP runtime of this process multiplexes its streams onto, as far as the host can know."""
+    if HW_QUEUES_LATE:
+        return 4
+    try:
+        return int(os.environ.get('GPU_MAX_HW_QUEUES', '4'))
+    except ValueError:
+        return 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TACO_LIB') or os.path.join(_HERE, 'libtaco_hip.so')   # TACO_LIB: an alternative build (tuning A/B)
@@ -75,6 +91,7 @@ EXPORTS = {
     'taco_decoder_mode': (C.c_int, [_I]),
     'taco_debug_spin': (C.c_int, [_I, _I, _I, _I, _P]),
     'taco_debug_clock_probe': (C.c_int, [_P, _I, _P]),
+    'taco_debug_fabric_probe': (C.c_int, [_P, _P, _P, C.c_int64, _I, _P]),
     'taco_denorm_unframe': (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'taco_griffinlim_workspace_bytes': (C.c_int64, [_I, _I]),
     'taco_griffinlim': (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
@@ -259,6 +276,33 @@ def clock_probe(iters=1 << 20):
     torch.cuda.synchronize()
     cyc, ticks = out[0].item(), out[1].item()
     return cyc / (ticks * 10.0) if ticks > 0 else 0.0
+
+
+def fabric_probe(iters=2000, scratch_mb=768):
+    """Latencies of this box that the latency-bound kernels wait on (include/taco_hip.h taco_debug_fabric_probe); host
+    synchronisation.  Returns ns per granule hop (one way) in the three exchange forms, ns per dependent load (L2 hit / miss of
+    every cache), the bandwidth one workgroup streams at, and which XCDs the probing workgroups ran on."""
+    out = torch.zeros(32, dtype=torch.int64, device='cuda')
+    gran = torch.zeros(512, dtype=torch.int64, device='cuda')
+    scratch = torch.zeros(scratch_mb << 18, dtype=torch.int32, device='cuda')
+    res = None
+    for _ in range(2):   # (first call: clocks ramping up, cold TLBs)
+        out.zero_(); gran.zero_()
+        _check(_lib.taco_debug_fabric_probe(ptr(out), ptr(gran), ptr(scratch), int(scratch.numel() * 4), int(iters), stream_ptr()),
+               'taco_debug_fabric_probe')
+        torch.cuda.synchronize()
+        res = out.tolist()
+    n = max(1, res[6])
+    ok = res[7]
+    xcc = res[8:32]
+    hop = lambda t: t * 10.0 / n / 2.0   # noqa: E731  (a round trip is two hops)
+    return {'hop_ns_same_xcd_l2_local': hop(res[0]) if ok & 1 else None,
+            'hop_ns_same_xcd_agent_scope': hop(res[1]) if ok & 2 else None,
+            'hop_ns_cross_xcd': hop(res[2]) if ok & 4 else None,
+            'load_ns_l2_hit': res[3] * 10.0 / n, 'load_ns_all_miss': res[4] * 10.0 / n,
+            'one_cu_stream_gb_s': (8 << 20) / (res[5] * 10e-9) / 1e9 if res[5] > 0 else None,
+            'xcc_of_pairs': {'l2_local': [xcc[0], xcc[8]], 'agent': [xcc[1], xcc[9]], 'cross': [xcc[2], xcc[3]]},
+            'scratch_mb': scratch_mb}
 
 
 def debug_spin(blocks, threads, lds_bytes, usec, stream=None):

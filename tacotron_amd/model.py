@@ -13,8 +13,11 @@ from .params import ParamBuffer
 
 
 class Tacotron(object):
+    ESCALATE_WINDOW = 2000   # steps: two exchange time-outs closer than this escalate the decoder mode (check())
+
     def __init__(self, config, inputs, train=True, device='cuda', params=None, seed=0, reducer=None):
         config.validate()
+        self._last_timeout_step = None
         self.config = config
         self.train = train
         self.device = torch.device(device)
@@ -163,14 +166,22 @@ class Tacotron(object):
         flags = self._err.tolist()
         if flags[0] or flags[1]:
             lib.clear_error(self.shape, self.train, self.workspace)
-            # self-heal: the next launches of this PROCESS use the next more conservative decoder mode (include/taco_hip.h
-            # taco_decoder_mode: XCD-local exchange -> agent-scope exchange -> decoder.hip); the caller decides whether to go on
+            # self-heal: a SECOND time-out within ESCALATE_WINDOW steps of the previous one moves this PROCESS to the next more
+            # conservative decoder mode (include/taco_hip.h taco_decoder_mode: XCD-local exchange -> agent-scope exchange ->
+            # decoder.hip, ~2 x slower per decoder step).  A single time-out -- e.g. another tenant briefly holding CUs -- only
+            # costs the updates skipped while the flag was set: it must not degrade the rest of a multi-day run.
             mode = lib.decoder_mode()
-            e = lib.TacoError('decoder cluster exchange timed out (forward=%d, backward=%d) in decoder mode %d; parameter updates '
-                              'were skipped while the flag was set%s' %
-                              (flags[0], flags[1], mode, '; switched to decoder mode %d' % (mode + 1) if mode < 2 else ''))
+            prev = self._last_timeout_step
+            self._last_timeout_step = self.global_step
+            repeat = prev is not None and self.global_step - prev <= self.ESCALATE_WINDOW
+            escalate = repeat and mode < 2
+            e = lib.TacoError('decoder cluster exchange timed out (forward=%d, backward=%d) in decoder mode %d at step %d; parameter '
+                              'updates were skipped while the flag was set%s' %
+                              (flags[0], flags[1], mode, self.global_step,
+                               '; second time-out within %d steps: switched to decoder mode %d' % (self.ESCALATE_WINDOW, mode + 1)
+                               if escalate else ('' if mode >= 2 else '; mode kept (first time-out in this window)')))
             e.recoverable = mode < 2
-            if mode < 2:
+            if escalate:
                 lib.decoder_mode(mode + 1)
             raise e
 
@@ -184,6 +195,16 @@ class Tacotron(object):
     @property
     def loss(self):
         return self._loss[0]
+
+    @property
+    def loss_terms(self):
+        """(seq2seq_loss, output_loss) -- the two sums of add_loss_op (tacotron.py:158-160) behind `loss`; device tensors."""
+        return self._loss[1], self._loss[2]
+
+    @property
+    def decoder_mode(self):
+        """The process-wide decoder mode in use (0 XCD-local exchange, 1 agent-scope exchange, 2 decoder.hip); see check()."""
+        return lib.decoder_mode()
 
     @property
     def global_gradient_norm(self):
@@ -202,7 +223,8 @@ class Tacotron(object):
         """Weights + Adam slots + global_step + the spectrogram normalisation statistics (the reference keeps stft_mean /
         stft_std as checkpointed variables, train.py:31-33, and test.py:27-28,64 de-normalises with them)."""
         d = {'params': self.params.flat.detach().cpu(), 'global_step': self.global_step,
-             'shape': (self.shape.r, self.shape.V), 'num_speakers': max(1, self.shape.S), 'taco_version': lib.version()}
+             'shape': (self.shape.r, self.shape.V), 'num_speakers': max(1, self.shape.S), 'taco_version': lib.version(),
+             'decoder_mode': lib.decoder_mode()}
         if self.stft_mean is not None:
             d['stft_mean'] = torch.as_tensor(self.stft_mean, dtype=torch.float32).cpu()
             d['stft_std'] = torch.as_tensor(self.stft_std, dtype=torch.float32).cpu()

@@ -13,7 +13,7 @@ import torch
 
 from . import config as config_module
 from .config import SAVE_EVERY, Config
-from .data import synthetic_batch
+from .data import DeviceFeeder, synthetic_batch, synthetic_corpus
 from .dist import GradReducer, init_from_env
 from .model import Tacotron
 
@@ -89,14 +89,16 @@ def train(config, num_steps=1000000, log_every=50, save_every=SAVE_EVERY):
         if rank == 0:
             print('no corpus under %s -- synthetic Nancy-shaped batches' % config.data_path)
         data, n = None, 0
-    draw = np.random.default_rng(1000 + rank)       # per-rank minibatch stream
+    if data is None:   # a pool of synthetic utterances stands in for the npy corpus; batches are index draws from it either way
+        data = synthetic_corpus(max(256, 4 * config.batch_size), 200, config.max_decode_iter, config.r, config.vocab_size,
+                                seed=1234, rank=rank, num_speakers=config.num_speakers)
+    # The reference's queue runners (train.py:44-45) become a prefetching feeder: per-rank index stream, rows gathered into
+    # pinned buffers by a worker thread, H2D on a copy stream two batches ahead; set_inputs() on its tensors is a pointer swap
+    # (a blocking pageable copy of the 51 MB batch alone would be ~2 x the 8.4 ms train step).
+    feeder = DeviceFeeder(data, config.batch_size, device=torch.device('cuda', local), depth=2, seed=1000 + rank)
 
     def next_batch(step):
-        if data is None:
-            return synthetic_batch(config.batch_size, 200, config.max_decode_iter, config.r, config.vocab_size,
-                                   seed=1234 + step * 9973, rank=rank, num_speakers=config.num_speakers)
-        idx = draw.integers(n, size=config.batch_size)
-        return {k: torch.from_numpy(v[idx]) for k, v in data.items()}
+        return feeder.next()
 
     # same initial parameters on every rank (seed 0); the dropout / sampling streams are offset by the reducer's rank
     # TACO_FORCE_DIST=1 at world size 1 takes every distributed branch too (as bench.py does): reducer, collectives, barriers
@@ -117,10 +119,15 @@ def train(config, num_steps=1000000, log_every=50, save_every=SAVE_EVERY):
             if rank == 0:
                 print('restored %s (global_step %d)' % (path, model.global_step))
     lr = config.init_lr
+    import time
+    t_mark, s_mark, step = None, 0, -1                    # throughput of the host loop itself (reported when the loop ends)
     for step in range(num_steps):
-        model.set_inputs(next_batch(step))
+        model.set_inputs(next_batch(step))                # device tensors from the feeder: a pointer swap
         model.step(lr)
         gs = model.global_step
+        if step == 10:                                    # (past the first steps' one-off costs: lazy allocations, LDS attribute calls)
+            torch.cuda.synchronize()
+            t_mark, s_mark = time.perf_counter(), step
         if gs % log_every == 0 or gs % save_every == 0:
             loss = float(model.loss)                      # the only host sync, every log_every steps
             try:
@@ -130,7 +137,10 @@ def train(config, num_steps=1000000, log_every=50, save_every=SAVE_EVERY):
                     raise
                 print('WARNING (rank %d): %s -- continuing' % (rank, e))   # check() moved to a more conservative decoder mode
             if rank == 0:
-                print('step %d loss %.1f gnorm %.2f' % (gs, loss, float(model.global_gradient_norm)))
+                # tacotron.py:162-164: the summaries 'loss', 'seq2seq_loss', 'output_loss' (scalars only)
+                s2s_l, out_l = (float(x) for x in model.loss_terms)
+                print('step %d loss %.1f (seq2seq %.1f + output %.1f) gnorm %.2f decoder-mode %d' %
+                      (gs, loss, s2s_l, out_l, float(model.global_gradient_norm), model.decoder_mode))
             if loss > 1e8 and gs > 500:                   # train.py:77-80
                 print('loss exploded')
                 break
@@ -147,8 +157,16 @@ def train(config, num_steps=1000000, log_every=50, save_every=SAVE_EVERY):
                 # rank 0 spent a while on the host; the others must not run ahead into the next step's collectives (and the
                 # persistent decoder kernels of a rank that waits inside a collective keep spinning on their peers)
                 torch.distributed.barrier()
+    torch.cuda.synchronize()
+    feeder.close()
+    if t_mark is not None and step > s_mark:
+        dt = time.perf_counter() - t_mark
+        fps = (step - s_mark) * config.batch_size * config.r * config.max_decode_iter * max(world, 1) / dt
+        model.host_loop_frames_per_s = fps
+        if rank == 0:
+            print('host loop: %d steps in %.2f s = %.3f ms/step, %.0f mel-frames/s (%d rank%s), data fed by DeviceFeeder' %
+                  (step - s_mark, dt, dt / (step - s_mark) * 1e3, fps, world, '' if world == 1 else 's'))
     if torch.distributed.is_initialized():
-        torch.cuda.synchronize()
         torch.distributed.destroy_process_group()
     return model
 

@@ -171,3 +171,97 @@ def test_tf_checkpoint_rename_table_round_trip(built_lib, S):
     assert missing == [table['decoder/attention_v']] and extra == ['decoder/attention_v_renamed']
     with pytest.raises(KeyError):
         import_tf_variables(bad, shape)
+
+
+def test_device_feeder_rotation_and_order():
+    """tacotron_amd.data.DeviceFeeder on the CPU path (no pinning, synchronous copies): batches arrive in draw order, the buffer
+    set handed out last is not overwritten until the next call, and the worker never runs more than
+    depth + 1 batches ahead of the consumer (the slot gate that keeps a set in use from being refilled)."""
+    import time
+    import numpy as np
+    from tacotron_amd.data import DeviceFeeder
+    n, B = 50, 4
+    data = {'text': np.arange(n * 3, dtype=np.int32).reshape(n, 3), 'mel': np.arange(n * 2, dtype=np.float32).reshape(n, 2, 1)}
+    drawn = []
+
+    def draw(step):
+        idx = (np.arange(B) * 7 + step * 3) % n
+        drawn.append(step)
+        return idx
+    f = DeviceFeeder(data, B, device='cpu', depth=2, draw=draw)
+    try:
+        time.sleep(0.3)
+        assert max(drawn) <= 2, 'worker ran %d batches ahead with nothing consumed (3 buffer sets)' % max(drawn)
+        for step in range(12):
+            b = f.next()
+            idx = (np.arange(B) * 7 + step * 3) % n
+            assert np.array_equal(b['text'].numpy(), data['text'][idx]) and np.array_equal(b['mel'].numpy(), data['mel'][idx])
+            time.sleep(0.02)   # (the worker has time to run ahead: the current set must survive it)
+            assert np.array_equal(b['text'].numpy(), data['text'][idx])
+            assert max(drawn) <= step + 3
+    finally:
+        f.close()
+
+
+def test_crc32c_and_snappy_primitives():
+    """Known answers of the two primitives the bundle reader rests on: CRC-32C("123456789") = 0xE3069283 (the Castagnoli check
+    value), the table magic, and a snappy stream with a literal and an overlapping back-reference."""
+    from tacotron_amd import tf_bundle as tb
+    assert tb.crc32c(b'123456789') == 0xE3069283
+    assert tb.mask_crc(0) == 0xa282ead8
+    # "abcabcabcabcX": literal 'abc' (tag 0x08), copy-1 len 9 off 3 (tag = 1 | (9 - 4) << 2 | (3 >> 8) << 5 = 0x15, byte 3), literal 'X'
+    stream = bytes([13, 0x08]) + b'abc' + bytes([0x15, 3, 0x00]) + b'X'
+    assert tb.snappy_decompress(stream) == b'abcabcabcabcX'
+
+
+@pytest.mark.parametrize('snappy,block_size', [(False, 4096), (False, 300), (True, 700)], ids=['plain', 'tiny-blocks', 'snappy'])
+def test_tf_bundle_reader_feeds_the_importer(built_lib, tmp_path, snappy, block_size):
+    """VERDICT r4 #8b: `tf_import.import_tf_variables` fed by the TensorFlow-free bundle reader.  A checkpoint with the reference's
+    variable names (weights, Adam slots, BN moving statistics, global_step, stft statistics) is written as `<prefix>.index` +
+    `<prefix>.data-00000-of-00001` by the independent writer of tests/bundle_writer.py -- several data blocks (prefix-compressed
+    keys across restart points), optionally snappy-framed -- read back with tf_bundle.load_checkpoint (index CRCs and tensor CRCs
+    verified) and imported: the parameter buffer equals the one the variables were made from; a flipped byte is detected."""
+    from oracle import taco_numpy as on
+    from tacotron_amd import tf_bundle as tb
+    from tacotron_amd.params import ParamBuffer
+    from tacotron_amd.tf_import import import_tf_variables, tf_name_map
+    from tests.bundle_writer import write_bundle
+    V, r, S = 33, 2, 1
+    shape = built_lib.make_shape(2, 8, 4, r, V, S)
+    p = on.init_params(V, r, seed=5, perturb=0.3, num_speakers=S)
+    table = tf_name_map(S)
+    rng = np.random.default_rng(1)
+    ckpt = {}
+    with_slots = not snappy and block_size == 4096   # (the CRCs are pure Python, ~10 MB/s: the 2 x 27 MB of Adam slots in one case only)
+    for n, a in p.items():
+        ckpt[table[n]] = a.astype(np.float32)
+        if with_slots:
+            ckpt[table[n] + '/Adam'] = rng.standard_normal(a.shape).astype(np.float32)
+            ckpt[table[n] + '/Adam_1'] = rng.random(a.shape).astype(np.float32)
+    ckpt['encoder/cbhg/batch_normalization/moving_mean'] = np.zeros(2048, np.float32)
+    ckpt['global_step'] = np.array(54321, dtype=np.int64)
+    ckpt['stft_mean'] = rng.standard_normal(1025 * r).astype(np.float32)
+    ckpt['stft_std'] = rng.random(1025 * r).astype(np.float32)
+    prefix = str(tmp_path / 'tacotron-54321')
+    write_bundle(prefix, ckpt, block_size=block_size, snappy=snappy)
+    listed = tb.list_variables(prefix)
+    assert set(listed) == set(ckpt) and listed['global_step'] == (np.int64, ())
+    assert listed[table['decoder/attention_v']] == (np.float32, (256,))
+    got = tb.load_checkpoint(prefix, verify_tensors=True)
+    assert set(got) == set(ckpt) and all(np.array_equal(got[k], ckpt[k]) and got[k].dtype == ckpt[k].dtype for k in ckpt)
+    sd = import_tf_variables(got, shape)
+    assert torch.equal(sd['params'], ParamBuffer(shape).load_dict_(p).flat) and sd['global_step'] == 54321
+    assert ('adam_m' in sd) == with_slots and torch.equal(sd['stft_std'], torch.from_numpy(ckpt['stft_std']))
+    only = tb.load_checkpoint(prefix, names={'global_step', 'stft_mean'})
+    assert set(only) == {'global_step', 'stft_mean'}
+    # corruption is detected: one byte of a tensor, one byte of the index
+    data = bytearray(open(prefix + '.data-00000-of-00001', 'rb').read())
+    data[100] ^= 0x40
+    open(prefix + '.data-00000-of-00001', 'wb').write(bytes(data))
+    with pytest.raises(ValueError, match='CRC'):
+        tb.load_checkpoint(prefix, verify_tensors=True)
+    idx = bytearray(open(prefix + '.index', 'rb').read())
+    idx[10] ^= 0x01
+    open(prefix + '.index', 'wb').write(bytes(idx))
+    with pytest.raises(ValueError):
+        tb.load_checkpoint(prefix)

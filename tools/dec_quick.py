@@ -23,7 +23,8 @@ if '--time-only' not in sys.argv:
 from tacotron_amd.config import Config
 from tacotron_amd.data import synthetic_batch
 from tacotron_amd.model import Tacotron
-print('box: %.2f GHz under a latency-bound load' % lib.clock_probe())
+if '--json' not in sys.argv:
+    print('box: %.2f GHz under a latency-bound load' % lib.clock_probe())
 c = Config(); c.r, c.vocab_size = 2, 60
 m = Tacotron(c, synthetic_batch(32, 200, 180, 2, 60), train=True, seed=0)
 for _ in range(3): m.step()
@@ -36,6 +37,11 @@ torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
 lib.profile_enable(0)
 f, b = lib.profile_read(0), lib.profile_read(1)
 m.check()
+if '--json' in sys.argv:   # bench.py's in-run A/B of decoder builds (TACO_LIB selects the library)
+    import json
+    print(json.dumps({'ms_per_step': dt * 1e3, 'us_per_decoder_step_fwd': float(np.median(f)) * 1e3 / 180,
+                      'us_per_decoder_step_bwd': float(np.median(b)) * 1e3 / 180, 'loss': float(m.loss)}))
+    sys.exit(0)
 print('S1: %.2f ms/step; decoder fwd %.3f ms (%.2f us/step, cluster %d), bwd %.3f ms (%.2f us/step); loss %.1f' %
       (dt * 1e3, np.median(f), np.median(f) * 1e3 / 180, lib.last_cluster(0), np.median(b), np.median(b) * 1e3 / 180, float(m.loss)))
 ci = Config(); ci.r, ci.vocab_size, ci.max_decode_iter = 2, 60, 180
