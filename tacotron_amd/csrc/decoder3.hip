@@ -19,6 +19,8 @@
 //
 // Scope: Tt <= 256, B <= 32, r in {2, 5} (the two frame-group sizes the drivers and fixtures use); training requires the
 // hoisted pre-net (model.hip always provides it).  Anything else returns TACO_ENOTFOUND and the caller takes decoder.hip.
+#include <string.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -100,6 +102,46 @@ __device__ __forceinline__ bool spin_fail(unsigned& spin, const Xc& X) {
   }
   __builtin_amdgcn_s_sleep(1);
   return false;
+}
+
+// Placement rendezvous at kernel start.  Every workgroup publishes the XCC id it runs on; the first 32 threads of a workgroup
+// read the ids of their cluster's 32 peers.  Result: 2 = all peers share an XCD (exchange through its L2), 1 = the cluster
+// straddles XCDs (placement-independent agent-scope exchange), 0 = a peer did not show up within kRendezvousTicks (50 ms of
+// the 100 MHz counter): the cluster is NOT CO-RESIDENT -- some other kernel holds CUs it needs (ADVICE r3 / VERDICT r4 #7b).
+// A healthy launch has its 256 workgroups dispatched within tens of microseconds, so this is the residency check the step
+// loop relies on, made BEFORE the first exchange instead of discovered by a 2^23-poll spin inside it: the workgroup raises
+// the error word (value 2) and leaves; a peer that arrives later finds the word set at its first poll check and leaves too.
+constexpr long long kRendezvousTicks = 5000000;
+__device__ __forceinline__ int placement_rendezvous(void* xchg, int table_ofs, int cl, int* err, float* smem) {
+  constexpr int NCL = 8;
+  const int tid = threadIdx.x;
+  gi32* tab = (gi32*)(reinterpret_cast<int*>(xchg) + table_ofs);
+  int* sflag = reinterpret_cast<int*>(smem);
+  if (tid == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    __hip_atomic_store(tab + blockIdx.x, (int)(xcc & 15u) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (tid < P3) {
+    int v = 0;
+    const long long t0 = wall_clock64();
+    for (;;) {
+      v = __hip_atomic_load(tab + tid * NCL + cl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (v != 0 || wall_clock64() - t0 > kRendezvousTicks) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
+    const int v0 = __shfl(v, 0, 64);
+    const bool here = __all(v != 0);
+    const bool same = __all(v != 0 && v == v0);
+    if (tid == 0) {
+      sflag[0] = !here ? 0 : (same ? 2 : 1);
+      if (!here) __hip_atomic_store((gi32*)err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+  const int r = sflag[0];
+  __syncthreads();
+  return r;
 }
 
 // threadIdx.x behind an opaque move: everything a round derives from it (columns, row selections, stash / granule / LDS addresses)
@@ -636,30 +678,13 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
   Xc X;
   X.base = (gu64*)(reinterpret_cast<u64*>(a.xchg) + (int64_t)cl * R * kX3Row);
   X.rs = __builtin_amdgcn_make_buffer_rsrc((void*)X.base, 0, R * kX3Row * 8, 0x00020000);
-  // ---- placement rendezvous: every workgroup publishes its XCC id; a cluster whose 32 ids agree exchanges through its L2 ----
+  // ---- clusters beyond the batch leave at once (B = 1 inference: 224 of the 256 workgroups; their CUs are free for whoever
+  //      else uses the chip -- they take no part in any rendezvous or exchange); the others meet their peers (above) ----
+  if (cl >= ncl_used) return;
   {
-    gi32* tab = (gi32*)(reinterpret_cast<int*>(a.xchg) + a.xcc_table_ofs);
-    int* sflag = reinterpret_cast<int*>(smem);
-    if (tid == 0) {
-      unsigned xcc;
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-      __hip_atomic_store(tab + blockIdx.x, (int)(xcc & 15u) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (tid < P3) {
-      int v = 0;
-      for (unsigned spin = 0; spin < (1u << 22); ++spin) {
-        v = __hip_atomic_load(tab + tid * NCL + cl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (v != 0) break;
-        __builtin_amdgcn_s_sleep(2);
-      }
-      const int v0 = __shfl(v, 0, 64);
-      const bool same = __all(tid >= P3 || (v != 0 && v == v0));
-      if (tid == 0) sflag[0] = same ? 1 : 0;
-    }
-    __syncthreads();
-    X.fast = sflag[0] != 0 && a.fast_ok;
-    __syncthreads();
-    if (cl >= ncl_used) return;
+    const int where = placement_rendezvous(a.xchg, a.xcc_table_ofs, cl, a.err, smem);
+    if (where == 0) return;   // not co-resident: error word raised
+    X.fast = where == 2 && a.fast_ok;
     // placement census (diagnostic; Tacotron.placement_census()): workgroups whose cluster exchanges through its XCD's L2 (word 4)
     // vs. at agent scope because the cluster straddles XCDs or TACO_DEC_V3_AGENT is set (word 5)
     if (tid == 0) atomicAdd(a.err + 4 + (X.fast ? 0 : 1), 1);
@@ -1322,29 +1347,11 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
   Xc X;
   X.base = (gu64*)(reinterpret_cast<u64*>(a.xchg) + (int64_t)cl * R * kX3Row);
   X.rs = __builtin_amdgcn_make_buffer_rsrc((void*)X.base, 0, R * kX3Row * 8, 0x00020000);
+  if (cl >= ncl_used) return;
   {
-    gi32* tab = (gi32*)(reinterpret_cast<int*>(a.xchg) + a.xcc_table_ofs);
-    int* sflag = reinterpret_cast<int*>(smem);
-    if (tid == 0) {
-      unsigned xcc;
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-      __hip_atomic_store(tab + blockIdx.x, (int)(xcc & 15u) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (tid < P3) {
-      int v = 0;
-      for (unsigned spin = 0; spin < (1u << 22); ++spin) {
-        v = __hip_atomic_load(tab + tid * NCL + cl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (v != 0) break;
-        __builtin_amdgcn_s_sleep(2);
-      }
-      const int v0 = __shfl(v, 0, 64);
-      const bool same = __all(tid >= P3 || (v != 0 && v == v0));
-      if (tid == 0) sflag[0] = same ? 1 : 0;
-    }
-    __syncthreads();
-    X.fast = sflag[0] != 0 && a.fast_ok;
-    __syncthreads();
-    if (cl >= ncl_used) return;
+    const int where = placement_rendezvous(a.xchg, a.xcc_table_ofs, cl, a.err, smem);
+    if (where == 0) return;   // not co-resident: error word raised
+    X.fast = where == 2 && a.fast_ok;
   }
   X.err = a.err;
   X.dead = dead;
@@ -1917,6 +1924,26 @@ int launch3b(DecBwdArgs& a, hipStream_t s) {
 // other tenants holding CUs, a partition mode whose L2 does not behave like gfx950 SPX -- degrades to a slower mode instead of
 // skipping every update.  The environment (read on every launch: tests and A/B tools switch it inside one process) is a floor
 // under the programmed value: TACO_DEC_V3=0 -> 2, TACO_DEC_V3_AGENT=1 -> 1.
+// The XCD-local exchange form publishes granules at WORKGROUP scope and reads them with L1-bypassing agent-scope loads: coherent
+// because all peers of a cluster share one XCD's L2 -- a property of the chip's cache hierarchy and partition mode, outside what
+// the HIP memory model promises.  It is therefore enabled only on an explicit allow-list (ADVICE r3 / VERDICT r4 #7c): gfx950 in
+// SPX mode (one device = 8 XCDs = 256 CUs), where it was validated (parity suite, 1,000-step soaks, tools/micro/pingpong); anything
+// else -- another architecture, a DPX / QPX / CPX partition, a future part -- gets the agent-scope form, which is merely slower.
+static bool xcd_local_exchange_allowed() {
+  static signed char cache[32] = {};   // 0 unknown, 1 allowed, -1 not
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return false;
+  if (cache[dev] == 0) {
+    hipDeviceProp_t prop;
+    bool ok = false;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      ok = strncmp(prop.gcnArchName, "gfx950", 6) == 0 && prop.multiProcessorCount == 256;
+    if (const char* e = getenv("TACO_DEC_ALLOW_XCD_LOCAL")) ok = atoi(e) != 0;   // (bring-up of a new part: force either way)
+    cache[dev] = ok ? 1 : -1;
+  }
+  return cache[dev] > 0;
+}
+
 static int g_dec_mode = 0;
 static int dec_mode() {
   const char* v3 = getenv("TACO_DEC_V3");
@@ -1939,7 +1966,7 @@ int launch_decoder3_bwd(DecBwdArgs a, hipStream_t s) {
   const int ncl = (a.B + R - 1) / R;
   if ((int64_t)ncl * R * kX3Row * 8 + 1024 > decoder_xchg_bytes(a.B, a.Tt)) return TACO_ENOTFOUND;
   a.xcc_table_ofs = (int)(decoder_xchg_bytes(a.B, a.Tt) / 4 - 256);
-  a.fast_ok = dec_mode() == 0 ? 1 : 0;
+  a.fast_ok = (dec_mode() == 0 && xcd_local_exchange_allowed()) ? 1 : 0;
   a.fakew = kProbes3 ? ((getenv("TACO_DEC_FAKEX") ? 2 : 0)) : 0;
   a.P = P3;
   decoder_note_cluster(1, P3);
@@ -1957,7 +1984,7 @@ int launch_decoder3_fwd(DecFwdArgs a, hipStream_t s) {
   const int ncl = (a.B + R - 1) / R;
   if ((int64_t)ncl * R * kX3Row * 8 + 1024 > decoder_xchg_bytes(a.B, a.Tt)) return TACO_ENOTFOUND;
   a.xcc_table_ofs = (int)(decoder_xchg_bytes(a.B, a.Tt) / 4 - 256);   // last 1 KB of the exchange area
-  a.fast_ok = dec_mode() == 0 ? 1 : 0;
+  a.fast_ok = (dec_mode() == 0 && xcd_local_exchange_allowed()) ? 1 : 0;
   a.P = P3;
   a.fakew = kProbes3 ? ((getenv("TACO_DEC_FAKEX") ? 2 : 0)) : 0;
   decoder_note_cluster(0, P3);

@@ -863,20 +863,23 @@ __global__ __launch_bounds__(64) void fabric_probe_kernel(long long* out, fp_u64
   } else if (b == 20 || b == 21) {
     // dependent loads: the next index is a multiplicative walk over the region PLUS the loaded word (the buffer holds zeros, which
     // the compiler cannot know), 32 words = one 128-byte line apart.  The L2-hit walk covers 64 KB and touches every line once
-    // before the clock starts; the loads are agent scope (they bypass the L1, as every poll of the decoder kernels does)
-    const long long lines = (b == 20 ? (64ll << 10) : scratch_words * 4) / 128;
+    // before the clock starts (64 KB exceeds the CU's L1: the walk is served by the XCD's L2); plain loads -- agent-scope loads
+    // were measured to take the same ~320 ns whether the line is in the L2 or nowhere, i.e. they are fabric round trips
+    long long lines = (b == 20 ? (64ll << 10) : scratch_words * 4) / 128;
+    while (lines & (lines - 1)) lines &= lines - 1;   // largest power of two: the walk is a mask, not a 64-bit software modulo
+    const unsigned long long mask = (unsigned long long)lines - 1;
     unsigned long long idx = 1;
     if (b == 20) {
       unsigned w = 0;
       for (long long l = 0; l < lines; ++l)
-        w += __hip_atomic_load((const __attribute__((address_space(1))) unsigned*)(scratch + (16ll << 20) / 4 + l * 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w += scratch[(16ll << 20) / 4 + l * 32];
       idx += w;
     }
     const unsigned* base = b == 20 ? scratch + (16ll << 20) / 4 : scratch;   // (the streaming block reads the first 8 MB)
     const long long t0 = wall_clock64();
     for (int i = 0; i < iters; ++i) {
-      const unsigned v = __hip_atomic_load((const __attribute__((address_space(1))) unsigned*)(base + idx * 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      idx = (idx * 2654435761ull + 12345ull + v) % (unsigned long long)lines;
+      const unsigned v = base[idx * 32];   // (a plain load: the next index depends on it, so it can be neither hoisted nor dropped)
+      idx = (idx * 1664525ull + 1013904223ull + v) & mask;   // (full-period LCG modulo 2^k)
     }
     const long long t1 = wall_clock64();
     out[b == 20 ? 3 : 4] = t1 - t0;

@@ -13,7 +13,7 @@ import torch
 
 from . import config as config_module
 from .config import SAVE_EVERY, Config
-from .data import DeviceFeeder, synthetic_batch, synthetic_corpus
+from .data import DeviceCorpus, DeviceFeeder, synthetic_batch, synthetic_corpus
 from .dist import GradReducer, init_from_env
 from .model import Tacotron
 
@@ -92,10 +92,16 @@ def train(config, num_steps=1000000, log_every=50, save_every=SAVE_EVERY):
     if data is None:   # a pool of synthetic utterances stands in for the npy corpus; batches are index draws from it either way
         data = synthetic_corpus(max(256, 4 * config.batch_size), 200, config.max_decode_iter, config.r, config.vocab_size,
                                 seed=1234, rank=rank, num_speakers=config.num_speakers)
-    # The reference's queue runners (train.py:44-45) become a prefetching feeder: per-rank index stream, rows gathered into
-    # pinned buffers by a worker thread, H2D on a copy stream two batches ahead; set_inputs() on its tensors is a pointer swap
-    # (a blocking pageable copy of the 51 MB batch alone would be ~2 x the 8.4 ms train step).
-    feeder = DeviceFeeder(data, config.batch_size, device=torch.device('cuda', local), depth=2, seed=1000 + rank)
+    # The reference's queue runners (train.py:44-45): the corpus lives in HBM and a batch is a device-side gather (DeviceCorpus);
+    # a corpus beyond TACO_CORPUS_HBM_GB (default 64) is fed by a prefetching worker through pinned buffers and a copy stream
+    # (DeviceFeeder).  Either way set_inputs() gets device tensors and is a pointer swap -- a blocking pageable copy of the 51 MB
+    # batch alone would be ~2 x the 8.4 ms train step.
+    dev = torch.device('cuda', local)
+    budget = float(os.environ.get('TACO_CORPUS_HBM_GB', '64')) * (1 << 30)
+    if DeviceCorpus.nbytes(data) <= budget:
+        feeder = DeviceCorpus(data, config.batch_size, device=dev, seed=1000 + rank)
+    else:
+        feeder = DeviceFeeder(data, config.batch_size, device=dev, depth=2, seed=1000 + rank)
 
     def next_batch(step):
         return feeder.next()
@@ -164,8 +170,8 @@ def train(config, num_steps=1000000, log_every=50, save_every=SAVE_EVERY):
         fps = (step - s_mark) * config.batch_size * config.r * config.max_decode_iter * max(world, 1) / dt
         model.host_loop_frames_per_s = fps
         if rank == 0:
-            print('host loop: %d steps in %.2f s = %.3f ms/step, %.0f mel-frames/s (%d rank%s), data fed by DeviceFeeder' %
-                  (step - s_mark, dt, dt / (step - s_mark) * 1e3, fps, world, '' if world == 1 else 's'))
+            print('host loop: %d steps in %.2f s = %.3f ms/step, %.0f mel-frames/s (%d rank%s), data fed by %s' %
+                  (step - s_mark, dt, dt / (step - s_mark) * 1e3, fps, world, '' if world == 1 else 's', type(feeder).__name__))
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
     return model

@@ -703,8 +703,11 @@ def test_twenty_step_trajectory_vs_oracle(built_lib):
     by taco_fill_bernoulli and READ BACK, forward, backward, global-norm clip, TF-form Adam with its bias correction, global_step --
     against 20 x {oracle loss_and_grads (fp64) + oracle clip_adam_step} fed the same masks.  Pins the mask plumbing (which byte
     buffer feeds which layer), the step counter the bias correction uses, the clip threshold and the update order; a wrong
-    `global_step` offset or a stale mask shows within two steps.  Tolerances: loss rel 1e-5 at every step, parameters after 20 steps
-    rel-L2 2e-5 per tensor (fp32 Adam on the device vs fp64: the sqrt(v) + eps denominator amplifies rounding for near-zero v)."""
+    `global_step` offset or a stale mask shows within two steps.  Tolerances (fp32 trajectory on the device vs an fp64 one: Adam's
+    m / (sqrt(v) + eps) turns rounding-level gradient differences of near-zero entries into lr-sized update differences, so the two
+    trajectories separate slowly -- measured: gnorm 2.5e-4 apart at step 6): loss rel 1e-4 and gnorm rel 2e-3 at every step; after
+    20 steps the MOVEMENT p20 - p0 of every tensor within 2 % rel-L2 of the oracle's (a bias-correction step off by one changes the
+    first updates by 34 % and the 20-step movement by ~8 %; a stale or swapped mask changes the loss by percents)."""
     import math
     from oracle import taco_torch as ot
     from tacotron_amd.config import Config
@@ -721,7 +724,7 @@ def test_twenty_step_trajectory_vs_oracle(built_lib):
     vt = {k: torch.zeros_like(v) for k, v in pt.items()}
     inp = {k: batch[k].numpy() for k in ('text', 'text_length', 'mel', 'stft')}
     lr = 1e-3
-    worst_loss = 0.0
+    worst_loss = worst_gn = 0.0
     for step in range(1, 21):
         masks = m.draw_masks()
         m.forward(masks)
@@ -733,19 +736,25 @@ def test_twenty_step_trajectory_vs_oracle(built_lib):
         gn = ot.clip_adam_step(pt, gt, mt, vt, step, lr)
         worst_loss = max(worst_loss, abs(float(m.loss) - loss) / loss)
         assert m.global_step == step
-        assert abs(float(m.global_gradient_norm) - gn) <= 2e-4 * gn, (step, float(m.global_gradient_norm), gn)
-        assert abs(float(m.loss) - loss) <= 1e-5 * loss, (step, float(m.loss), loss)
+        worst_gn = max(worst_gn, abs(float(m.global_gradient_norm) - gn) / gn)
+        assert abs(float(m.global_gradient_norm) - gn) <= 2e-3 * gn, (step, float(m.global_gradient_norm), gn)
+        assert abs(float(m.loss) - loss) <= 1e-4 * loss, (step, float(m.loss), loss)
     m.check()
     got = m.params.to_dict()
-    worst = 0.0
+    worst, worst_k = 0.0, None
     for k, v in pt.items():
-        ref = v.numpy()
-        d = np.linalg.norm(got[k].astype(np.float64) - ref) / max(np.linalg.norm(ref), 1e-30)
-        worst = max(worst, d)
-        assert d <= 2e-5 or np.abs(got[k] - ref).max() <= 1e-6, (k, d)
+        mv_ref = v.numpy() - p64[k]
+        mv_hip = got[k].astype(np.float64) - p64[k]
+        if np.linalg.norm(mv_ref) < 1e-12:
+            continue
+        d = np.linalg.norm(mv_hip - mv_ref) / np.linalg.norm(mv_ref)
+        if d > worst:
+            worst, worst_k = d, k
     # the trajectory moved: 20 updates of lr-sized Adam steps, not a no-op
     moved = max(np.abs(got[k].astype(np.float64) - p64[k]).max() for k in p64)
-    print('  20 steps: worst loss rel %.2e, worst parameter rel-L2 %.2e, largest parameter movement %.2e' % (worst_loss, worst, moved))
+    print('  20 steps: worst loss rel %.2e, worst gnorm rel %.2e, worst movement rel-L2 %.2e (%s), largest parameter movement %.2e' %
+          (worst_loss, worst_gn, worst, worst_k, moved))
+    assert worst <= 2e-2, (worst_k, worst)
     assert moved > 5 * lr
 
 

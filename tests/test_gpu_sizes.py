@@ -279,3 +279,51 @@ def test_config1_peaked_attention_full_size(built_lib):
     assert ri1 < 1e-4 and mi3 < 5e-3
     ni = _argmax_check(Ri.al.cpu().numpy(), ai, inp['text_length'], min_margin=1e-2)
     assert ni >= 0.95 * B * Td
+
+
+def test_b1_inference_tolerates_a_co_tenant(built_lib):
+    """VERDICT r4 #7 / ADVICE r3: at B = 1 the decoder needs ONE cluster (32 workgroups on one XCD); the 224 workgroups of the
+    other seven clusters leave at kernel entry, so their CUs are free for whoever else uses the chip.  A co-tenant stand-in that
+    occupies 64 CUs for the whole call (64 workgroups x 256 threads x 64 KB of LDS, spinning 6 ms, dispatched FIRST on another
+    stream): the utterance completes with both error words clear, on the XCD-local exchange, and its persistent decoder kernel
+    within 10 % of its solo time (the feed-forward kernels around it share 256 - 64 CUs with the spinner and are slower by that)."""
+    import time
+    from tacotron_amd.config import Config
+    from tacotron_amd.data import synthetic_batch
+    from tacotron_amd.model import Tacotron
+    ci = Config()
+    ci.r, ci.vocab_size, ci.max_decode_iter = 2, 60, 180
+    mi = Tacotron(ci, synthetic_batch(1, 140, 180, 2, 60, seed=77, min_len=40), train=False, seed=0)
+    for _ in range(3):
+        mi.run()
+    torch.cuda.synchronize()
+    mi.check()
+    side = torch.cuda.Stream()
+
+    def timed(with_tenant):
+        built_lib.profile_read(0)
+        built_lib.profile_enable(1)
+        wall = []
+        for _ in range(7):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            if with_tenant:
+                built_lib.debug_spin(64, 256, 64 * 1024, 6000, stream=side)
+                time.sleep(0.0005)           # (the spinner is resident before the utterance is enqueued)
+            mi.run()
+            torch.cuda.current_stream().synchronize()
+            wall.append((time.perf_counter() - t0) * 1e3)
+            torch.cuda.synchronize()
+        built_lib.profile_enable(0)
+        dec = built_lib.profile_read(0)
+        return sorted(dec)[len(dec) // 2], sorted(wall)[len(wall) // 2]
+    dec_solo, wall_solo = timed(False)
+    dec_ten, wall_ten = timed(True)
+    err = mi._err.tolist()
+    census = mi.placement_census()
+    print('  B=1 decoder kernel: solo %.3f ms, beside a 64-CU co-tenant %.3f ms; whole call %.2f -> %.2f ms; err %s census %s' %
+          (dec_solo, dec_ten, wall_solo, wall_ten, err, census[:2]))
+    mi.check()
+    assert err == [0, 0]
+    assert census[1] == 0 and census[0] % 32 == 0      # every counted workgroup: one cluster of 32 on the XCD-local form
+    assert dec_ten <= 1.10 * dec_solo
