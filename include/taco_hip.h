@@ -196,7 +196,7 @@ int taco_debug_clock_probe(long long* out3, int iters, void* stream);
  * One launch of 64 small workgroups; out32 (device int64[32], zeroed by the caller) receives, in ticks of the 100 MHz counter,
  * the total of `iters` round trips of a granule ping-pong between two workgroups of ONE XCD with workgroup-scope stores [0]
  * (decoder3.hip's exchange) and agent-scope stores [1], between two XCDs [2] (decoder.hip's exchange), of `iters` dependent loads
- * that hit the L2 [3] / that miss every cache (walk over the whole scratch buffer, which should exceed 256 MB) [4], and the time
+ * that hit the L2 [3] / agent-scope loads of cold lines anywhere in the scratch buffer [4], and the time
  * one workgroup needs to stream 8 MB [5]; [6] = iters, [7] = ok bits, [8 + b] = XCC id of workgroup b < 24.
  * gran4k: 4 KiB of zeroed device memory; scratch: zeroed device memory, scratch_bytes >= 32 MiB.  No counterpart in the reference. */
 int taco_debug_fabric_probe(long long* out32, void* gran4k, const void* scratch, long long scratch_bytes, int iters, void* stream);

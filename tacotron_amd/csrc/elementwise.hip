@@ -802,8 +802,8 @@ int launch_clock_probe(long long* out, int iters, hipStream_t s) {
 //        blocks 1 <-> 9   the same with agent-scope stores (written through; decoder3's fallback form) -> out[1]
 //        blocks 2 <-> 3   agent scope, two DIFFERENT XCDs (decoder.hip's exchange)                     -> out[2]
 //        block  20        a chain of dependent loads over a warm 64 KB region (L2 hits)                 -> out[3]
-//        block  21        a chain of dependent loads over the whole scratch buffer (>= 512 MB: beyond the 256 MB Infinity
-//                         Cache, i.e. HBM round trips as the stash / prefetch traffic of the BPTT kernel pays them) -> out[4]
+//        block  21        a chain of dependent AGENT-SCOPE loads over the whole scratch buffer (cold lines: the memory-side
+//                         round trip an L2-bypassing load pays when no peer has just written the line)          -> out[4]
 //        block  22        64 lanes streaming 8 MB of the scratch buffer with 16-byte loads (one CU's stream bandwidth) -> out[5]
 //      Ticks are the constant 100 MHz counter; out[8 + b] = XCC id of block b (b < 24); out[6] = iterations, out[7] = ok flags.
 typedef unsigned long long fp_u64;
@@ -878,7 +878,10 @@ __global__ __launch_bounds__(64) void fabric_probe_kernel(long long* out, fp_u64
     const unsigned* base = b == 20 ? scratch + (16ll << 20) / 4 : scratch;   // (the streaming block reads the first 8 MB)
     const long long t0 = wall_clock64();
     for (int i = 0; i < iters; ++i) {
-      const unsigned v = base[idx * 32];   // (a plain load: the next index depends on it, so it can be neither hoisted nor dropped)
+      // block 20: a plain load (served by the L2 after the warm-up); block 21: an agent-scope load, which bypasses L1 AND is
+      // not served from another XCD's L2 -- the kind of load every exchange poll is, here on lines nobody has written lately
+      const unsigned v = b == 20 ? base[idx * 32]
+                                 : __hip_atomic_load((const __attribute__((address_space(1))) unsigned*)(base + idx * 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       idx = (idx * 1664525ull + 1013904223ull + v) & mask;   // (full-period LCG modulo 2^k)
     }
     const long long t1 = wall_clock64();

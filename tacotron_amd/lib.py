@@ -280,8 +280,8 @@ def clock_probe(iters=1 << 20):
 
 def fabric_probe(iters=2000, scratch_mb=768):
     """Latencies of this box that the latency-bound kernels wait on (include/taco_hip.h taco_debug_fabric_probe); host
-    synchronisation.  Returns ns per granule hop (one way) in the three exchange forms, ns per dependent load (L2 hit / miss of
-    every cache), the bandwidth one workgroup streams at, and which XCDs the probing workgroups ran on."""
+    synchronisation.  Returns ns per granule hop (one way) in the three exchange forms, ns per dependent load (plain, L2 hit / agent scope
+    on cold lines), the bandwidth one workgroup streams at, and which XCDs the probing workgroups ran on."""
     out = torch.zeros(32, dtype=torch.int64, device='cuda')
     gran = torch.zeros(512, dtype=torch.int64, device='cuda')
     scratch = torch.zeros(scratch_mb << 18, dtype=torch.int32, device='cuda')
@@ -299,7 +299,7 @@ def fabric_probe(iters=2000, scratch_mb=768):
     return {'hop_ns_same_xcd_l2_local': hop(res[0]) if ok & 1 else None,
             'hop_ns_same_xcd_agent_scope': hop(res[1]) if ok & 2 else None,
             'hop_ns_cross_xcd': hop(res[2]) if ok & 4 else None,
-            'load_ns_l2_hit': res[3] * 10.0 / n, 'load_ns_all_miss': res[4] * 10.0 / n,
+            'load_ns_l2_hit': res[3] * 10.0 / n, 'load_ns_agent_scope_cold': res[4] * 10.0 / n,
             'one_cu_stream_gb_s': (8 << 20) / (res[5] * 10e-9) / 1e9 if res[5] > 0 else None,
             'xcc_of_pairs': {'l2_local': [xcc[0], xcc[8]], 'agent': [xcc[1], xcc[9]], 'cross': [xcc[2], xcc[3]]},
             'scratch_mb': scratch_mb}
