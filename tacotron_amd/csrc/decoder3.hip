@@ -180,6 +180,32 @@ constexpr bool kGroupedFanDq = true;   // FAN / DQ rounds of the BPTT kernel: on
 #else
 constexpr bool kGroupedFanDq = false;
 #endif
+// tanh(keys + q) of the attention rounds from a PRODUCT of exponentials (round 5).  tanh(x) = 1 - 2 / (1 + exp(2 x)) costs two
+// quarter-rate instructions per element (v_exp_f32, v_rcp_f32); with exp(2 (k + q)) = exp(2 k) exp(2 q) the key factor is formed
+// once per launch (the keys are launch-resident anyway) and the query factor once per step and unit, which leaves ONE
+// transcendental per element: r = rcp(fma(ka, qb, 1)), tanh = 1 - 2 r, 1 - tanh^2 = 4 r (1 - r).  Both factors stay normal
+// numbers for |k|, |q| <= 40 (exp2(+-115)); a wave that holds a key beyond that, or sees a query beyond it in some step, takes the
+// exact sum form for that step (wave-uniform branch, keys re-read from memory) -- results never depend on the bound.  The
+// relative error of exp(2 x) is ~|2 x log2 e| 2^-24 ln 2 in either form; the product form pays |k| + |q| where the sum form
+// pays |k + q|.  -DTACO_NO_TANH_SPLIT: the sum form everywhere (A/B builds).
+#if !defined(TACO_NO_TANH_SPLIT)
+constexpr bool kTanhSplit = true;
+#else
+constexpr bool kTanhSplit = false;
+#endif
+// The BPTT kernel's energy backward uses the same factors (1 - tanh^2 = 4 r (1 - r), which unlike 1 - th * th does not cancel near
+// saturation), as TWO unswitched passes chosen by one wave-uniform branch per step: with the exact-form fallback INSIDE the
+// (memory row, batch row) loop the kernel got slower (13.55 -> 13.95 us per step), as two passes faster (13.61 -> 13.50;
+// profiles/r05_tanh_ab.txt).  -DTACO_NO_TANH_SPLIT_BWD: the sum form (A/B builds).
+#if !defined(TACO_NO_TANH_SPLIT_BWD) && !defined(TACO_NO_TANH_SPLIT)
+constexpr bool kTanhSplitB = true;
+#else
+constexpr bool kTanhSplitB = false;
+#endif
+constexpr float kTwoLog2e = 2.8853900817779268f;
+constexpr float kTanhBound = 40.f;
+__device__ __forceinline__ float exp2_2x(float x) { return __builtin_amdgcn_exp2f(kTwoLog2e * x); }   // exp(2 x)
+
 template <int KPLG0, int MODE>
 struct EShadowSplit {
   static constexpr int lo = 4;                                                   // first weight register behind the pre-net rows
@@ -778,6 +804,17 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
     }
   }
   const float4 v4 = reinterpret_cast<const float4*>(w.att_v)[lane];
+  // (kTanhSplit) the resident keys become their factors exp(2 k); kbig: this WAVE holds a key beyond the bound and scores with
+  // the exact form (keys re-read) in every step
+  bool kbig = false;
+  if constexpr (kTanhSplit) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      kbig |= fmaxf(fmaxf(fabsf(kres[i].x), fabsf(kres[i].y)), fmaxf(fabsf(kres[i].z), fabsf(kres[i].w))) > kTanhBound;
+      kres[i] = make_float4(exp2_2x(kres[i].x), exp2_2x(kres[i].y), exp2_2x(kres[i].z), exp2_2x(kres[i].w));
+    }
+    kbig = __any(kbig) != 0;
+  }
   __syncthreads();
 
   float* const H1 = U0 + KA * R;     // h of GRU-1 lives behind [p2 ; out]
@@ -1148,13 +1185,43 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
         // the wave's four slots together: four independent partial sums per lane, ONE reduction of all four (col_sum_all), and
         // the result lane of slot i publishes it -- instead of four dependent {score, wave sum, branch, publish} sequences
         Acc<4> e4;
+        if constexpr (kTanhSplit) {
+          // (slot g = i 256 + wave 32 + peer scores row g % R = peer % R for every i: one query per lane and step)
+          const float4 q4 = reinterpret_cast<const float4*>(QS + (peer % R) * kAtt)[L.lane];
+          const bool qbig = fmaxf(fmaxf(fabsf(q4.x), fabsf(q4.y)), fmaxf(fabsf(q4.z), fabsf(q4.w))) > kTanhBound;
+          {
+            const float4 b4 = make_float4(exp2_2x(q4.x), exp2_2x(q4.y), exp2_2x(q4.z), exp2_2x(q4.w));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int g = i * 256 + L.wave * 32 + peer;
-          const float4 q4 = reinterpret_cast<const float4*>(QS + (g % R) * kAtt)[L.lane];
-          const float4 k4 = kres[i];
-          e4.v[i] = v4.x * tanh_fast(k4.x + q4.x) + v4.y * tanh_fast(k4.y + q4.y) + v4.z * tanh_fast(k4.z + q4.z) +
-                    v4.w * tanh_fast(k4.w + q4.w);
+            for (int i = 0; i < 4; ++i) {
+              const float4 ka = kres[i];
+              const float tx = fmaf(-2.f, __builtin_amdgcn_rcpf(fmaf(ka.x, b4.x, 1.f)), 1.f);
+              const float ty = fmaf(-2.f, __builtin_amdgcn_rcpf(fmaf(ka.y, b4.y, 1.f)), 1.f);
+              const float tz = fmaf(-2.f, __builtin_amdgcn_rcpf(fmaf(ka.z, b4.z, 1.f)), 1.f);
+              const float tw = fmaf(-2.f, __builtin_amdgcn_rcpf(fmaf(ka.w, b4.w, 1.f)), 1.f);
+              e4.v[i] = v4.x * tx + v4.y * ty + v4.z * tz + v4.w * tw;
+            }
+          }
+          if (__builtin_expect(kbig || __any(qbig), 0)) {   // a key or a query beyond the bound: the exact form on keys re-read from memory
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int g = i * 256 + L.wave * 32 + peer;
+              const int rho = g % R, sidx = g / R;
+              const float4 k4 = sidx < rsel<R>(len, rho)
+                                    ? reinterpret_cast<const float4*>(a.keys + ((int64_t)rsel<R>(brow, rho) * Tt + sidx) * kAtt)[L.lane]
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+              e4.v[i] = v4.x * tanh_fast(k4.x + q4.x) + v4.y * tanh_fast(k4.y + q4.y) + v4.z * tanh_fast(k4.z + q4.z) +
+                        v4.w * tanh_fast(k4.w + q4.w);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int g = i * 256 + L.wave * 32 + peer;
+            const float4 q4 = reinterpret_cast<const float4*>(QS + (g % R) * kAtt)[L.lane];
+            const float4 k4 = kres[i];
+            e4.v[i] = v4.x * tanh_fast(k4.x + q4.x) + v4.y * tanh_fast(k4.y + q4.y) + v4.z * tanh_fast(k4.z + q4.z) +
+                      v4.w * tanh_fast(k4.w + q4.w);
+          }
         }
         col_sum_all<4, 64>(e4);
         const int i = rs_rho<4, 64>(L.lane);   // result lane of slot i
@@ -1383,6 +1450,7 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
   WReg<8> wc0, wc1, wc2;                                  // wT.cw[l] (256, 512): column unit (lanes 0-31) / 256 + unit (lanes 32-63)
   WReg<16> wg0, wg1, wg2;                                 // wT.gw[l] (512, 512): likewise
   float4 vres[4];
+  bool kbig_b = false;   // (kTanhSplit) this wave holds a key beyond the bound
   {
     load_w<4, 64>(wdp2, w.in_w, kPre2 + kAtt, kDec, peer * 4 + (wave & 3), lane, wave < 4);
     load_w<2, 64>(wdp1, w.pre_w2, kPre1, kPre2, unit, lane, true);
@@ -1420,11 +1488,14 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int sx = lane + 64 * i;
-        KR[i * NT * R + q] = sx < ln ? kb[(int64_t)sx * kAtt + unit] : 0.f;
+        const float kv = sx < ln ? kb[(int64_t)sx * kAtt + unit] : 0.f;
+        if (kTanhSplitB) kbig_b |= fabsf(kv) > kTanhBound;
+        KR[i * NT * R + q] = kTanhSplitB ? exp2_2x(kv) : kv;   // (kTanhSplit: the key's factor exp(2 k), see the forward kernel)
         DKR[i * NT * R + q] = 0.f;
       }
     });
   }
+  if (kTanhSplitB) kbig_b = __any(kbig_b) != 0;
   const float vu = a.att_v[unit];
   Acc<R> dvu;      // d attention_v[unit] per row: this lane's partial over its memory rows, all steps
   dvu.zero();
@@ -1656,23 +1727,63 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
         float* const KR = smem + D::o_kr + L.tid * R;
         float* const DKR = smem + D::o_dkr + L.tid * R;
         const XV<R> qv = lds_rows<R>(OWN + (D::w_q * 8 + L.wave) * R);
+        // one pass over the wave's 4 x R (memory row, batch row) elements; PRODUCT: tanh from the resident key factors (kTanhSplitB)
+        auto pass = [&](auto product_c, const XV<R>& qf) __attribute__((always_inline)) {
+          constexpr bool product = decltype(product_c)::value;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const XV<R> kr = lds_rows<R>(KR + i * NT * R);
-          XV<R> dk = lds_rows<R>(DKR + i * NT * R);
-          const XV<R> dev = lds_rows<R>(DES + (L.lane + 64 * i) * R);   // de of the R rows (zero past text_length: the softmax backward wrote al = 0 there)
+          for (int i = 0; i < 4; ++i) {
+            XV<R> kr = lds_rows<R>(KR + i * NT * R);
+            XV<R> dk = lds_rows<R>(DKR + i * NT * R);
+            const XV<R> dev = lds_rows<R>(DES + (L.lane + 64 * i) * R);   // de of the R rows (zero past text_length: the softmax backward wrote al = 0 there)
+            if constexpr (kTanhSplitB && !product) {   // exact form: the raw keys, re-read (the slots hold their factors)
+              static_for<R>([&](auto Q) {
+                constexpr int q = decltype(Q)::value;
+                const int sx = L.lane + 64 * i;
+                kr.v[q] = sx < len.template get<q>() ? a.keys[((int64_t)brow.template get<q>() * Tt + sx) * kAtt + u] : 0.f;
+              });
+            }
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+              const float de = dev.v[q];
+              float th, pre;
+              if constexpr (product) {
+                const float r = __builtin_amdgcn_rcpf(fmaf(kr.v[q], qf.v[q], 1.f));
+                th = fmaf(-2.f, r, 1.f);
+                pre = (de * (4.f * vu)) * fmaf(-r, r, r);          // 1 - th^2 = 4 r (1 - r)
+              } else if constexpr (kTanhSplitB) {
+                // (the exact-form fallback is taken in the saturated regime: there 1 - th * th cancels to zero in fp32 -- measured
+                //  6e-4 on the attention gradients of the queries-beyond-bound test -- while 4 r (1 - r) keeps its digits)
+                //  E = exp(2 x), s = 1 / (1 + E):  1 - th^2 = 4 E s^2 = 4 s (1 - s); the first form keeps its digits for E < 1
+                //  (x < 0, where 1 + E rounds to 1 and 1 - s to 0), the second for E >= 1 (where E s^2 would be inf * 0))
+                const float E = exp2_2x(kr.v[q] + qf.v[q]);
+                const float r = __builtin_amdgcn_rcpf(1.f + E);
+                th = fmaf(-2.f, r, 1.f);
+                pre = (de * (4.f * vu)) * (E < 1.f ? (E * r) * r : fmaf(-r, r, r));
+              } else {
+                th = tanh_fast(kr.v[q] + qf.v[q]);
+                pre = de * vu * (1.f - th * th);
+              }
+              dq.v[q] += pre;
+              dk.v[q] += pre;
+              dvu.v[q] += de * th;
+            }
+            if constexpr (R == 4) *reinterpret_cast<float4*>(DKR + i * NT * R) = make_float4(dk.v[0], dk.v[1], dk.v[2], dk.v[3]);
+            else if constexpr (R == 2) *reinterpret_cast<float2*>(DKR + i * NT * R) = make_float2(dk.v[0], dk.v[1]);
+            else DKR[i * NT * R] = dk.v[0];
+          }
+        };
+        if constexpr (kTanhSplitB) {
+          bool qbig = false;
+          XV<R> qb;
 #pragma unroll
           for (int q = 0; q < R; ++q) {
-            const float de = dev.v[q];
-            const float th = tanh_fast(kr.v[q] + qv.v[q]);
-            const float pre = de * vu * (1.f - th * th);
-            dq.v[q] += pre;
-            dk.v[q] += pre;
-            dvu.v[q] += de * th;
+            qbig |= fabsf(qv.v[q]) > kTanhBound;
+            qb.v[q] = exp2_2x(qv.v[q]);
           }
-          if constexpr (R == 4) *reinterpret_cast<float4*>(DKR + i * NT * R) = make_float4(dk.v[0], dk.v[1], dk.v[2], dk.v[3]);
-          else if constexpr (R == 2) *reinterpret_cast<float2*>(DKR + i * NT * R) = make_float2(dk.v[0], dk.v[1]);
-          else DKR[i * NT * R] = dk.v[0];
+          if (__builtin_expect(!(kbig_b || __any(qbig)), 1)) pass(std::true_type{}, qb);
+          else pass(std::false_type{}, qv);
+        } else {
+          pass(std::false_type{}, qv);
         }
       }
       float dqv = 0.f;
