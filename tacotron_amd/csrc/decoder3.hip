@@ -92,6 +92,33 @@ __device__ __forceinline__ void put_granule(const Xc& X, int reg, int n, int rho
   else __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Round 5 (late): the poll loop is WAVE-UNIFORM.  Round 3/4's form let every lane leave the loop when its own unit had arrived; the
+// structurizer turns that into ~70 scalar exec-mask instructions per poll iteration (nested saveexec / andn2 / or chains around
+// one buffer load and two compares) -- 1,500 of the step's 4,000 instructions per wave, sitting between "granule arrived" and
+// "round continues".  Now a wave polls until ALL of its lanes have their units (one ballot, one scalar branch per iteration);
+// lanes without a unit load from beyond the buffer's range (returns zeros, no memory access) instead of being masked off, the LDS
+// puts happen once behind the loop.  Re-reading a unit that has already arrived is safe for the reason a late first read is: no
+// peer can publish the region's next epoch before this workgroup has passed the barrier behind this gather.
+// The launch-fatal flag (`dead`, LDS) is no longer read at the head of every gather (an LDS round trip in front of the first poll
+// of every round): a dead launch is noticed through the global error word at the 8th poll of a gather, then every 1,024th.
+// -DTACO_NO_UNIPOLL: the per-lane form (A/B builds).
+#if !defined(TACO_NO_UNIPOLL)
+constexpr bool kUniPoll = true;
+#else
+constexpr bool kUniPoll = false;
+#endif
+__device__ __forceinline__ bool spin_fail_uniform(unsigned& spin, const Xc& X) {
+  if ((++spin & 1023u) == 8u) {
+    const int e = __hip_atomic_load((gi32*)X.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (spin > (1u << 23) || __builtin_amdgcn_ballot_w64(e != 0) != 0) {
+      __hip_atomic_store((gi32*)X.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *X.dead = 1;
+      return true;
+    }
+  }
+  __builtin_amdgcn_s_sleep(1);
+  return false;
+}
 __device__ __forceinline__ bool spin_fail(unsigned& spin, const Xc& X) {
   if ((++spin & 1023u) == 0u) {
     if (spin > (1u << 23) || __hip_atomic_load((gi32*)X.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
@@ -260,9 +287,18 @@ template <int R, int MAXU, int NP, class Col>
 __device__ __forceinline__ void poll_batch(Xc& X, GatherState<R, MAXU>& S, Col col) {
   constexpr int G = GatherState<R, MAXU>::G;
   if (kProbes3) X.polls++;
+  if constexpr (kUniPoll && G == 2 && kPoll128) {
 #pragma unroll
-  for (int i = 0; i < MAXU; ++i)
-    if (S.pend[i]) S.g[i] = poll_unit<G>(X, (unsigned)(col(S.un[i]) * R + S.uh[i] * G));
+    for (int i = 0; i < MAXU; ++i) {   // (lanes without a unit: an offset beyond num_records -- the load returns zeros and touches no memory)
+      const unsigned ofs = S.pend[i] ? (unsigned)(col(S.un[i]) * R + S.uh[i] * G) * 8u : 0x7ffffff0u;
+      const v4u g = __builtin_amdgcn_raw_buffer_load_b128(X.rs, ofs, 0, 16 /* sc1 */);
+      S.g[i].val[0] = g[0]; S.g[i].tag[0] = g[1]; S.g[i].val[1] = g[2]; S.g[i].tag[1] = g[3];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i)
+      if (S.pend[i]) S.g[i] = poll_unit<G>(X, (unsigned)(col(S.un[i]) * R + S.uh[i] * G));
+  }
 }
 template <int R, int MAXU, int NP = NT, class Col, class Own>
 __device__ __forceinline__ GatherState<R, MAXU> gather_begin(Xc& X, Col col, int N, Own own) {
@@ -271,7 +307,8 @@ __device__ __forceinline__ GatherState<R, MAXU> gather_begin(Xc& X, Col col, int
   static_assert(NP % 64 == 0 && NP <= NT, "pollers are whole waves");
   GatherState<R, MAXU> S;
   const int tid = opaque_tid();
-  const bool skip = (NP < NT && tid >= NP) || *X.dead || (kProbes3 && (X.fake & 2));
+  bool skip = (NP < NT && tid >= NP) || (kProbes3 && (X.fake & 2));
+  if constexpr (!kUniPoll) skip = skip || *X.dead;
   S.any = false;
 #pragma unroll
   for (int i = 0; i < MAXU; ++i) {
@@ -281,6 +318,7 @@ __device__ __forceinline__ GatherState<R, MAXU> gather_begin(Xc& X, Col col, int
     S.pend[i] = !skip && S.un[i] < N && !own(S.un[i]);
     S.any |= S.pend[i];
   }
+  if constexpr (kUniPoll) S.any = __builtin_amdgcn_ballot_w64(S.any) != 0;   // wave-uniform from here on
   if (S.any) poll_batch<R, MAXU, NP>(X, S, col);
   return S;
 }
@@ -288,6 +326,35 @@ template <int R, int MAXU, int NP = NT, class Col, class Put, class Need = NeedA
 __device__ __forceinline__ void gather_end(Xc& X, GatherState<R, MAXU>& S, Col col, Put put, Need need = Need()) {
   constexpr int G = GatherState<R, MAXU>::G;
   unsigned spin = 0;
+  if constexpr (kUniPoll) {
+    if (S.any) {
+      bool failed = false;
+      for (;;) {
+        bool miss = false;
+#pragma unroll
+        for (int i = 0; i < MAXU; ++i)
+#pragma unroll
+          for (int q = 0; q < G; ++q) miss |= S.pend[i] & (S.g[i].tag[q] != X.epoch) & need(S.un[i], S.uh[i] * G + q);
+        if (__builtin_amdgcn_ballot_w64(miss) == 0) break;
+        if (spin_fail_uniform(spin, X)) {   // (fatal: the error word is set)
+          failed = true;
+          break;
+        }
+        poll_batch<R, MAXU, NP>(X, S, col);
+      }
+      if (!failed) {
+#pragma unroll
+        for (int i = 0; i < MAXU; ++i)
+          if (S.pend[i]) {
+#pragma unroll
+            for (int q = 0; q < G; ++q)
+              if (need(S.un[i], S.uh[i] * G + q)) put(S.un[i], S.uh[i] * G + q, __uint_as_float(S.g[i].val[q]));
+          }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    return;
+  }
   while (S.any) {
     S.any = false;
 #pragma unroll
