@@ -116,7 +116,9 @@ __device__ __forceinline__ bool spin_fail_uniform(unsigned& spin, const Xc& X) {
       return true;
     }
   }
+#if !defined(TACO_POLL_NOSLEEP)
   __builtin_amdgcn_s_sleep(1);
+#endif
   return false;
 }
 __device__ __forceinline__ bool spin_fail(unsigned& spin, const Xc& X) {
@@ -912,11 +914,8 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
       const int n = i / R, q = i - n * R;
       U0[n * R + q] = a.pre2[(unsigned)(rsel<R>(brow, q) * Td) * ldp2 + n];
     }
-    if (a.prein && lead && tid < kMel * R) {   // pre-net input frame of step 0 (train stash for the layer-1 weight gradient)
-      const int q = tid / kMel, i = tid - q * kMel;
-      if (rsel<R>(valid, q))
-        a.prein[((int64_t)rsel<R>(brow, q) * Td) * kMel + i] = a.mel[((int64_t)rsel<R>(brow, q) * Td) * R80 + kMel * (RR - 1) + i];
-    }
+    // (a.prein, the pre-net input frames kept for the layer-1 weight gradient: model.hip copies the teacher frames of ALL steps
+    //  before the launch; this kernel only writes the frames of steps fed by the previous output, in round OUT)
   } else {
     for (int i = tid; i < kPre1 * R; i += NT) P1[i] = fmaxf(w.pre_b1[i / R], 0.f);
     __syncthreads();
@@ -940,19 +939,15 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
   // sampling flags.  They are parked RAW: any arithmetic on a loaded value (byte -> multiplier, byte -> bool, a register copy)
   // makes the compiler wait for the load on the spot -- with the in-order counter that is a wait for every parked load, i.e. a
   // full HBM round trip exposed once per step.  Conversions happen at the use sites (rounds OUT / E of the next step).
-  float p2n = 0.f, frn = 0.f;
+  float p2n = 0.f;
   unsigned k1n = 1, k2n = 1;
   unsigned fon[R];
 #pragma unroll
   for (int q = 0; q < R; ++q) fon[q] = 0;
   // Their addresses are `base + tn * stride` with launch-constant bases (-1: this lane has no such load): four registers, set
   // up once, instead of ~100 address instructions per step in the instruction stream behind round E.
-  int pk_fr = -1, pk_p2 = -1, pk_k1 = -1, pk_k2 = -1;
+  int pk_p2 = -1, pk_k1 = -1, pk_k2 = -1;
   if (TR) {
-    if (a.prein && lead && tid < kMel * R) {   // teacher frame of step tn (the pre-net weight gradient reads a.prein for every step)
-      const int q = tid / kMel, i = tid - q * kMel;
-      pk_fr = rsel<R>(brow, q) * Td * R80 + kMel * (RR - 1) + i;
-    }
     if (tid < kPre2 * R) {
       const int n = tid / R, q = tid - n * R;
       pk_p2 = rsel<R>(brow, q) * Td * (int)ldp2 + n;
@@ -966,7 +961,6 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
   auto park_next = [&](int tn) {
     p2n = 0.f;
     k1n = k2n = 1;
-    frn = 0.f;
 #pragma unroll
     for (int q = 0; q < R; ++q) fon[q] = 0;
 #ifdef TACO_P_NOPARK
@@ -974,13 +968,15 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
 #else
     if (TR && tn < Td) {
 #endif
+#ifdef TACO_P_PARKHOT
+      tn = 1;   // timing probe: the same loads from lines that are L2-resident (issue cost without the miss latency; garbage results)
+#endif
       if (a.sample) {   // step tn - 1's flags: row q of step tn is fed by that step's output
         static_for<R>([&](auto Q) {
           constexpr int q = decltype(Q)::value;
           fon[q] = a.sample[(unsigned)((tn - 1) * B + brow.template get<q>())];
         });
       }
-      if (pk_fr >= 0) frn = a.mel[(unsigned)(pk_fr + tn * R80)];
       if (pk_p2 >= 0) p2n = a.pre2[(unsigned)(pk_p2 + tn * (int)ldp2)];
       if (pk_k1 >= 0) k1n = a.keep1[(unsigned)(pk_k1 + tn * kPre1)];
       if (pk_k2 >= 0) k2n = a.keep2[(unsigned)(pk_k2 + tn * kPre2)];
@@ -1351,14 +1347,13 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
             [&](int n, int q) { return n < kPre2 || n - kPre2 < rsel<R>(len, q); });
       }
       tstamp(X);   // E: gathered (before the deferred stores / next-step prefetch)
+#ifdef TACO_P_NOTAIL
+      if (false) {   // timing probe: no deferred stores behind round E (the stash misses p2 of sampled rows, prein is not written)
+#else
       if (TR && has_next) {
+#endif
         if (sb64 >= 0 && L.wave < 4 && rsel<R>(from_out, L.rho))
           stash[(unsigned)(sb64 * Td + t + 1) * kStRec + kStP2 + n4] = y2;
-        // teacher frames of step t+1 for the pre-net weight gradient (model.hip reads a.prein for every step)
-        if (a.prein && lead && L.tid < kMel * R) {
-          const int q = L.tid / kMel, i = L.tid - q * kMel;
-          if (!rsel<R>(from_out, q) && rsel<R>(valid, q)) a.prein[(unsigned)(rsel<R>(brow, q) * Td + t + 1) * kMel + i] = frn;
-        }
       }
       park_next(t + 2);
       tstamp(X);

@@ -420,6 +420,11 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
   // the decoder's exchange area (granule epochs of the previous launch): zeroed by the same launch; decoder3.hip then issues no
   // memset in front of the forward decoder (decoder.hip, the fallback, still zeroes for itself)
   TACO_TRY(ib.fill(ws + W.xchg, decoder_xchg_bytes(B, Tt) / 4));
+  // pre-net input frames of the TEACHER-FORCED steps (the layer-1 weight gradient reads W.prein for every step): the last frame of
+  // mel[t], known now -- copied here instead of being loaded and stored frame by frame by the lead workgroup of every decoder
+  // cluster behind round E (the lead is on every peer's critical path).  decoder3.hip writes only the frames of steps that are fed
+  // by the previous output (scheduled sampling); decoder.hip, the fallback, still writes all of them itself.
+  if (train) TACO_TRY(ib.copy2d(ws + W.prein, kMel, mel + kMel * (r - 1), R80, B * Td, kMel));
   TACO_TRY(build_dec_composites(P, PL, W, ws, r, ib, sd));
   if (train) {
     // everything the backward pass derives from the parameters alone (transposed / tap-flipped weight copies, transposed
