@@ -116,9 +116,12 @@ __device__ __forceinline__ bool spin_fail_uniform(unsigned& spin, const Xc& X) {
       return true;
     }
   }
-#if !defined(TACO_POLL_NOSLEEP)
-  __builtin_amdgcn_s_sleep(1);
+#ifndef TACO_POLL_SLEEP
+#define TACO_POLL_SLEEP 1
 #endif
+  // (measured on the wave-uniform loop, profiles/r05_unipoll_knobs.txt: sleeping only on long waits, or not at all, gains 0.05 us
+  //  per step in the forward kernel and LOSES 0.13 in the BPTT kernel -- its re-polls compete with the stash prefetch for the L2)
+  if (TACO_POLL_SLEEP > 0) __builtin_amdgcn_s_sleep(TACO_POLL_SLEEP);
   return false;
 }
 __device__ __forceinline__ bool spin_fail(unsigned& spin, const Xc& X) {
@@ -963,7 +966,12 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
     k1n = k2n = 1;
 #pragma unroll
     for (int q = 0; q < R; ++q) fon[q] = 0;
-#ifdef TACO_P_NOPARK
+#ifdef TACO_P_PARKOPAQUE   // timing probe: the parked values come out of opaque moves instead of loads (nothing folds; garbage results)
+    asm volatile("" : "+v"(p2n), "+v"(k1n), "+v"(k2n));
+#pragma unroll
+    for (int q = 0; q < R; ++q) asm volatile("" : "+v"(fon[q]));
+    if (false) {
+#elif defined(TACO_P_NOPARK)
     if (false) {   // timing probe: no next-step input loads at all (results are garbage)
 #else
     if (TR && tn < Td) {
