@@ -203,7 +203,7 @@ def ab_gemm(model, rounds=3, steps=8):
 
 def ab_decoder(rounds=3):
     """In-run A/B of decoder builds: the product library against libtaco_prevdec.so (the same sources with the previous decoder
-    form: -DTACO_NO_RS -DTACO_NO_POLL128 -DTACO_NO_SHADOW -DTACO_NO_GROUPED_FANDQ), alternated `rounds` times on this box
+    form: -DTACO_NO_RS -DTACO_NO_POLL128 -DTACO_NO_SHADOW -DTACO_NO_GROUPED_FANDQ -DTACO_NO_UNIPOLL -DTACO_NO_TANH_SPLIT), alternated `rounds` times on this box
     (one short subprocess each: tools/dec_quick.py --json, S1 shape)."""
     import subprocess
     libs = {'current': os.path.join(ROOT, 'tacotron_amd', 'libtaco_hip.so'), 'previous_form': os.path.join(ROOT, 'tacotron_amd', 'libtaco_prevdec.so')}
@@ -223,8 +223,8 @@ def ab_decoder(rounds=3):
     if not all(runs.values()):
         return None
     med = lambda k, f: sorted(x[f] for x in runs[k])[len(runs[k]) // 2]   # noqa: E731
-    return {'what': 'S1 train step: product build vs the previous decoder form (round 3 column sums / 8-byte polls / no poll-shadow '
-                    'work), %d alternations on this box' % rounds,
+    return {'what': 'S1 train step: product build vs the round-3 decoder form (column sums by wave / 8-byte polls / no poll-shadow work / '
+                    'per-lane poll loops / tanh in its sum form), %d alternations on this box' % rounds,
             **{k: {'ms_per_step': med(k, 'ms_per_step'), 'us_per_decoder_step_fwd': med(k, 'us_per_decoder_step_fwd'),
                    'us_per_decoder_step_bwd': med(k, 'us_per_decoder_step_bwd'), 'runs': len(runs[k])} for k in libs}}
 

@@ -22,9 +22,10 @@ hipcc $FLAGS -DTACO_DEC_PROBES -c decoder.hip -o ../../build/obj/decoder_probe.o
 pids+=($!)
 hipcc $FLAGS $D3FLAGS -DTACO_DEC_PROBES -c decoder3.hip -o ../../build/obj/decoder3_probe.o &
 pids+=($!)
-# the previous decoder form (round 3's column sums, 8-byte polls, no poll-shadow work): bench.py alternates it with the product build
-# on the box it runs on (`ab.decoder`), so that a decoder gain or loss is visible on the driver's box and not only on the builder's
-hipcc $FLAGS $D3FLAGS -DTACO_NO_RS -DTACO_NO_POLL128 -DTACO_NO_SHADOW -DTACO_NO_GROUPED_FANDQ -c decoder3.hip -o ../../build/obj/decoder3_prev.o &
+# the round-3 decoder form (column sums by wave, 8-byte polls, no poll-shadow work, per-lane poll loops, tanh in its sum form; this
+# round's compiler flags): bench.py alternates it with the product build on the box it runs on (`ab.decoder`), so that a decoder gain
+# or loss is visible on the driver's box and not only on the builder's
+hipcc $FLAGS $D3FLAGS -DTACO_NO_RS -DTACO_NO_POLL128 -DTACO_NO_SHADOW -DTACO_NO_GROUPED_FANDQ -DTACO_NO_UNIPOLL -DTACO_NO_TANH_SPLIT -c decoder3.hip -o ../../build/obj/decoder3_prev.o &
 pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT ../../build/obj/{gemm,gemm2,vocoder,elementwise,bigru,decoder,decoder3,highway,prenet,layout,model}.o

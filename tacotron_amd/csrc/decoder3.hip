@@ -736,7 +736,11 @@ struct Lane {
   __device__ __forceinline__ Lane() {
     tid = opaque_tid();
     lane = tid & 63;
+#if defined(TACO_SWAVE)
+    wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: what depends on it alone is scalar code (branches, not exec masks)
+#else
     wave = tid >> 6;
+#endif
     lk = lane & (LPC - 1);
     rho = rs_rho<R, LPC>(lk);
     res = rho >= 0;
