@@ -505,9 +505,32 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTnArgs& P, const int bx, 
   }
 }
 
+// XCD-aware block order of the weight-gradient launches (round 5).  The dispatcher deals consecutive workgroups round-robin to the 8
+// XCDs, so the gx * gy output tiles of ONE row-range slice z -- which all read the same rows of A and dY -- used to be spread over
+// all eight L2s: every L2 fetched (nearly) every slice, up to 8 x the operand bytes over the fabric (profiles/r05_pmc_step.txt:
+// 2.75 GB fetched per step by these kernels for ~0.4 GB of operands).  With this order slice z is worked on by XCD z % 8 alone: the
+// s-th workgroup that lands on XCD x takes tile s % per of slice x + 8 (s / per).  Slices beyond the last multiple of 8 keep the
+// plain order.  L: linear workgroup index within the problem (its first workgroup is at a multiple of 8 of the grid).
+__device__ __forceinline__ void tn_xcd_order(int L, int per, int gz, bool on, int& t, int& z) {
+  const int zfull = gz & ~7;
+  if (on && L < per * zfull) {
+    const int x = L & 7, s = L >> 3;
+    const int g = s / per;
+    z = x + 8 * g;
+    t = s - g * per;
+  } else {
+    z = L / per;
+    t = L - z * per;
+  }
+}
+
 template <int WM, int WN, bool VA, bool VB, bool BX = false>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs P) {
-  gemm_tn_body<WM, WN, VA, VB, BX>(P, blockIdx.x, blockIdx.y, blockIdx.z);
+  const int gx = gridDim.x, per = gx * gridDim.y;
+  int t, z;
+  tn_xcd_order(blockIdx.x + gx * (blockIdx.y + gridDim.y * blockIdx.z), per, gridDim.z, P.xcd != 0, t, z);
+  const int by = t / gx;
+  gemm_tn_body<WM, WN, VA, VB, BX>(P, t - by * gx, by, z);
 }
 
 // Grouped launch: independent weight-gradient GEMMs (all 64x64 tiles, vector contract) share ONE grid; block -> problem
@@ -518,12 +541,13 @@ __global__ __launch_bounds__(256) void gemm_tn_batch_kernel(GemmTnBatch B) {
   for (int i = 1; i < B.n; ++i)
     if ((int)blockIdx.x >= B.first[i]) pi = i;
   const GemmTnArgs& P = B.p[pi];
-  int rel = blockIdx.x - B.first[pi];
-  const int gx = B.gx[pi], gy = B.gy[pi];
-  const int bz = rel / (gx * gy);
-  rel -= bz * gx * gy;
-  const int by = rel / gx, bx = rel - by * gx;
-  gemm_tn_body<1, 1, true, true, BX>(P, bx, by, bz);
+  const int rel = blockIdx.x - B.first[pi];   // (B.first[] are multiples of 8: a problem's workgroup `rel` runs on XCD rel % 8)
+  const int gx = B.gx[pi], per = gx * B.gy[pi], gz = P.batch * P.taps * P.splits;
+  if (rel >= per * gz) return;                 // padding up to the next problem's first workgroup
+  int t, z;
+  tn_xcd_order(rel, per, gz, P.xcd != 0, t, z);
+  const int by = t / gx;
+  gemm_tn_body<1, 1, true, true, BX>(P, t - by * gx, by, z);
 }
 
 __global__ void gemm_naive_kernel(ConvGemmProblem P) {
@@ -778,6 +802,8 @@ static int plan_gemm_tn(GemmTnArgs& a, bool force_small, dim3& grid, int64_t gro
   a.splits = splits;
   a.chunk = chunk;
   grid = dim3(cdiv(a.K, bm), cdiv(a.N, bm), a.batch * a.taps * splits);
+  static const int xcd = [] { const char* e = getenv("TACO_TN_XCD"); return e ? atoi(e) : 1; }();   // XCD-aware block order (0: plain)
+  a.xcd = xcd;
   return bm;
 }
 
@@ -854,6 +880,7 @@ int launch_gemm_tn_batch(GemmTnBatch& b, hipStream_t stream) {
     grouped.gx[j] = (int)grid.x;
     grouped.gy[j] = (int)grid.y;
     blocks += (int)(grid.x * grid.y * grid.z);
+    blocks = (blocks + 7) & ~7;   // every problem starts on XCD 0 (tn_xcd_order); the <= 7 padding workgroups return at once
   }
   if (nbig > 0) {
     const int pslot = taco_prof_begin(2, stream);

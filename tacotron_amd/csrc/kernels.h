@@ -62,6 +62,7 @@ struct GemmTnArgs {
   int64_t strideA = 0, strideY = 0, strideW = 0;
   int splits = 1, chunk = 0, flags = 0;
   int Nld = 0;   // loadable Y columns (>= N, multiple of 4, <= ldy) when Y rows are zero-padded; 0 = derive from N
+  int xcd = 0;   // 1: XCD-aware block order (set by the launcher, gemm.hip `tn_xcd_order`)
 };
 
 int launch_conv_gemm_batch(ConvGemmBatch& batch, hipStream_t stream);
