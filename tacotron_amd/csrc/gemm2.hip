@@ -96,7 +96,9 @@ struct Gemm2Args {
   ConvGemmBatch batch;
   int first[kMaxGemmBatch];   // first linear tile of each problem
   int mt[kMaxGemmBatch];      // m-tiles of each problem (m runs fastest inside a problem)
-  int xcd_map;                // 1: XCD-aware tile order (below)
+  int xcd_map;                // 1: XCD-aware tile order (below); 2: conv-bank order (problems dealt to XCDs, below)
+  // conv-bank order: XCD x works on tiles [a0, a0 + na) of problem pa, then on tiles [b0, b0 + nb) of problem pb
+  int bk_pa[8], bk_a0[8], bk_na[8], bk_pb[8], bk_b0[8], bk_nb[8];
 };
 
 template <int BK, int NS, bool BX = false>
@@ -118,19 +120,34 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
   //    n-tiles write at their seam (row pitch 1025) merge in that L2.
   //  * otherwise (conv banks: problems of different depth, longest first) the list is dealt in order so that every XCD gets
   //    the same mix of long and short tiles.
+  //  * xcd_map == 2 (round 5; conv banks of 16 or 8 widths with equal tile counts): whole PROBLEMS are dealt to the XCDs -- the
+  //    widths are paired deepest with shallowest (16 + 1, 15 + 2, ... taps: every pair is the same work), one pair per XCD (16
+  //    widths) or per two XCDs that split its m-tiles (8 widths).  An XCD then streams the tap weights of its own two widths only
+  //    (17 x 64 KB for the encoder bank: L2-resident) instead of all 8.9 MB per m-tile.
   int lin = blockIdx.x;
-  if (G.xcd_map) {
+  int bank_pi = -1, bank_rel = 0;
+  if (G.xcd_map == 2) {
+    const int x = lin & 7, j = lin >> 3;
+    if (j < G.bk_na[x]) { bank_pi = G.bk_pa[x]; bank_rel = G.bk_a0[x] + j; }
+    else if (j < G.bk_na[x] + G.bk_nb[x]) { bank_pi = G.bk_pb[x]; bank_rel = G.bk_b0[x] + j - G.bk_na[x]; }
+    else return;   // (padding of the shorter halves)
+  }
+  if (G.xcd_map == 1) {
     const int tiles = gridDim.x, q = tiles >> 3, rem = tiles & 7, x = lin & 7, j = lin >> 3;
     lin = x * q + (x < rem ? x : rem) + j;
   }
   int pi = 0;
-  for (int i = 1; i < G.batch.n; ++i)
-    if (lin >= G.first[i]) pi = i;
+  if (bank_pi >= 0) {
+    pi = bank_pi;
+  } else {
+    for (int i = 1; i < G.batch.n; ++i)
+      if (lin >= G.first[i]) pi = i;
+  }
   const ConvGemmProblem& P = G.batch.p[pi];
-  const int rel = lin - G.first[pi];
+  const int rel = bank_pi >= 0 ? bank_rel : lin - G.first[pi];
   const int mtiles = G.mt[pi];
   int tnn, tmm;
-  if (G.xcd_map) {
+  if (G.xcd_map == 1) {
     const int ntiles = (P.N + TN - 1) / TN;
     tmm = rel / ntiles;
     tnn = rel - tmm * ntiles;
@@ -949,6 +966,26 @@ int launch_conv_gemm2(ConvGemmBatch& batch, hipStream_t stream, bool force) {
     for (int i = 1; i < batch.n; ++i) same = same && depth(g.batch.p[i]) == depth(g.batch.p[0]);
     const char* e = getenv("TACO_GEMM2_XCD");
     g.xcd_map = (same && !(e && atoi(e) == 0)) ? 1 : 0;
+    // conv-bank order: 16 or 8 problems of different depth with the same number of tiles each (g.batch.p is sorted deepest first)
+    const char* eb = getenv("TACO_GEMM2_BANK_XCD");
+    bool bank = !same && !(eb && atoi(eb) == 0) && (batch.n == 16 || batch.n == 8);
+    const int t = g.mt[0] * cdiv(g.batch.p[0].N, TN);
+    for (int i = 1; i < batch.n && bank; ++i) bank = g.mt[i] * cdiv(g.batch.p[i].N, TN) == t;
+    if (bank) {
+      g.xcd_map = 2;
+      const int h = (t + 1) / 2;
+      for (int x = 0; x < 8; ++x) {
+        if (batch.n == 16) {
+          g.bk_pa[x] = x; g.bk_a0[x] = 0; g.bk_na[x] = t;
+          g.bk_pb[x] = 15 - x; g.bk_b0[x] = 0; g.bk_nb[x] = t;
+        } else {
+          const int pr = x >> 1, lo = (x & 1) ? h : 0, cnt = (x & 1) ? t - h : h;
+          g.bk_pa[x] = pr; g.bk_a0[x] = lo; g.bk_na[x] = cnt;
+          g.bk_pb[x] = 7 - pr; g.bk_b0[x] = lo; g.bk_nb[x] = cnt;
+        }
+      }
+      tiles = batch.n == 16 ? 16 * t : 8 * 2 * h;   // grid: 8 XCDs x the longest share
+    }
   }
   Variant v = env_variant();
   if (!getenv("TACO_GEMM2_VARIANT")) {
