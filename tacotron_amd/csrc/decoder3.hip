@@ -1467,8 +1467,12 @@ struct BDims {
   static constexpr int kFloats = o_dkr + 4 * NT * R;
 };
 
-template <int R, int RR>
-__global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
+// FAST: the cluster's exchange form -- workgroup-scope publishes that stay in the XCD's L2 (all peers on one XCD, allow-listed part)
+// or agent-scope ones.  It is decided at run time by the placement rendezvous, but it is a TEMPLATE parameter of the kernel body:
+// the kernel instantiates both bodies and branches once.  As a run-time flag the scope was a scalar branch inside every publish, on
+// every round's critical path: a probe build without it measured BPTT 10.74 -> 10.50 us per step (profiles/r05_dec_tail_ab.txt).
+template <int R, int RR, bool FAST>
+__device__ __forceinline__ void decoder3_bwd_body(const DecBwdArgs& a) {
   typedef BDims<R, RR> D;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1488,12 +1492,8 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
   Xc X;
   X.base = (gu64*)(reinterpret_cast<u64*>(a.xchg) + (int64_t)cl * R * kX3Row);
   X.rs = __builtin_amdgcn_make_buffer_rsrc((void*)X.base, 0, R * kX3Row * 8, 0x00020000);
-  if (cl >= ncl_used) return;
-  {
-    const int where = placement_rendezvous(a.xchg, a.xcc_table_ofs, cl, a.err, smem);
-    if (where == 0) return;   // not co-resident: error word raised
-    X.fast = where == 2 && a.fast_ok;
-  }
+  (void)ncl_used;   // (clusters beyond the batch left in the kernel wrapper, before the placement rendezvous)
+  X.fast = FAST;
   X.err = a.err;
   X.dead = dead;
   X.epoch = 0;
@@ -2040,6 +2040,17 @@ __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
       }
     });
   }
+}
+
+template <int R, int RR>
+__global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int cl = blockIdx.x % 8;
+  if (cl >= (a.B + R - 1) / R) return;   // clusters beyond the batch take no part in any rendezvous or exchange
+  const int where = __builtin_amdgcn_readfirstlane(placement_rendezvous(a.xchg, a.xcc_table_ofs, cl, a.err, smem));
+  if (where == 0) return;                 // not co-resident: error word raised
+  if (where == 2 && a.fast_ok) decoder3_bwd_body<R, RR, true>(a);
+  else decoder3_bwd_body<R, RR, false>(a);
 }
 
 template <int R, int RR>
