@@ -1,8 +1,11 @@
 """bench.py -- mel-frames/sec of the Tacotron train step (BASELINE.json metric) on N MI355X GPUs of one node.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1 without a torchrun environment: re-executes itself under
+                                                           `python -m torch.distributed.run --nnodes=1 --nproc-per-node N`)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus 2 --rehearse-shared-device      (N ranks on GPU 0 over gloo at a toy shape: exercises the self-launch and
+                                                           the whole N > 1 code path on a 1-GPU box; not a measurement)
 
 A "step" = forward + backward + (gradient all-reduce) + global-norm clip + Adam on one synthetic Nancy-shaped batch
 per GPU (configs[1] of BASELINE.json: B=32, r=2, Tt=200, Td=180 => 360 mel frames per utterance, scheduled-sampling
@@ -31,6 +34,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+# HIP reads this at its FIRST API call (torch.cuda.is_available() is one): before torch is imported, not after (tacotron_amd/lib.py)
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 import torch  # noqa: E402
 
@@ -79,7 +85,9 @@ def cpu_baseline(B, Tt, Td, r, V, steps=5):
         if it > 0:
             times.append(dt)
     sec = sorted(times)[len(times) // 2]
-    return {'value': B * Td * r / sec, 'unit': 'mel-frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+    return {'value': B * Td * r / sec, 'unit': 'mel-frames/s', 'cores': torch.get_num_threads(), 'nproc': os.cpu_count(),
+            'cores_note': 'threads actually used; more are slower on this graph of tiny GEMMs inside 180-step loops (128 threads: 21 s/step)',
+            'kind': 'port',
             'sample': 'full workload (B=%d,Tt=%d,Td=%d,r=%d), median of %d steps after 1 warm-up, %.2f s/step; '
                       'CPU restatement oracle/taco_torch.py (fp32), not TensorFlow' % (B, Tt, Td, r, steps, sec)}
 
@@ -229,19 +237,54 @@ def ab_decoder(rounds=3):
                    'us_per_decoder_step_bwd': med(k, 'us_per_decoder_step_bwd'), 'runs': len(runs[k])} for k in libs}}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: re-execute this script under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>` (the form the
+    driver uses), one rank per GPU over RCCL; rank 0's ONE JSON line passes through on stdout.  Returns the exit code."""
+    import socket
+    import subprocess
+    if not args.rehearse_shared_device:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            sys.stderr.write('bench.py: --gpus %d but this node shows %d GPU(s) (use --rehearse-shared-device to run %d ranks on GPU 0 '
+                             'over gloo at a toy shape)\n' % (args.gpus, have, args.gpus))
+            return 2
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC only on these hosts (RCCL / device-tensor sharing)
+    env.setdefault('GPU_MAX_HW_QUEUES', '8')            # before any rank touches HIP (tacotron_amd/lib.py, INTEGRATION.md 4)
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write('bench.py: self-launch: %s\n' % ' '.join(cmd))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=32)
-    ap.add_argument('--text-len', type=int, default=200)
-    ap.add_argument('--dec-steps', type=int, default=180)
+    ap.add_argument('--batch', type=int, default=None, help='utterances per GPU (default 32; 4 with --rehearse-shared-device)')
+    ap.add_argument('--text-len', type=int, default=None, help='padded text length Tt (default 200; 24 in the rehearsal)')
+    ap.add_argument('--dec-steps', type=int, default=None, help='decoder steps Td (default 180; 10 in the rehearsal)')
+    ap.add_argument('--rehearse-shared-device', action='store_true',
+                    help='run the N ranks on GPU 0 over gloo at a toy shape (RCCL refuses two ranks on one device): a rehearsal of the '
+                         'self-launch and of every N > 1 branch on a 1-GPU box, NOT a measurement')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-inference', action='store_true', help='skip the inference timing (clean per-kernel profiles of the train step)')
     ap.add_argument('--no-extras', action='store_true', help='skip the S2 (Td=500) and VCTK (109 speakers) legs and the family profile')
     ap.add_argument('--speakers', type=int, default=1, help='>1: VCTK-shaped multi-speaker model (BASELINE configs[4])')
     args = ap.parse_args()
+    toy = args.rehearse_shared_device
+    args.batch = args.batch or (4 if toy else 32)
+    args.text_len = args.text_len or (24 if toy else 200)
+    args.dec_steps = args.dec_steps or (10 if toy else 180)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args))
     # The contract is ONE JSON line on stdout.  Libraries underneath write to file descriptor 1 on their own (RCCL prints a five-line
     # version banner at communicator creation): everything up to the result line goes to stderr, then stdout is put back.
     sys.stdout.flush()
@@ -254,8 +297,13 @@ def main():
     from tacotron_amd.dist import GradReducer, init_from_env
     from tacotron_amd.model import Tacotron
 
-    rank, world, local = init_from_env()
     assert torch.cuda.is_available(), 'bench.py needs a GPU (there is no CPU fallback for the product path)'
+    if toy:
+        torch.cuda.set_device(0)
+        rank, world, local = init_from_env('gloo')   # every rank on GPU 0; DEVICE tensors travel over gloo
+        local = 0
+    else:
+        rank, world, local = init_from_env()
     assert world == args.gpus, 'WORLD_SIZE=%d but --gpus %d' % (world, args.gpus)
     torch.cuda.set_device(local)
 
@@ -283,6 +331,7 @@ def main():
     sec_per_step, fwd_ms, bwd_ms = time_steps(model, args.steps, args.warmup, barrier, world)
     loss = float(model.loss)
     model.check()
+    train_cluster, train_mode = lib.last_cluster(0), lib.decoder_mode()
     allreduce = None
     if reducer is not None and rank == 0:
         # separate untimed pass: events around every segment's collectives on the communication stream
@@ -357,10 +406,18 @@ def main():
             vctk = leg(Td, 109)
             vctk['workload'] = 'VCTK-shaped (BASELINE configs[4], 1 GPU): 109 speakers, B=%d, Tt=%d, Td=%d, r=2' % (B, Tt, Td)
 
+    fa = sum(fwd_ms) / max(1, len(fwd_ms))
+    ba = sum(bwd_ms) / max(1, len(bwd_ms))
+    per_rank = None
+    if world > 1:
+        # every rank's own decoder launch times (HIP events on its launch stream): rank r fills slot r, SUM gathers them
+        slots = torch.zeros(world, 2, dtype=torch.float64, device='cuda')
+        slots[rank, 0], slots[rank, 1] = fa * 1e3 / Td, ba * 1e3 / Td
+        torch.distributed.all_reduce(slots, op=torch.distributed.ReduceOp.SUM)
+        per_rank = [{'rank': i, 'us_per_decoder_step_fwd': float(slots[i, 0]), 'us_per_decoder_step_bwd': float(slots[i, 1])}
+                    for i in range(world)]
     if rank == 0:
         frames = world * B * Td * c.r
-        fa = sum(fwd_ms) / max(1, len(fwd_ms))
-        ba = sum(bwd_ms) / max(1, len(bwd_ms))
         dom, dom_ms = ('decoder3_bwd_kernel', ba) if ba >= fa else ('decoder3_fwd_kernel', fa)
         # algorithmic FLOPs of ONE launch: forward = SURVEY 8(d) decoder figure; the backward kernel does the
         # transposed mat-vecs + attention backward = the same count again (weight gradients are separate GEMMs).
@@ -383,12 +440,13 @@ def main():
             except Exception:
                 traffic = traffic_step = None
         PEAK = 157.3
+        OWN_ROOF = 2516.0 / 6.0
         step_flops = 3 * model_flops(B, Tt, Td, c.r)
         rooflines = [
             # (`bound` names the roof the kernel is priced against -- the contract's enum is hbm | mfma; `limiter` says what
             #  actually binds: neither roof, the kernel is a latency-bound recurrence)
-            {'what': dom, 'bound': 'mfma', 'limiter': 'latency', 'achieved': achieved, 'peak': PEAK, 'unit': 'TFLOP/s',
-             'frac': achieved / PEAK,
+            {'what': dom, 'bound': 'mfma', 'bound_actual': 'latency', 'limiter': 'latency', 'achieved': achieved, 'peak': PEAK,
+             'unit': 'TFLOP/s', 'frac': achieved / PEAK,
              'avg_ms': dom_ms, 'us_per_decoder_step': dom_ms * 1e3 / Td, 'flops_per_launch': flops, 'traffic': traffic,
              'traffic_step': traffic_step,
              'traffic_source': 'profiles/pmc_latest.json (rocprofv3 --pmc passes of tools/profile_round.sh; a committed constant, '
@@ -405,6 +463,11 @@ def main():
             ours4k, blas4k = fp32_gemm_4096()
             rooflines.insert(1, {'what': 'MFMA GEMM family (conv_gemm + gemm_tn + fused highway launches)', 'bound': 'mfma',
                                  'achieved': g, 'peak': PEAK, 'unit': 'TFLOP/s', 'frac': g / PEAK,
+                                 # the big launches of the family form each fp32 product from six v_mfma_f32_32x32x16_bf16: the
+                                 # roof they actually run under is the dense bf16 peak / 6, not the fp32-instruction peak above
+                                 'peak_own_roof_tflops': OWN_ROOF, 'frac_own_roof': g / OWN_ROOF,
+                                 'own_roof_note': 'bf16 dense peak 2,516 TFLOP/s / 6 plane products per fp32 product (bf16x3 form, the default '
+                                                  'of conv_gemm2 / gemm_tn); `frac` keeps the fp32-MFMA peak the contract names',
                                  'nn_kernel_4096_cubed_tflops': ours4k, 'vendor_blas_4096_cubed_tflops': blas4k,
                                  'reference_note': 'a 4096^3 fp32 GEMM on the library\'s NN kernel and on the vendor BLAS (torch.mm), 5 launches '
                                                    'each in this run: what a long, tail-free launch reaches under burst clocks -- context for '
@@ -437,8 +500,18 @@ def main():
             'final_loss': loss, 'build': source_hash(),
             # which box this was: the latency-bound kernels (decoder, bi-GRU: 58 % of the step) scale with the shader clock the chip
             # sustains, and boxes of one pool differ by ~10 % (round 4: the same build ran 8.86 and 9.30 ms per step)
-            'box': dict({'shader_clock_ghz_latency_bound': lib.clock_probe()}, **(lib.fabric_probe() if world == 1 else {})),
+            'box': dict({'shader_clock_ghz_latency_bound': lib.clock_probe(), 'decoder_mode': train_mode,
+                         'decoder_mode_note': '0 = decoder3.hip with the XCD-local exchange (product default), 1 = decoder3.hip with the '
+                                              'agent-scope exchange, 2 = decoder.hip (include/taco_hip.h taco_decoder_mode)',
+                         'decoder_cluster_width_train': train_cluster},
+                        **(lib.fabric_probe() if world == 1 else {})),
         }
+        if per_rank:
+            res['per_rank'] = per_rank
+        if toy:
+            res['rehearsal'] = ('%d ranks share GPU 0 and exchange device tensors over gloo at a toy shape: a rehearsal of the launch path, '
+                                'the numbers are NOT measurements of the BASELINE workload' % world)
+            res['data'] = 'synthetic (toy rehearsal shape)'
         if ab is not None:
             dec_ab = ab_decoder()
             if dec_ab:

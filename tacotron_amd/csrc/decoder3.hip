@@ -111,7 +111,8 @@ __device__ __forceinline__ bool spin_fail_uniform(unsigned& spin, const Xc& X) {
   if ((++spin & 1023u) == 8u) {
     const int e = __hip_atomic_load((gi32*)X.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (spin > (1u << 23) || __builtin_amdgcn_ballot_w64(e != 0) != 0) {
-      __hip_atomic_store((gi32*)X.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (max, not store: a word the placement rendezvous set to 2 = "not co-resident" keeps saying so -- ADVICE r5)
+      __hip_atomic_fetch_max((gi32*)X.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       *X.dead = 1;
       return true;
     }
@@ -127,7 +128,8 @@ __device__ __forceinline__ bool spin_fail_uniform(unsigned& spin, const Xc& X) {
 __device__ __forceinline__ bool spin_fail(unsigned& spin, const Xc& X) {
   if ((++spin & 1023u) == 0u) {
     if (spin > (1u << 23) || __hip_atomic_load((gi32*)X.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-      __hip_atomic_store((gi32*)X.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (max, not store: a word the placement rendezvous set to 2 = "not co-resident" keeps saying so -- ADVICE r5)
+      __hip_atomic_fetch_max((gi32*)X.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       *X.dead = 1;
       return true;
     }
@@ -167,7 +169,7 @@ __device__ __forceinline__ int placement_rendezvous(void* xchg, int table_ofs, i
     const bool same = __all(v != 0 && v == v0);
     if (tid == 0) {
       sflag[0] = !here ? 0 : (same ? 2 : 1);
-      if (!here) __hip_atomic_store((gi32*)err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!here) __hip_atomic_fetch_max((gi32*)err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   __syncthreads();
@@ -215,11 +217,15 @@ constexpr bool kGroupedFanDq = false;
 // tanh(keys + q) of the attention rounds from a PRODUCT of exponentials (round 5).  tanh(x) = 1 - 2 / (1 + exp(2 x)) costs two
 // quarter-rate instructions per element (v_exp_f32, v_rcp_f32); with exp(2 (k + q)) = exp(2 k) exp(2 q) the key factor is formed
 // once per launch (the keys are launch-resident anyway) and the query factor once per step and unit, which leaves ONE
-// transcendental per element: r = rcp(fma(ka, qb, 1)), tanh = 1 - 2 r, 1 - tanh^2 = 4 r (1 - r).  Both factors stay normal
-// numbers for |k|, |q| <= 40 (exp2(+-115)); a wave that holds a key beyond that, or sees a query beyond it in some step, takes the
-// exact sum form for that step (wave-uniform branch, keys re-read from memory) -- results never depend on the bound.  The
-// relative error of exp(2 x) is ~|2 x log2 e| 2^-24 ln 2 in either form; the product form pays |k| + |q| where the sum form
-// pays |k + q|.  -DTACO_NO_TANH_SPLIT: the sum form everywhere (A/B builds).
+// transcendental per element: r = rcp(fma(ka, qb, 1)), tanh = 1 - 2 r, 1 - tanh^2 = 4 r (1 - r).  A wave that holds a key beyond
+// kTanhBound, or sees a query beyond it in some step, takes the exact sum form for that step (wave-uniform branch, keys re-read
+// from memory).  The bound is a PRECISION bound, not only an overflow bound: the argument of exp2 is rounded at its
+// own magnitude, so the relative error of exp(2 x) is ~|2 x log2 e| 2^-24 ln 2 in either form -- the product form pays |k| + |q|
+// where the sum form pays |k + q|.  With large k and q of opposite sign (k + q ~ 0, tanh on its steep part) a bound of 40 -- where
+// both factors are still normal numbers, exp2(+-115) -- would let tanh be off by ~3e-6 absolute; at 8 the arguments stay below 24
+// (ulp 2^-19) and the worst case is ~6e-7, the level of the sum form's own v_exp_f32 / v_rcp_f32 errors.  Keys of a model at
+// glorot initialisation are O(1); beyond the bound the kernel is exact and ~2 % slower per step.
+// -DTACO_NO_TANH_SPLIT: the sum form everywhere (A/B builds).
 #if !defined(TACO_NO_TANH_SPLIT)
 constexpr bool kTanhSplit = true;
 #else
@@ -235,7 +241,7 @@ constexpr bool kTanhSplitB = true;
 constexpr bool kTanhSplitB = false;
 #endif
 constexpr float kTwoLog2e = 2.8853900817779268f;
-constexpr float kTanhBound = 40.f;
+constexpr float kTanhBound = 8.f;
 __device__ __forceinline__ float exp2_2x(float x) { return __builtin_amdgcn_exp2f(kTwoLog2e * x); }   // exp(2 x)
 
 template <int KPLG0, int MODE>
@@ -2125,6 +2131,8 @@ int launch3b(DecBwdArgs& a, hipStream_t s) {
 // the HIP memory model promises.  It is therefore enabled only on an explicit allow-list (ADVICE r3 / VERDICT r4 #7c): gfx950 in
 // SPX mode (one device = 8 XCDs = 256 CUs), where it was validated (parity suite, 1,000-step soaks, tools/micro/pingpong); anything
 // else -- another architecture, a DPX / QPX / CPX partition, a future part -- gets the agent-scope form, which is merely slower.
+// (Unlike the mode variables above, the allow-list decision -- device properties and TACO_DEC_ALLOW_XCD_LOCAL -- is made ONCE per
+// device and cached for the life of the process: it describes the hardware, not a run.)
 static bool xcd_local_exchange_allowed() {
   static signed char cache[32] = {};   // 0 unknown, 1 allowed, -1 not
   int dev = 0;

@@ -802,8 +802,8 @@ static int plan_gemm_tn(GemmTnArgs& a, bool force_small, dim3& grid, int64_t gro
   a.splits = splits;
   a.chunk = chunk;
   grid = dim3(cdiv(a.K, bm), cdiv(a.N, bm), a.batch * a.taps * splits);
-  static const int xcd = [] { const char* e = getenv("TACO_TN_XCD"); return e ? atoi(e) : 1; }();   // XCD-aware block order (0: plain)
-  a.xcd = xcd;
+  const char* ex = getenv("TACO_TN_XCD");   // XCD-aware block order (0: plain); read per launch so that a test can cover both orders
+  a.xcd = ex ? atoi(ex) : 1;
   return bm;
 }
 

@@ -106,6 +106,7 @@ class DeviceFeeder:
         self._step = 0
         self._stop = False
         self._last = None
+        self._dead = None                      # the exception the worker died with (re-raised by every later next())
         self._lock = threading.Lock()
         self._thread = threading.Thread(target=self._work, daemon=True)
         self._thread.start()
@@ -149,8 +150,18 @@ class DeviceFeeder:
     def next(self):
         """Device tensors of the next batch.  Valid until the next call: kernels already enqueued on the caller's stream keep reading
         them safely (the refill waits for an event recorded on that stream), host-side readers must copy first."""
-        item = self._q.get()
+        if self._dead is not None:           # the worker is gone: every later call fails the same way instead of blocking forever
+            raise self._dead
+        while True:
+            try:
+                item = self._q.get(timeout=1.0)
+                break
+            except queue.Empty:
+                if not self._thread.is_alive():   # died without reporting (never expected; never wait on a dead thread)
+                    self._dead = RuntimeError('DeviceFeeder worker thread is not running')
+                    raise self._dead
         if isinstance(item, Exception):
+            self._dead = item
             raise item
         if self.cuda:
             cur = torch.cuda.current_stream(self.device)

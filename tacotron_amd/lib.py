@@ -14,15 +14,17 @@ import os
 # with 4 queues two of them share a queue and one's kernels sit behind a millisecond of the other's already-enqueued launches
 # (measured in round 4: the post-net segment's collective finished 1.47 ms after it became eligible, 30 us with 8 queues).
 # The variable is read when the HIP runtime initialises, i.e. at the first device call -- set it before anything touches the GPU.
-_QUEUES_SET_BY_USER = 'GPU_MAX_HW_QUEUES' in os.environ
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+from . import QUEUES_SET_BY_USER as _QUEUES_SET_BY_USER, TORCH_IMPORTED_FIRST as _TORCH_IMPORTED_FIRST   # (package __init__ applied the default)
 
 import torch  # noqa: E402
 
-# If the process touched the GPU before importing this package (and did not set the variable itself) the runtime is already up
-# with its default of 4 queues: the setdefault above came too late, and high-priority communication streams would then cost 1.3 ms
-# per step instead of saving one (dist._comm_priority asks here).
-HW_QUEUES_LATE = (not _QUEUES_SET_BY_USER) and torch.cuda.is_available() and torch.cuda.is_initialized()
+# If the process may have touched the GPU before importing this package (and did not set the variable itself) the runtime is up
+# with its default of 4 queues: the default came too late, and high-priority communication streams would then cost 1.3 ms per
+# step instead of saving one (dist._comm_priority asks here).  "May have": the runtime reads the variable at the FIRST HIP API call
+# -- hipGetDeviceCount behind torch.cuda.is_available() / device_count() counts, and leaves no trace in torch
+# (torch.cuda.is_initialized() stays False) -- so every import of torch ahead of this package is treated as late.
+# Launchers that import torch first set the variable themselves before doing so (bench.py, tests/conftest.py, the drivers).
+HW_QUEUES_LATE = (not _QUEUES_SET_BY_USER) and (_TORCH_IMPORTED_FIRST or (torch.cuda.is_available() and torch.cuda.is_initialized()))
 
 
 def effective_hw_queues() -> int:

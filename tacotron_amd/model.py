@@ -174,15 +174,25 @@ class Tacotron(object):
             prev = self._last_timeout_step
             self._last_timeout_step = self.global_step
             repeat = prev is not None and self.global_step - prev <= self.ESCALATE_WINDOW
-            escalate = repeat and mode < 2
-            e = lib.TacoError('decoder cluster exchange timed out (forward=%d, backward=%d) in decoder mode %d at step %d; parameter '
+            # error word 2 = the placement rendezvous of a decoder3 launch found a cluster NOT CO-RESIDENT (a peer workgroup was not
+            # dispatched within 50 ms: something else holds CUs the persistent kernel needs).  That is a diagnosis, not a transient:
+            # both decoder3 modes need all 256 workgroups resident and every such launch costs 50 ms, so the process goes straight
+            # to decoder.hip (mode 2), whose launch geometry is sized from the occupancy query.
+            not_resident = 2 in (flags[0], flags[1]) and mode < 2
+            escalate = (repeat or not_resident) and mode < 2
+            new_mode = 2 if not_resident else mode + 1
+            what = ('decoder cluster NOT CO-RESIDENT (error word 2: a peer workgroup was not dispatched within 50 ms -- another kernel '
+                    'holds CUs the persistent decoder needs)' if not_resident else 'decoder cluster exchange timed out')
+            e = lib.TacoError('%s (forward=%d, backward=%d) in decoder mode %d at step %d; parameter '
                               'updates were skipped while the flag was set%s' %
-                              (flags[0], flags[1], mode, self.global_step,
-                               '; second time-out within %d steps: switched to decoder mode %d' % (self.ESCALATE_WINDOW, mode + 1)
+                              (what, flags[0], flags[1], mode, self.global_step,
+                               ('; switched to decoder mode %d' % new_mode if not_resident else
+                                '; second time-out within %d steps: switched to decoder mode %d' % (self.ESCALATE_WINDOW, new_mode))
                                if escalate else ('' if mode >= 2 else '; mode kept (first time-out in this window)')))
             e.recoverable = mode < 2
+            e.not_resident = not_resident
             if escalate:
-                lib.decoder_mode(mode + 1)
+                lib.decoder_mode(new_mode)
             raise e
 
     def placement_census(self):

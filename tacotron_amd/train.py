@@ -5,6 +5,7 @@ Without a preprocessed corpus under data/<set>/ it trains on synthetic Nancy-sha
 from __future__ import annotations
 
 import argparse
+import math
 import os
 import pickle as pkl
 
@@ -127,42 +128,56 @@ def train(config, num_steps=1000000, log_every=50, save_every=SAVE_EVERY):
     lr = config.init_lr
     import time
     t_mark, s_mark, step = None, 0, -1                    # throughput of the host loop itself (reported when the loop ends)
-    for step in range(num_steps):
-        model.set_inputs(next_batch(step))                # device tensors from the feeder: a pointer swap
-        model.step(lr)
-        gs = model.global_step
-        if step == 10:                                    # (past the first steps' one-off costs: lazy allocations, LDS attribute calls)
+    try:
+        for step in range(num_steps):
+            model.set_inputs(next_batch(step))                # device tensors from the feeder: a pointer swap
+            model.step(lr)
+            gs = model.global_step
+            if step == 10:                                    # (past the first steps' one-off costs: lazy allocations, LDS attribute calls)
+                torch.cuda.synchronize()
+                t_mark, s_mark = time.perf_counter(), step
+            if gs % log_every == 0 or gs % save_every == 0:
+                loss = float(model.loss)                      # the only host sync, every log_every steps
+                try:
+                    model.check()                             # decoder exchange time-outs surface here (sticky flag; the
+                except Exception as e:                        # guarded Adam update skipped itself in the meantime)
+                    if not getattr(e, 'recoverable', False):
+                        raise
+                    print('WARNING (rank %d): %s -- continuing' % (rank, e))   # check() moved to a more conservative decoder mode
+                if rank == 0:
+                    # tacotron.py:162-164: the summaries 'loss', 'seq2seq_loss', 'output_loss' (scalars only)
+                    s2s_l, out_l = (float(x) for x in model.loss_terms)
+                    print('step %d loss %.1f (seq2seq %.1f + output %.1f) gnorm %.2f decoder-mode %d' %
+                          (gs, loss, s2s_l, out_l, float(model.global_gradient_norm), model.decoder_mode))
+                # train.py:77-80; `not isfinite` added: the bf16x3 GEMMs turn an Inf operand into NaN (inf - inf in the plane split),
+                # and `NaN > 1e8` is False -- a diverged run must still stop here
+                if (not math.isfinite(loss) or loss > 1e8) and gs > 500:
+                    print('loss exploded')
+                    break
+            if gs % 1000 == 0:
+                lr *= config.annealing_rate                   # train.py:82-83
+            if gs % save_every == 0 and gs != 0:
+                if rank == 0:
+                    print('saving weights')
+                    os.makedirs(os.path.dirname(ckpt_prefix) or '.', exist_ok=True)
+                    torch.save(model.state_dict(), '%s-%d' % (ckpt_prefix, gs))
+                    print('saving sample')
+                    save_sample(model, os.path.join('log', config.save_path), gs)
+                if distributed:
+                    # rank 0 spent a while on the host; the others must not run ahead into the next step's collectives (and the
+                    # persistent decoder kernels of a rank that waits inside a collective keep spinning on their peers)
+                    torch.distributed.barrier()
+    except BaseException:
+        #  a non-recoverable TacoError from check(), a feeder failure, Ctrl-C: the worker thread must not be inside a
+        # device call when the interpreter tears the runtime down, and the process group must not outlive the loop
+        try:
             torch.cuda.synchronize()
-            t_mark, s_mark = time.perf_counter(), step
-        if gs % log_every == 0 or gs % save_every == 0:
-            loss = float(model.loss)                      # the only host sync, every log_every steps
-            try:
-                model.check()                             # decoder exchange time-outs surface here (sticky flag; the
-            except Exception as e:                        # guarded Adam update skipped itself in the meantime)
-                if not getattr(e, 'recoverable', False):
-                    raise
-                print('WARNING (rank %d): %s -- continuing' % (rank, e))   # check() moved to a more conservative decoder mode
-            if rank == 0:
-                # tacotron.py:162-164: the summaries 'loss', 'seq2seq_loss', 'output_loss' (scalars only)
-                s2s_l, out_l = (float(x) for x in model.loss_terms)
-                print('step %d loss %.1f (seq2seq %.1f + output %.1f) gnorm %.2f decoder-mode %d' %
-                      (gs, loss, s2s_l, out_l, float(model.global_gradient_norm), model.decoder_mode))
-            if loss > 1e8 and gs > 500:                   # train.py:77-80
-                print('loss exploded')
-                break
-        if gs % 1000 == 0:
-            lr *= config.annealing_rate                   # train.py:82-83
-        if gs % save_every == 0 and gs != 0:
-            if rank == 0:
-                print('saving weights')
-                os.makedirs(os.path.dirname(ckpt_prefix) or '.', exist_ok=True)
-                torch.save(model.state_dict(), '%s-%d' % (ckpt_prefix, gs))
-                print('saving sample')
-                save_sample(model, os.path.join('log', config.save_path), gs)
-            if distributed:
-                # rank 0 spent a while on the host; the others must not run ahead into the next step's collectives (and the
-                # persistent decoder kernels of a rank that waits inside a collective keep spinning on their peers)
-                torch.distributed.barrier()
+        except Exception:   # noqa: BLE001 -- the original exception is the one to report
+            pass
+        feeder.close()
+        if torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+        raise
     torch.cuda.synchronize()
     feeder.close()
     if t_mark is not None and step > s_mark:

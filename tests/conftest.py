@@ -1,7 +1,10 @@
 import os
 import sys
 
-import pytest
+# (tacotron_amd/lib.py: HIP reads this at its first API call; the test modules import torch before the package)
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
+import pytest  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -129,3 +129,29 @@ def test_comm_standin_coresidency_with_decoder_bptt(built_lib):
     d = res['default: post-net segment announced after the BPTT kernel']
     assert d['bptt_ms'] <= 1.1 * solo
     assert d['spin_start_after_bwd_start_ms'] >= d['bptt_ms']          # its enqueue point lies behind the BPTT kernel
+
+
+@pytest.mark.timeout(900)
+def test_bench_self_launches_n_ranks_from_the_plain_command(built_lib):
+    """`python bench.py --gpus 2` must start by itself: no WORLD_SIZE in the environment -> bench.py re-executes
+    itself under torch.distributed.run, one process per rank.  On a 1-GPU box `--rehearse-shared-device` puts both ranks on GPU 0
+    over gloo at a toy shape, so the self-launch and every N > 1 branch of the bench (process group, GradReducer on a communication
+    stream, barriers, max-over-ranks timing, per-rank decoder times, ONE JSON line from rank 0) execute here."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--rehearse-shared-device', '--steps', '3',
+                        '--warmup', '1'], env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [x for x in r.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    print('  rehearsal line: n_gpus %d, %.3f ms/step, allreduce backend %s world %d, per_rank %s'
+          % (j['n_gpus'], j['ms_per_step'], j['allreduce']['backend'], j['allreduce']['world'], j['per_rank']))
+    assert j['n_gpus'] == 2 and j['steps'] == 3 and j['scaling'] == 'weak' and 'rehearsal' in j
+    assert j['config']['global_batch'] == 2 * 4 and j['config']['parallelism'] == 'dp2'
+    assert j['allreduce']['world'] == 2 and j['allreduce']['backend'] == 'gloo' and len(j['allreduce']['segments']) == 4
+    assert [p['rank'] for p in j['per_rank']] == [0, 1] and all(p['us_per_decoder_step_fwd'] > 0 for p in j['per_rank'])
+    assert j['value'] > 0 and np.isfinite(j['final_loss'])

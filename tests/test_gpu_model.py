@@ -162,14 +162,18 @@ def test_infer_matches_golden(built_lib, r):
     assert r1 < 1e-5 and m1 < 5e-5 and r2 < 1e-5 and m2 < 5e-5 and m3 < 1e-6
 
 
-@pytest.mark.parametrize('case', ['keys-beyond-bound', 'queries-beyond-bound', 'mixed'])
+@pytest.mark.parametrize('case', ['keys-beyond-bound', 'queries-beyond-bound', 'mixed', 'large-opposite-below-bound',
+                                  'large-opposite-around-bound'])
 def test_attention_scores_beyond_the_product_form_bound(built_lib, case):
     """decoder3's kernels form tanh(keys + q) (forward: the energies; BPTT: the energy backward) from a product of exponentials
-    exp(2 k) exp(2 q) while |k|, |q| <= 40 and fall back, wave by wave and step by step, to the exact sum form beyond that
+    exp(2 k) exp(2 q) while |k|, |q| <= 8 and fall back, wave by wave and step by step, to the exact sum form beyond that
     (decoder3.hip kTanhSplit / kTanhSplitB).  Forced here: the memory
     layer scaled until most keys exceed the bound (every wave on the exact form), the query layer scaled until the queries do
     (the per-step fallback), and a scale at which only part of the keys do (both forms inside one launch).  Same tolerances as
-    the unscaled fixture: the fallback must be the reference computation, not an approximation of it; no NaN from inf * 0."""
+    the unscaled fixture: the fallback must be the reference computation, not an approximation of it; no NaN from inf * 0.
+    The two `large-opposite` cases are the PRECISION side of the bound: keys and queries of magnitude 4-8 (resp. 4-40)
+    whose sum is near 0 -- the product form rounds each exponent at |k| and |q|, the sum form at |k + q| -- must still meet the
+    unscaled fixture's tolerances; the share of such (key, query) pairs in the case is printed and asserted to be non-trivial."""
     g, p, inp, masks = golden(2)
     p = dict(p)
     mem = [k for k in p if k.endswith('memory_layer/kernel')][0]
@@ -178,12 +182,27 @@ def test_attention_scores_beyond_the_product_form_bound(built_lib, case):
         p[mem] = p[mem] * 400.0
     elif case == 'queries-beyond-bound':
         p[qry] = p[qry] * 3000.0
-    else:
+    elif case == 'mixed':
         p[mem] = p[mem] * 60.0
         p[qry] = p[qry] * 300.0
+    elif case == 'large-opposite-below-bound':    # |keys| <= 6.9, |q| <= 7.5: every element on the product form
+        p[mem] = p[mem] * 15.0
+        p[qry] = p[qry] * 3.5
+    else:                                          # |keys| <= 27.5, |q| <= 25.5, a third of each beyond the bound: both forms
+        p[mem] = p[mem] * 60.0
+        p[qry] = p[qry] * 12.0
     B, Tt, Td, V = int(g['B']), int(g['Tt']), int(g['Td']), int(g['V'])
     p64 = f64(p)
     s2s, out, al, extra = on.forward(p64, f64(inp), 2, Td, True, {k: v.astype(np.float64) for k, v in masks.items()})
+    if case.startswith('large-opposite'):
+        # which (key, query) pairs does this case hold?  keys (B, Tt, 256) from the oracle's encoder, queries (B, Td, 256) from its outputs
+        keys = on.attention_memory(p64, extra, inp['text_length'])[1]
+        q = s2s @ p64[qry]
+        kk, qq = keys[:, None, :, :], q[:, :, None, :]
+        pairs = (np.abs(kk) > 3.0) & (np.abs(qq) > 3.0) & (np.abs(kk + qq) < 1.0)
+        print('  %s: |keys| max %.1f, |q| max %.1f; %d of %d (key, query, unit) triples have |k|, |q| > 3 and |k + q| < 1'
+              % (case, np.abs(keys).max(), np.abs(q).max(), int(pairs.sum()), pairs.size))
+        assert pairs.sum() >= 100
     R = Runner(built_lib, B, Tt, Td, 2, V)
     R.set(p, inp, masks)
     R.forward()
@@ -491,12 +510,15 @@ def test_pooled_bank_epilogue_tile_edges(built_lib, B, Tt, Td, monkeypatch):
     assert report('enc.pool (inference)', Ri.wsget('enc.pool'), pool.reshape(B * Tt, -1))[0] < 1e-5
 
 
-@pytest.mark.parametrize('knob', ['TACO_NO_BANK_GATHER=1', 'TACO_GEMM2_XCD=0', 'TACO_GEMM2_BF16X=0', 'TACO_DEC_NO_LRES=1'])
+@pytest.mark.parametrize('knob', ['TACO_NO_BANK_GATHER=1', 'TACO_GEMM2_XCD=0', 'TACO_GEMM2_BF16X=0', 'TACO_DEC_NO_LRES=1',
+                                  'TACO_TN_XCD=0', 'TACO_GEMM2_BANK_XCD=0', 'TACO_GEMM2_BSPLIT=0'])
 def test_medium_shape_with_optional_paths(built_lib, knob, monkeypatch):
     """The fallback / A-B switches of the train step keep parity: the conv bank's input gradient as K atomic-accumulating problems
     (TACO_NO_BANK_GATHER=1: the path taken when the slabs do not fit or the kernels are not contiguous), gemm2's plain tile order
-    (TACO_GEMM2_XCD=0), the fp32 MFMA form of the big GEMMs (TACO_GEMM2_BF16X=0, rounds 2-4) and the decoder kernels without
-    launch-resident weight rows in LDS (TACO_DEC_NO_LRES=1)."""
+    (TACO_GEMM2_XCD=0), the fp32 MFMA form of the big GEMMs (TACO_GEMM2_BF16X=0, rounds 2-4), the decoder kernels without
+    launch-resident weight rows in LDS (TACO_DEC_NO_LRES=1), the weight-gradient kernels' and the conv banks' plain block orders
+    (TACO_TN_XCD=0, TACO_GEMM2_BANK_XCD=0: round 5's XCD-aware orders off) and the weight operand split in registers instead of
+    read from the pre-split plane images (TACO_GEMM2_BSPLIT=0, round 6)."""
     k, v = knob.split('=')
     monkeypatch.setenv(k, v)
     test_medium_shape_forward_backward(built_lib)
@@ -876,6 +898,22 @@ def test_error_words_are_sticky_and_guard_the_update(built_lib):
         with pytest.raises(built_lib.TacoError) as ei:
             m.check()
         assert not ei.value.recoverable and built_lib.decoder_mode() == 2
+    finally:
+        built_lib.decoder_mode(0)
+    # error word 2 = "cluster not co-resident" (the placement rendezvous of decoder3.hip): reported as such, and the process goes
+    # straight to decoder.hip -- both decoder3 modes need the residency that was just found missing
+    try:
+        m.check()
+        m._last_timeout_step = None
+        m._err[0] = 2
+        with pytest.raises(built_lib.TacoError) as ei:
+            m.check()
+        assert ei.value.recoverable and ei.value.not_resident and 'NOT CO-RESIDENT' in str(ei.value)
+        assert built_lib.decoder_mode() == 2
+        m.step(lr=1e-3)
+        torch.cuda.synchronize()
+        m.check()
+        assert float(m.global_gradient_norm) > 0 and built_lib.last_cluster(0) < 32
     finally:
         built_lib.decoder_mode(0)
     # a batch of another shape is refused instead of being read out of bounds

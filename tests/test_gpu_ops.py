@@ -152,6 +152,70 @@ def test_bf16x3_products_are_fp32_grade(built_lib, scale, monkeypatch):
     assert err['1'][0] <= 2.0 * err['0'][0] and err['1'][1] <= 2.5 * err['0'][1]
 
 
+def _ones_mantissa(rng, shape, spread=2):
+    """Same-signed fp32 values with ALL mantissa bits set, (2 - 2^-23) * 2^e with e ~ U{-spread..spread}: each of the three bf16
+    planes of the split is as large as it can be relative to the one above, and with one sign the three dropped plane products
+    (m l, l m, l l) of the bf16x3 form cannot cancel -- its coherent worst case (VERDICT r5 #9)."""
+    e = rng.integers(-spread, spread + 1, shape)
+    return (np.float32(2.0 - 2.0 ** -23) * np.exp2(e).astype(np.float32)).astype(np.float32)
+
+
+@pytest.mark.parametrize('kind', ['ones-mantissa-same-sign', 'heavy-tailed'])
+@pytest.mark.parametrize('kernel', ['nn', 'tn'])
+def test_bf16x3_adversarial_operands(built_lib, kernel, kind, monkeypatch):
+    """Worst-case rather than statistical evidence for the bf16x3 products (VERDICT r5 #9 / next #7a), on BOTH kernels that use them:
+    the NN kernel of gemm2.hip and the weight-gradient kernel of gemm.hip (gemm_tn), K = 6144 deep (encoder proj1's depth).
+    `ones-mantissa-same-sign`: every operand positive with all 23 mantissa bits set -- the dropped plane products (m l, l m, l l) are
+    all of one sign, a coherent relative bias of ~2^-23 that random signs hide; `heavy-tailed`: log-normal magnitudes over ~5 decades
+    (the NN case of test_bf16x3_products_are_fp32_grade, here for gemm_tn as well).  Asserted against an fp64 product: the bf16x3
+    form within 3 x the error of the fp32 MFMA form of the same kernel (floor 1e-7: below that both are at fp32 rounding level),
+    and within the 5e-6 every GEMM test of this file states; the measured errors are printed (and the stricter 4e-7 of the
+    verdict's proposal is reported, asserted only where the fp32 MFMA form itself meets it: with 6,144 same-signed terms the fp32
+    ACCUMULATION of either form performs a random walk of ~sqrt(K / 3) roundings)."""
+    monkeypatch.setenv('TACO_GEMM2_MIN_TILES', '1')
+    monkeypatch.setenv('TACO_GEMM2_VARIANT', '16x4')
+    rng = np.random.default_rng(23)
+    if kernel == 'nn':
+        M, N, K = 512, 256, 6144
+        if kind == 'heavy-tailed':
+            A = (rng.standard_normal((M, K)) * np.exp(rng.standard_normal((M, K)) * 3)).astype(np.float32)
+            W = (rng.standard_normal((1, K, N)) * np.exp(rng.standard_normal((1, K, N)) * 3) / np.sqrt(K)).astype(np.float32)
+        else:
+            A, W = _ones_mantissa(rng, (M, K)), _ones_mantissa(rng, (1, K, N))
+        ref = A.astype(np.float64) @ W[0].astype(np.float64)
+
+        def run():
+            C = torch.full((M, N), float('nan'), device='cuda')
+            before = built_lib.debug_gemm2_window(0, 1 << 30)
+            built_lib.conv_gemm(dev(A), dev(W), C, M, N, K, taps=1, T=M, pad_l=0, act=0)
+            assert built_lib.debug_gemm2_window(0, 1 << 30) == 1, 'the launch did not go to gemm2.hip'
+            return C.cpu().numpy()
+    else:
+        M, N, K = 6144, 256, 512          # dW (K, N) = A^T (K, M) dY (M, N): the reduction runs over the M = 6144 rows
+        if kind == 'heavy-tailed':
+            A = (rng.standard_normal((M, K)) * np.exp(rng.standard_normal((M, K)) * 3)).astype(np.float32)
+            dY = (rng.standard_normal((M, N)) * np.exp(rng.standard_normal((M, N)) * 3) / np.sqrt(M)).astype(np.float32)
+        else:
+            A, dY = _ones_mantissa(rng, (M, K)), _ones_mantissa(rng, (M, N))
+        ref = A.astype(np.float64).T @ dY.astype(np.float64)
+
+        def run():
+            dW = torch.full((1, K, N), float('nan'), device='cuda')
+            built_lib.gemm_tn(dev(A), dev(dY), dW, M, N, K, taps=1, T=M, pad_l=0, accumulate=False)
+            return dW[0].cpu().numpy()
+    err = {}
+    for bx in ('0', '1'):
+        monkeypatch.setenv('TACO_GEMM2_BF16X', bx)
+        err[bx] = report('%s %s %s' % (kernel, kind, 'bf16x3' if bx == '1' else 'fp32  '), run(), ref)
+    print('  %s / %s: rel-L2 bf16x3 %.2e vs fp32 MFMA %.2e (ratio %.2f); 4e-7 bar: bf16x3 %s, fp32 MFMA %s'
+          % (kernel, kind, err['1'][0], err['0'][0], err['1'][0] / max(err['0'][0], 1e-30),
+             'met' if err['1'][0] <= 4e-7 else 'NOT met', 'met' if err['0'][0] <= 4e-7 else 'NOT met'))
+    assert err['0'][0] < 5e-6 and err['1'][0] < 5e-6
+    assert err['1'][0] <= 3.0 * max(err['0'][0], 1e-7)
+    if err['0'][0] <= 4e-7 / 3:
+        assert err['1'][0] <= 4e-7
+
+
 @pytest.mark.parametrize('case', [(1000, 200, 128, 2048, 3, 1, 1), (520, 130, 256, 1024, 3, 1, 0), (300, 300, 132, 516, 1, 0, 3)],
                          ids=['enc-proj1-like', 'post-proj1-like', 'ragged'])
 def test_conv_gemm_ksplit(built_lib, case):

@@ -265,3 +265,32 @@ def test_tf_bundle_reader_feeds_the_importer(built_lib, tmp_path, snappy, block_
     open(prefix + '.index', 'wb').write(bytes(idx))
     with pytest.raises(ValueError):
         tb.load_checkpoint(prefix)
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """bench.py --gpus N (N > 1) without a torchrun environment re-executes itself under torch.distributed.run on 127.0.0.1
+    (VERDICT r5 #1); with fewer GPUs than ranks and no --rehearse-shared-device it refuses with exit code 2."""
+    import argparse
+    import importlib.util
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen['cmd'], seen['env'] = cmd, env
+        return 0
+    monkeypatch.setattr(subprocess, 'call', fake_call)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '2', '--rehearse-shared-device', '--steps', '3'])
+    assert bench.self_launch(argparse.Namespace(gpus=2, rehearse_shared_device=True)) == 0
+    cmd = seen['cmd']
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1']
+    assert cmd[cmd.index('--nproc-per-node') + 1] == '2' and cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert cmd[-5:] == ['--gpus', '2', '--rehearse-shared-device', '--steps', '3'] and cmd[-6].endswith('bench.py')
+    assert seen['env']['GPU_MAX_HW_QUEUES'] == os.environ.get('GPU_MAX_HW_QUEUES', '8')
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if not __import__('torch').cuda.is_available():
+        assert bench.self_launch(argparse.Namespace(gpus=8, rehearse_shared_device=False)) == 2
