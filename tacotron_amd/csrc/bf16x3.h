@@ -78,4 +78,23 @@ inline bool env_bf16x() {
   return !(e && atoi(e) == 0);
 }
 
+// Longest accumulation CHAIN (k-products added into one accumulator register) a launch may have on the bf16x3 form; longer chains
+// take the fp32 MFMA form.  Why (round 6; tools/micro/mfma_bf16_probe.hip, tools/bf16x3_chain_probe.py, profiles/r06_mfma_probe.txt,
+// r06_bf16x3_chain.txt): the matrix pipe rounds every PRODUCT by itself onto the accumulator's grid (2^-26 of its leading bit; both
+// instructions do: 16 products of 1/16 ulp(C) each vanish although their sum is a whole ulp) before adding.  For the fp32 instruction
+// that is an eighth of an ulp per product.  For the split form it means the low-order plane products (l h, h l: 2^-16 of a product)
+// drop out entirely once the accumulator exceeds ~2^11 products' worth -- invisible with mixed signs (accumulators stay small, the
+// losses cancel: Gaussian / post-ReLU x glorot / heavy-tailed operands measure 0.9-1.2 x the fp32 form at every depth up to 6144),
+// but with same-signed operands the accumulator grows linearly and the loss is one-sided: all-ones mantissas, one sign:
+// 3.8e-7 / 8.5e-7 / 1.9e-6 at chains of 256 / 1024 / 2048, then 8.7e-6 at 4096 and 1.7e-5 at 6144 (fp32 form: 2-5e-8).
+// Up to 2048 every case stays inside the 5e-6 the GEMM tests state; beyond it the bf16x3 form is not fp32-grade in the worst
+// case, so it is not used there.  Every launch of the train step is inside the bound (deepest: encoder conv bank width 16 =
+// 16 x 128 = 2048; the deeper reductions -- proj1, the bank input gradient -- are k-split into chains of 768-1741, the weight
+// gradients into row ranges of 320-720); what the bound catches is a plain deep call (taco_conv_gemm with K x taps > 2048) and
+// TACO_DETERMINISTIC=1's one-workgroup-per-tile weight gradients.  TACO_BF16X_MAX_CHAIN overrides (probing).
+inline int bf16x_max_chain() {
+  const char* e = getenv("TACO_BF16X_MAX_CHAIN");
+  return e ? atoi(e) : 2048;
+}
+
 }  // namespace

@@ -747,7 +747,8 @@ template <int WM, int WN>
 static void dispatch_tn(int flags, dim3 grid, hipStream_t s, const GemmTnArgs& a) {
   switch (flags & 3) {
     case 3:
-      if (env_bf16x()) hipLaunchKernelGGL((gemm_tn_kernel<WM, WN, true, true, true>), grid, dim3(256), 0, s, a);
+      // (bf16x3 only for row ranges inside the chain bound, bf16x3.h bf16x_max_chain: TACO_DETERMINISTIC=1's single-workgroup row ranges are not)
+      if (env_bf16x() && a.chunk <= bf16x_max_chain()) hipLaunchKernelGGL((gemm_tn_kernel<WM, WN, true, true, true>), grid, dim3(256), 0, s, a);
       else hipLaunchKernelGGL((gemm_tn_kernel<WM, WN, true, true>), grid, dim3(256), 0, s, a);
       break;
     case 1: hipLaunchKernelGGL((gemm_tn_kernel<WM, WN, true, false>), grid, dim3(256), 0, s, a); break;
@@ -895,7 +896,9 @@ int launch_gemm_tn_batch(GemmTnBatch& b, hipStream_t stream) {
     const int pslot = taco_prof_begin(2, stream);
     taco_prof_label(2, pslot, "tn-batch n=%d blocks=%d first: M=%d N=%d K=%d taps=%d", grouped.n, blocks, grouped.p[0].M, grouped.p[0].N, grouped.p[0].K,
                     grouped.p[0].taps);
-    if (env_bf16x()) hipLaunchKernelGGL(gemm_tn_batch_kernel<true>, dim3(blocks), dim3(256), 0, stream, grouped);
+    int max_chunk = 0;
+    for (int i = 0; i < grouped.n; ++i) max_chunk = grouped.p[i].chunk > max_chunk ? grouped.p[i].chunk : max_chunk;
+    if (env_bf16x() && max_chunk <= bf16x_max_chain()) hipLaunchKernelGGL(gemm_tn_batch_kernel<true>, dim3(blocks), dim3(256), 0, stream, grouped);
     else hipLaunchKernelGGL(gemm_tn_batch_kernel<false>, dim3(blocks), dim3(256), 0, stream, grouped);
     taco_prof_end(2, pslot, stream, flops);
     TACO_LAUNCH_CHECK("gemm_tn_batch");

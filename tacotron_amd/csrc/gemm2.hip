@@ -999,7 +999,14 @@ int launch_conv_gemm2(ConvGemmBatch& batch, hipStream_t stream, bool force) {
     for (int i = 0; i < batch.n; ++i) bank32 = bank32 && batch.p[i].pool == 1 && batch.p[i].K % 32 == 0;
     v = bank32 ? Variant{32, 2} : Variant{16, 4};
   }
-  if (env_bf16x()) {   // 16-deep tiles only (K = 80, K % 32 != 0 and the forward banks alike); the ring depth follows the variant
+  // chain length of the deepest problem in k-products (k-split chunks count with their own [it0, it1) range of 32-deep k-tiles)
+  int64_t chain = 0;
+  for (int i = 0; i < g.batch.n; ++i) {
+    const ConvGemmProblem& p = g.batch.p[i];
+    const int64_t c = p.it1 > 0 ? (int64_t)(p.it1 - p.it0) * 32 : (int64_t)p.taps * p.K;
+    chain = c > chain ? c : chain;
+  }
+  if (env_bf16x() && chain <= bf16x_max_chain()) {   // 16-deep tiles only (K = 80, K % 32 != 0 and the forward banks alike); the ring depth follows the variant
     if (v.bk == 16 && v.ns == 3) return launch_variant<16, 3, true>(g, tiles, stream);
     if (v.bk == 16 && v.ns == 5) return launch_variant<16, 5, true>(g, tiles, stream);
     return launch_variant<16, 4, true>(g, tiles, stream);

@@ -160,60 +160,87 @@ def _ones_mantissa(rng, shape, spread=2):
     return (np.float32(2.0 - 2.0 ** -23) * np.exp2(e).astype(np.float32)).astype(np.float32)
 
 
-@pytest.mark.parametrize('kind', ['ones-mantissa-same-sign', 'heavy-tailed'])
-@pytest.mark.parametrize('kernel', ['nn', 'tn'])
-def test_bf16x3_adversarial_operands(built_lib, kernel, kind, monkeypatch):
-    """Worst-case rather than statistical evidence for the bf16x3 products (VERDICT r5 #9 / next #7a), on BOTH kernels that use them:
-    the NN kernel of gemm2.hip and the weight-gradient kernel of gemm.hip (gemm_tn), K = 6144 deep (encoder proj1's depth).
-    `ones-mantissa-same-sign`: every operand positive with all 23 mantissa bits set -- the dropped plane products (m l, l m, l l) are
-    all of one sign, a coherent relative bias of ~2^-23 that random signs hide; `heavy-tailed`: log-normal magnitudes over ~5 decades
-    (the NN case of test_bf16x3_products_are_fp32_grade, here for gemm_tn as well).  Asserted against an fp64 product: the bf16x3
-    form within 3 x the error of the fp32 MFMA form of the same kernel (floor 1e-7: below that both are at fp32 rounding level),
-    and within the 5e-6 every GEMM test of this file states; the measured errors are printed (and the stricter 4e-7 of the
-    verdict's proposal is reported, asserted only where the fp32 MFMA form itself meets it: with 6,144 same-signed terms the fp32
-    ACCUMULATION of either form performs a random walk of ~sqrt(K / 3) roundings)."""
-    monkeypatch.setenv('TACO_GEMM2_MIN_TILES', '1')
-    monkeypatch.setenv('TACO_GEMM2_VARIANT', '16x4')
-    rng = np.random.default_rng(23)
-    if kernel == 'nn':
-        M, N, K = 512, 256, 6144
+def _adversarial_case(rng, kernel, kind, depth):
+    """(run, ref): the NN kernel of gemm2.hip (M x depth @ depth x N) or the weight-gradient kernel of gemm.hip (dW = A^T dY over
+    `depth` rows) on same-signed all-ones-mantissa or heavy-tailed operands."""
+    def operand(shape, norm):
         if kind == 'heavy-tailed':
-            A = (rng.standard_normal((M, K)) * np.exp(rng.standard_normal((M, K)) * 3)).astype(np.float32)
-            W = (rng.standard_normal((1, K, N)) * np.exp(rng.standard_normal((1, K, N)) * 3) / np.sqrt(K)).astype(np.float32)
-        else:
-            A, W = _ones_mantissa(rng, (M, K)), _ones_mantissa(rng, (1, K, N))
+            return (rng.standard_normal(shape) * np.exp(rng.standard_normal(shape) * 3) / norm).astype(np.float32)
+        return _ones_mantissa(rng, shape)
+    if kernel == 'nn':
+        M, N, K = 512, 256, depth
+        A, W = operand((M, K), 1.0), operand((1, K, N), np.sqrt(K))
         ref = A.astype(np.float64) @ W[0].astype(np.float64)
 
-        def run():
+        def run(built_lib):
             C = torch.full((M, N), float('nan'), device='cuda')
-            before = built_lib.debug_gemm2_window(0, 1 << 30)
+            built_lib.debug_gemm2_window(0, 1 << 30)
             built_lib.conv_gemm(dev(A), dev(W), C, M, N, K, taps=1, T=M, pad_l=0, act=0)
             assert built_lib.debug_gemm2_window(0, 1 << 30) == 1, 'the launch did not go to gemm2.hip'
             return C.cpu().numpy()
     else:
-        M, N, K = 6144, 256, 512          # dW (K, N) = A^T (K, M) dY (M, N): the reduction runs over the M = 6144 rows
-        if kind == 'heavy-tailed':
-            A = (rng.standard_normal((M, K)) * np.exp(rng.standard_normal((M, K)) * 3)).astype(np.float32)
-            dY = (rng.standard_normal((M, N)) * np.exp(rng.standard_normal((M, N)) * 3) / np.sqrt(M)).astype(np.float32)
-        else:
-            A, dY = _ones_mantissa(rng, (M, K)), _ones_mantissa(rng, (M, N))
+        M, N, K = depth, 256, 512          # dW (K, N) = A^T (K, M) dY (M, N): the reduction runs over the M = depth rows
+        A, dY = operand((M, K), 1.0), operand((M, N), np.sqrt(M))
         ref = A.astype(np.float64).T @ dY.astype(np.float64)
 
-        def run():
+        def run(built_lib):
             dW = torch.full((1, K, N), float('nan'), device='cuda')
             built_lib.gemm_tn(dev(A), dev(dY), dW, M, N, K, taps=1, T=M, pad_l=0, accumulate=False)
             return dW[0].cpu().numpy()
+    return run, ref
+
+
+@pytest.mark.parametrize('kind', ['ones-mantissa-same-sign', 'heavy-tailed'])
+@pytest.mark.parametrize('kernel,depth', [('nn', 6144), ('nn', 2048), ('tn', 6144), ('tn-deterministic', 6144)],
+                         ids=['nn-6144', 'nn-2048-deepest-bf16x3-chain', 'tn-6144', 'tn-6144-one-workgroup-per-tile'])
+def test_bf16x3_adversarial_operands(built_lib, kernel, depth, kind, monkeypatch):
+    """Worst-case rather than statistical evidence for the products of the big GEMM kernels (VERDICT r5 #9 / next #7a), on BOTH
+    kernels that have a bf16x3 form: the NN kernel of gemm2.hip and the weight-gradient kernel of gemm.hip (gemm_tn).
+    `ones-mantissa-same-sign`: every operand positive with all 23 mantissa bits set -- no cancellation anywhere: the three dropped
+    plane products (m l, l m, l l) are one-signed, and the accumulator grows linearly, which is what exposes how the matrix pipe adds
+    (it rounds every product by itself onto the accumulator's grid: tools/micro/mfma_bf16_probe.hip); `heavy-tailed`: log-normal
+    magnitudes over ~5 decades.  What the library does about it (bf16x3.h `bf16x_max_chain`): the bf16x3 form is used for accumulation
+    chains of at most 2048 products; deeper ones run the fp32 MFMA instruction.  Asserted, default settings against an fp64 product:
+      * depth 6144 (encoder proj1's depth), NN and gemm_tn, split and single-workgroup row ranges: <= 4e-7 and <= 3 x the error
+        of the forced fp32 MFMA form (floor 1e-7) -- the verdict's bar, met because deep chains are not on the bf16x3 form
+        (gemm_tn's split row ranges are 384 rows each and stay on it);
+      * depth 2048, the deepest chain the bf16x3 form is used for (the encoder conv bank's width 16): within the 5e-6 every GEMM
+        test of this file states; heavy-tailed also <= 3 x the fp32 form.  For same-signed full mantissas it measures 1.9e-6 against
+        2e-8 of the fp32 instruction: the 4e-7 bar is NOT met there, and bench.py's `dtype_note` says so."""
+    monkeypatch.setenv('TACO_GEMM2_MIN_TILES', '1')
+    monkeypatch.setenv('TACO_GEMM2_VARIANT', '16x4')
+    if kernel == 'tn-deterministic':
+        monkeypatch.setenv('TACO_DETERMINISTIC', '1')
+    run, ref = _adversarial_case(np.random.default_rng(23), kernel[:2], kind, depth)
     err = {}
     for bx in ('0', '1'):
         monkeypatch.setenv('TACO_GEMM2_BF16X', bx)
-        err[bx] = report('%s %s %s' % (kernel, kind, 'bf16x3' if bx == '1' else 'fp32  '), run(), ref)
-    print('  %s / %s: rel-L2 bf16x3 %.2e vs fp32 MFMA %.2e (ratio %.2f); 4e-7 bar: bf16x3 %s, fp32 MFMA %s'
-          % (kernel, kind, err['1'][0], err['0'][0], err['1'][0] / max(err['0'][0], 1e-30),
+        err[bx] = report('%s depth %d %s %s' % (kernel, depth, kind, 'default' if bx == '1' else 'fp32  '), run(built_lib), ref)
+    print('  %s depth %d / %s: rel-L2 default %.2e vs forced fp32 MFMA %.2e (ratio %.2f); 4e-7 bar: default %s, fp32 MFMA %s'
+          % (kernel, depth, kind, err['1'][0], err['0'][0], err['1'][0] / max(err['0'][0], 1e-30),
              'met' if err['1'][0] <= 4e-7 else 'NOT met', 'met' if err['0'][0] <= 4e-7 else 'NOT met'))
     assert err['0'][0] < 5e-6 and err['1'][0] < 5e-6
-    assert err['1'][0] <= 3.0 * max(err['0'][0], 1e-7)
-    if err['0'][0] <= 4e-7 / 3:
-        assert err['1'][0] <= 4e-7
+    if depth > 2048:
+        assert err['1'][0] <= 3.0 * max(err['0'][0], 1e-7)
+        assert err['1'][0] <= max(4e-7, 1.05 * err['0'][0])     # (heavy-tailed NN: the fp32 instruction itself measures 4.3e-7 at this depth)
+    elif kind == 'heavy-tailed':
+        assert err['1'][0] <= 3.0 * max(err['0'][0], 1e-7)
+
+
+def test_bf16x3_chain_bound_is_what_keeps_deep_same_signed_sums_fp32_grade(built_lib, monkeypatch):
+    """The reason for `bf16x_max_chain` (bf16x3.h), kept executable: with the bound lifted, a 6144-deep sum of same-signed
+    full-mantissa products on the bf16x3 form is ~300 x less accurate than on the fp32 instruction (measured 1.7e-5 vs 5e-8: the
+    low-order plane products are each rounded away against the large accumulator), while mixed-sign operands are unaffected at
+    any depth (0.9-1.2 x; tools/bf16x3_chain_probe.py, profiles/r06_bf16x3_chain.txt).  If this test ever FAILS because the
+    forced form has become accurate, the bound can go."""
+    monkeypatch.setenv('TACO_GEMM2_MIN_TILES', '1')
+    monkeypatch.setenv('TACO_GEMM2_VARIANT', '16x4')
+    monkeypatch.setenv('TACO_GEMM2_BF16X', '1')
+    run, ref = _adversarial_case(np.random.default_rng(23), 'nn', 'ones-mantissa-same-sign', 6144)
+    bounded = report('nn 6144 same-signed, default bound', run(built_lib), ref)[0]
+    monkeypatch.setenv('TACO_BF16X_MAX_CHAIN', str(1 << 30))
+    forced = report('nn 6144 same-signed, bf16x3 forced ', run(built_lib), ref)[0]
+    assert bounded <= 4e-7 and forced > 10 * bounded and forced > 5e-6
 
 
 @pytest.mark.parametrize('case', [(1000, 200, 128, 2048, 3, 1, 1), (520, 130, 256, 1024, 3, 1, 0), (300, 300, 132, 516, 1, 0, 3)],
