@@ -23,7 +23,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default)
 
-#define TACO_VERSION 116
+#define TACO_VERSION 117
 
 #define TACO_OK 0
 #define TACO_EINVAL (-1)   /* bad argument / unsupported shape   */
@@ -86,6 +86,15 @@ int taco_conv_gemm(const float* A, int lda, const float* W, int ldw, const float
 /* debug: only the eligible NN launches whose running index falls in [lo, hi) use gemm2.hip's kernel (bisecting a divergence);
  * returns the number of eligible (non-pooled) launches seen since the previous call and restarts the count */
 int taco_debug_gemm2_window(int lo, int hi);
+/* Pre-split weight images (round 6; csrc/kernels.h "weight images"): the bf16 plane image of a weight tensor W (taps, K, N; row pitch
+ * ldw) that gemm2.hip's NN kernel reads instead of splitting W in registers.  The model-level entry points build the images of
+ * their own weights themselves (into the workspace); this is the op-level door for parity tests and tools.
+ *   W == NULL: clears this host thread's table, returns the number of launches that ran the image form since the previous such
+ *   call (all threads).   img == NULL: returns the bytes image(W) needs.
+ *   otherwise: registers image(W) at img (16-byte aligned, img_bytes >= that size) and enqueues its build on `stream`; the
+ *   following taco_conv_gemm / taco_debug_conv_gemm_* calls of this thread whose weight pointer, pitch, taps, K equal W's and whose
+ *   N <= N run the image form.  Replaces nothing in the reference (TF holds fp32 kernels only; models/ops.py:54-60,80-86). */
+int64_t taco_debug_weight_image(const float* W, int ldw, int taps, int K, int N, void* img, int64_t img_bytes, void* stream);
 /* debug / test aid: dense layer with weight rows zero-padded to nld loadable columns (the final 256 -> 1025 layer's form) */
 int taco_debug_conv_gemm_nld(const float* A, int lda, const float* W, int ldw, int nld, const float* bias, float* C, int ldc, int M,
                              int N, int K, int act, void* stream);

@@ -101,15 +101,17 @@ struct Gemm2Args {
   int bk_pa[8], bk_a0[8], bk_na[8], bk_pb[8], bk_b0[8], bk_nb[8];
 };
 
-template <int BK, int NS, bool BX = false>
+// BX: 0 = v_mfma_f32_32x32x2_f32; 1 = bf16x3 products, both operands split into planes in registers; 2 (round 6) = bf16x3 with
+// the B (weight) operand read as READY-MADE plane fragments from a pre-split image (WImg below): only A is split in registers
+template <int BK, int NS, int BX = 0>
 __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
   static_assert(!BX || BK == 16, "the bf16x3 form works on 16-deep k-tiles (one v_mfma_f32_32x32x16_bf16 group per tile)");
   constexpr int SLOTS = BK / 4;               // 16-byte slots per A row
   constexpr int A_RPI = 64 / SLOTS;           // A rows per wave instruction: 8 (BK = 32) / 16 (BK = 16)
   constexpr int A_INSTR = TM / A_RPI / 4;     // per wave
-  constexpr int B_INSTR = BK / 2 / 4;         // one instruction = 2 k-rows of 128 floats; per wave
+  constexpr int B_INSTR = BX == 2 ? kWImgTileBytes / 4096 : BK / 2 / 4;   // one instruction = 2 k-rows of 128 floats (BX == 2: 1 KB of the image tile); per wave
   constexpr int NLD = A_INSTR + B_INSTR;      // DMA instructions per wave per k-tile
-  constexpr int A_FLOATS = TM * BK, B_FLOATS = BK * TN, STAGE = A_FLOATS + B_FLOATS;
+  constexpr int A_FLOATS = TM * BK, B_FLOATS = BX == 2 ? kWImgTileBytes / 4 : BK * TN, STAGE = A_FLOATS + B_FLOATS;
   constexpr int SWZ_SH = BK == 32 ? 1 : 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];   // NS * STAGE floats, the ONLY LDS object of the kernel
 
@@ -164,7 +166,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
 
   // ---- DMA source setup: each thread serves the same A rows / B slots for every k-tile.  Byte offsets against
   //      A - pad_l rows (so that the tap shift is a non-negative scalar) and W; the launcher bounds both below 2 GiB ----
-  const __amdgpu_buffer_rsrc_t rsA = dma_rsrc(P.A - (int64_t)pad_l * lda), rsW = dma_rsrc(P.W);
+  const __amdgpu_buffer_rsrc_t rsA = dma_rsrc(P.A - (int64_t)pad_l * lda),
+                               rsW = dma_rsrc(BX == 2 ? reinterpret_cast<const float*>(P.Wimg) : P.W);
   int a_vo[A_INSTR], a_cur[A_INSTR], a_t[A_INSTR], a_klim[A_INSTR];
 #pragma unroll
   for (int i = 0; i < A_INSTR; ++i) {
@@ -180,7 +183,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
   const bool b_ok = b_c < P.Nld;
   const int b_r0 = wave * B_INSTR * 2 + (lane >> 5);
   const int b_klim = K - b_r0;                   // row k0 + 2 i + b_r0 exists while k0 + 2 i < b_klim
-  const int b_vo = b_ok ? (b_r0 * ldw + b_c) * 4 : kOOB;
+  // BX == 2: the image tile of (n-tile, k-tile `it`) is 12 KB of fragment-ordered planes, contiguous, already zero-padded:
+  // wave w copies its 1 KB pieces 4 i + w, no masks; the tile index goes into the scalar offset
+  const int b_vo = BX == 2 ? (wave * 1024 + lane * 16) : (b_ok ? (b_r0 * ldw + b_c) * 4 : kOOB);
 
   // k-tiles per tap, counted so that a tap always spans whole 32-deep units (a k-split chunk [it0, it1) is given in those
   // units whatever BK is; with BK = 16 an odd tail tile is all-masked zeros)
@@ -190,6 +195,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
 
   // next tile to issue: (tap, k0) advance incrementally (no division on the loop path)
   int n_tap = it_begin / ktiles, n_k0 = (it_begin - n_tap * ktiles) * BK;
+  int n_img = (tnn * P.img_its + it_begin) * kWImgTileBytes;   // BX == 2: byte offset of the next image tile to issue
   // row shift of the tap (t_sh) and, in the conv bank's gather mode (ConvGemmProblem::bank_filters), the filter it belongs to
   // (bf, tap bj of it) with the column block of A that filter reads (t_col)
   const int bankF = P.bank_filters;
@@ -217,11 +223,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
       blds16(rsA, vo, ((t_sh + pad_l) * lda + t_col + n_k0) * 4, As + (wave * A_INSTR + g) * A_RPI * BK);
     } else {
       const int i = g - A_INSTR;
-      const int vo = n_k0 + 2 * i < b_klim ? b_vo : kOOB;
-      blds16(rsW, vo, ((n_tap * K + n_k0 + 2 * i) * ldw) * 4, As + A_FLOATS + (wave * B_INSTR + i) * 2 * TN);
+      if constexpr (BX == 2) {
+        blds16(rsW, b_vo, n_img + i * 4096, As + A_FLOATS + (4 * i + wave) * 256);
+      } else {
+        const int vo = n_k0 + 2 * i < b_klim ? b_vo : kOOB;
+        blds16(rsW, vo, ((n_tap * K + n_k0 + 2 * i) * ldw) * 4, As + A_FLOATS + (wave * B_INSTR + i) * 2 * TN);
+      }
     }
   };
   auto advance = [&]() __attribute__((always_inline)) {
+    if constexpr (BX == 2) n_img += kWImgTileBytes;
     n_k0 += BK;
     if (n_k0 >= ktiles * BK) {
       n_k0 = 0;
@@ -348,8 +359,59 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
     asm volatile("" : "+v"(pb2_c.h), "+v"(pb2_c.m), "+v"(pb2_c.l), "+v"(pb3_c.h), "+v"(pb3_c.m), "+v"(pb3_c.l));
     __builtin_amdgcn_sched_barrier(0);
   };
+  // ---- BX == 2: the B planes come ready-made from the image (12 conflict-free ds_read_b128: plane P of sub-tile j is the
+  //      wave's 1 KB run (4 P + j), lane-ordered), only A is split: 44 instead of 220 VALU operations per 24 MFMAs.  Same software
+  //      pipeline as above: sub-tiles 2 / 3 of tile t - 1 (planes carried in registers) cover the LDS latency of tile t's reads. ----
+  Pl3 qb2_c = zero_pl3(), qb3_c = zero_pl3();
+  auto compute_bi = [&](int stage, int fill_stage, auto fill_c) __attribute__((always_inline)) {
+    constexpr bool fill = decltype(fill_c)::value;
+    const uint32_t sb = lds0 + (uint32_t)stage * (STAGE * 4u);
+    const uint32_t bb = sb + (uint32_t)(A_FLOATS * 4) + (uint32_t)lane * 16u;
+    const f32x4 ra0 = dsr128<0>(sb + a_off[0]);
+    const f32x4 ra1 = dsr128<0>(sb + a_off[NP - 1]);
+    u32x4 pl[4][3];
+    static_for<0, 4>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      static_for<0, 3>([&](auto pc) {
+        constexpr int pp = decltype(pc)::value;
+        pl[j][pp] = __builtin_bit_cast(u32x4, dsr128<(4 * pp + j) * 1024>(bb));
+      });
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    mfma6(acc[2], pa_c, qb2_c);
+#ifndef GEMM2_LAB_NODMA
+    if (fill) {
+#pragma unroll
+      for (int g = 0; g < NLD; ++g) issue_piece(g, fill_stage);
+    }
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    wait_lgkm<12>();                 // the two A reads were issued first
+    __builtin_amdgcn_sched_barrier(0);
+    mfma6(acc[3], pa_c, qb3_c);      // (still the previous tile's A planes)
+    const Pl3 pa_n = split8(ra0[0], ra0[1], ra0[2], ra0[3], ra1[0], ra1[1], ra1[2], ra1[3]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {    // one MFMA, then its share of the 44 split instructions
+      __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x2, 8, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    wait_lgkm<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    pa_c = pa_n;
+    Pl3 q0, q1;
+    q0.h = pl[0][0]; q0.m = pl[0][1]; q0.l = pl[0][2];
+    q1.h = pl[1][0]; q1.m = pl[1][1]; q1.l = pl[1][2];
+    mfma6(acc[0], pa_c, q0);
+    mfma6(acc[1], pa_c, q1);
+    qb2_c.h = pl[2][0]; qb2_c.m = pl[2][1]; qb2_c.l = pl[2][2];
+    qb3_c.h = pl[3][0]; qb3_c.m = pl[3][1]; qb3_c.l = pl[3][2];
+    asm volatile("" : "+v"(qb2_c.h), "+v"(qb2_c.m), "+v"(qb2_c.l), "+v"(qb3_c.h), "+v"(qb3_c.m), "+v"(qb3_c.l));
+    __builtin_amdgcn_sched_barrier(0);
+  };
   auto run_tile = [&](int stage, int fill_stage, auto fill_c) __attribute__((always_inline)) {
-    if constexpr (BX) compute_bx(stage, fill_stage, fill_c);
+    if constexpr (BX == 2) compute_bi(stage, fill_stage, fill_c);
+    else if constexpr (BX == 1) compute_bx(stage, fill_stage, fill_c);
     else compute(stage, fill_stage, fill_c);
   };
 
@@ -383,9 +445,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
     asm volatile("" ::: "memory");
     run_tile(it % NS, 0, std::false_type{});
   }
-  if constexpr (BX) {   // the last tile's sub-tiles 2 / 3
+  if constexpr (BX == 1) {   // the last tile's sub-tiles 2 / 3
     mfma6(acc[2], pa_c, pb2_c);
     mfma6(acc[3], pa_c, pb3_c);
+  }
+  if constexpr (BX == 2) {
+    mfma6(acc[2], pa_c, qb2_c);
+    mfma6(acc[3], pa_c, qb3_c);
   }
   wait_vm<0>();   // (nothing outstanding by construction; keeps the invariant explicit before the epilogue's ordinary loads)
 
@@ -851,9 +917,9 @@ Variant env_variant() {   // read on every launch (tests and the tuning harness 
   }
   return r;
 }
-template <int BK, int NS, bool BX = false>
+template <int BK, int NS, int BX = 0>
 int launch_variant(const Gemm2Args& g, int tiles, hipStream_t s) {
-  constexpr size_t smem = (size_t)NS * (TM * BK + BK * TN) * sizeof(float);
+  constexpr size_t smem = (size_t)NS * ((size_t)TM * BK * sizeof(float) + (BX == 2 ? (size_t)kWImgTileBytes : (size_t)BK * TN * sizeof(float)));
   static DynSmemOnce once;
   TACO_REQUIRE(ensure_dyn_smem(once, reinterpret_cast<const void*>(conv_gemm2_kernel<BK, NS, BX>), smem),
                "conv_gemm2: cannot reserve %zu bytes of LDS", smem);
@@ -861,7 +927,101 @@ int launch_variant(const Gemm2Args& g, int tiles, hipStream_t s) {
   return TACO_OK;
 }
 
+
+// ---- weight images (kernels.h): builder kernel and the per-thread table ----
+constexpr int kMaxWImgJobs = 40;
+struct WImgJob {
+  const float* W;
+  unsigned short* img;
+  int ldw, taps, K, N, kt, first;   // kt = k-tiles of 16 per tap (whole 32-deep units, as the GEMM kernel counts them); first = first block
+};
+struct WImgBatch {
+  WImgJob j[kMaxWImgJobs];
+  int n;
+};
+// one workgroup per (job, n-tile, k-tile): thread (j, li, kh) reads its 8 k-slots of column 128 nb + 4 li + j (coalesced: a wave reads
+// 64 consecutive columns of one row per slot), splits them exactly as the GEMM kernel would (split8) and writes three 16-byte fragments
+__global__ __launch_bounds__(256) void weight_image_kernel(WImgBatch B) {
+  int ji = 0;
+  for (int i = 1; i < B.n; ++i)
+    if ((int)blockIdx.x >= B.j[i].first) ji = i;
+  const WImgJob& J = B.j[ji];
+  const int rel = blockIdx.x - J.first;
+  const int its = J.taps * J.kt;
+  const int nb = rel / its, it = rel - nb * its;
+  const int tap = it / J.kt, k0 = (it - tap * J.kt) * 16;
+  const int t = threadIdx.x, j = t & 3, li = (t >> 2) & 31, kh = t >> 7;
+  const int n = nb * 128 + 4 * li + j;
+  float w[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int k = k0 + 8 * (q >> 2) + 4 * kh + (q & 3);
+    w[q] = (k < J.K && n < J.N) ? J.W[((int64_t)tap * J.K + k) * J.ldw + n] : 0.f;
+  }
+  const Pl3 p = split8(w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]);
+  u32x4* dst = reinterpret_cast<u32x4*>(reinterpret_cast<char*>(J.img) + ((int64_t)nb * its + it) * kWImgTileBytes) + (j * 64 + kh * 32 + li);
+  dst[0] = p.h;
+  dst[4 * 64] = p.m;
+  dst[8 * 64] = p.l;
+}
+
+struct WImgEntry {
+  const float* W;
+  const void* img;
+  int ldw, taps, K, N, its;
+};
+constexpr int kMaxWImgEntries = 96;
+thread_local WImgEntry g_wimg[kMaxWImgEntries];
+thread_local int g_wimg_n = 0;
+thread_local WImgBatch g_wimg_q;
+
 }  // namespace
+
+static inline int wimg_kt(int K) { return ((K + 31) / 32) * 2; }
+int64_t weight_image_bytes(int taps, int K, int N) { return (int64_t)cdiv(N, 128) * taps * wimg_kt(K) * kWImgTileBytes; }
+void weight_images_clear() {
+  g_wimg_n = 0;
+  g_wimg_q.n = 0;
+}
+int weight_image_add(const float* W, int ldw, int taps, int K, int N, void* img, bool queue_build, const float* src, int src_ldw) {
+  TACO_REQUIRE(W && img && (reinterpret_cast<uintptr_t>(img) & 15) == 0 && taps > 0 && K > 0 && N > 0 && N <= ldw && (!src || N <= src_ldw),
+               "weight_image_add: bad arguments");
+  TACO_REQUIRE(g_wimg_n < kMaxWImgEntries, "weight_image_add: table full (%d)", kMaxWImgEntries);
+  TACO_REQUIRE(weight_image_bytes(taps, K, N) < ((int64_t)1 << 31), "weight_image_add: image beyond 2 GiB");
+  g_wimg[g_wimg_n++] = WImgEntry{W, img, ldw, taps, K, N, taps * wimg_kt(K)};
+  if (queue_build) {
+    TACO_REQUIRE(g_wimg_q.n < kMaxWImgJobs, "weight_image_add: build queue full (call weight_images_build every %d jobs)", kMaxWImgJobs);
+    WImgJob& j = g_wimg_q.j[g_wimg_q.n++];
+    j.W = src ? src : W; j.img = reinterpret_cast<unsigned short*>(img); j.ldw = src ? src_ldw : ldw; j.taps = taps; j.K = K; j.N = N; j.kt = wimg_kt(K); j.first = 0;
+  }
+  return TACO_OK;
+}
+int weight_images_build(hipStream_t s) {
+  if (g_wimg_q.n == 0) return TACO_OK;
+  int blocks = 0;
+  for (int i = 0; i < g_wimg_q.n; ++i) {
+    WImgJob& j = g_wimg_q.j[i];
+    j.first = blocks;
+    blocks += cdiv(j.N, 128) * j.taps * j.kt;
+  }
+  hipLaunchKernelGGL(weight_image_kernel, dim3(blocks), dim3(256), 0, s, g_wimg_q);
+  TACO_LAUNCH_CHECK("weight_image_kernel");
+  g_wimg_q.n = 0;
+  return TACO_OK;
+}
+const void* weight_image_find(const float* W, int ldw, int taps, int K, int N, int* its) {
+  for (int i = 0; i < g_wimg_n; ++i) {
+    const WImgEntry& e = g_wimg[i];
+    // (columns between the registered N and the end of its last 4-column group are zeros of the image: a launch whose loadable
+    //  width is N rounded up to the float4 contract -- the final dense layer: 1025 -> 1028 -- reads the same values it would
+    //  read from its zero-padded fp32 copy)
+    if (e.W == W && e.ldw == ldw && e.taps == taps && e.K == K && N <= (e.N + 3) / 4 * 4) {
+      *its = e.its;
+      return e.img;
+    }
+  }
+  return nullptr;
+}
 
 int gemm2_min_tiles() {
   const char* e = getenv("TACO_GEMM2_MIN_TILES");   // 0 disables the second-generation kernel
@@ -872,11 +1032,33 @@ int gemm2_min_tiles() {
 // with 128 x 128 tiles; the caller then falls back to conv_gemm_kernel.
 // debug: only the eligible launches whose running index falls in [lo, hi) use the new kernel (bisecting a divergence)
 static int g_win_lo = 0, g_win_hi = 1 << 30, g_win_idx = 0;
+static int64_t g_img_launches = 0;   // launches that took the B-image form since the last taco_debug_weight_image(NULL, ...)
 extern "C" __attribute__((visibility("default"))) int taco_debug_gemm2_window(int lo, int hi) {
   g_win_lo = lo; g_win_hi = hi;
   const int n = g_win_idx;
   g_win_idx = 0;
   return n;   // eligible launches seen since the last call
+}
+
+// Op-level access to the weight images (tests, tools): W == null clears this thread's table; img == null returns the bytes
+// image(W) needs; otherwise registers image(W) at img and builds it on `stream` -- the next taco_conv_gemm calls of this thread
+// whose weights are W then run the B-image form of the kernel.
+extern "C" __attribute__((visibility("default"))) int64_t taco_debug_weight_image(const float* W, int ldw, int taps, int K, int N, void* img,
+                                                                                  int64_t img_bytes, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (!W) {
+    weight_images_clear();
+    const int64_t n = g_img_launches;
+    g_img_launches = 0;
+    return n;
+  }
+  if (taps <= 0 || K <= 0 || N <= 0) return TACO_EINVAL;
+  const int64_t need = weight_image_bytes(taps, K, N);
+  if (!img) return need;
+  if (img_bytes < need) return TACO_EINVAL;
+  const int rc = weight_image_add(W, ldw, taps, K, N, img, true);
+  if (rc != TACO_OK) return rc;
+  return weight_images_build(stream);
 }
 
 // m-tiles of a problem: pooled problems advance by TM - 1 rows (the last row of a tile is the next tile's first)
@@ -1007,9 +1189,24 @@ int launch_conv_gemm2(ConvGemmBatch& batch, hipStream_t stream, bool force) {
     chain = c > chain ? c : chain;
   }
   if (env_bf16x() && chain <= bf16x_max_chain()) {   // 16-deep tiles only (K = 80, K % 32 != 0 and the forward banks alike); the ring depth follows the variant
-    if (v.bk == 16 && v.ns == 3) return launch_variant<16, 3, true>(g, tiles, stream);
-    if (v.bk == 16 && v.ns == 5) return launch_variant<16, 5, true>(g, tiles, stream);
-    return launch_variant<16, 4, true>(g, tiles, stream);
+    // every problem's weights have a pre-split plane image (weight_image_add): the B-image form.  TACO_GEMM2_BSPLIT=0: never (A/B runs).
+    const char* eb2 = getenv("TACO_GEMM2_BSPLIT");
+    bool img = !(eb2 && atoi(eb2) == 0);
+    for (int i = 0; i < g.batch.n && img; ++i) {
+      ConvGemmProblem& p = g.batch.p[i];
+      p.Wimg = weight_image_find(p.W, p.ldw, p.taps, p.K, p.Nld > 0 ? p.Nld : p.N, &p.img_its);
+      img = p.Wimg != nullptr;
+    }
+    if (img) {
+      ++g_img_launches;
+      // 20 KB per stage: three stages = 60 KB (two workgroups per CU), four = 80 KB (2 x 80 = the CU's whole 160 KB)
+      static const int bi_ns = [] { const char* e = getenv("TACO_GEMM2_BI_NS"); return e ? atoi(e) : 3; }();
+      if (bi_ns == 4) return launch_variant<16, 4, 2>(g, tiles, stream);
+      return launch_variant<16, 3, 2>(g, tiles, stream);
+    }
+    if (v.bk == 16 && v.ns == 3) return launch_variant<16, 3, 1>(g, tiles, stream);
+    if (v.bk == 16 && v.ns == 5) return launch_variant<16, 5, 1>(g, tiles, stream);
+    return launch_variant<16, 4, 1>(g, tiles, stream);
   }
   if (v.bk == 32 && v.ns == 2) return launch_variant<32, 2>(g, tiles, stream);
   if (v.bk == 32 && v.ns == 3) return launch_variant<32, 3>(g, tiles, stream);

@@ -46,6 +46,10 @@ struct ConvGemmProblem {
   const float* pool_x = nullptr;
   float* pool_dgamma = nullptr;
   float* pool_dbeta = nullptr;
+  // gemm2.hip only, filled by launch_conv_gemm2 from the weight-image table (weight_image_find): the pre-split bf16 plane image
+  // of W and its k-tiles (of 16) per n-tile; null = split W in registers
+  const void* Wimg = nullptr;
+  int img_its = 0;
 };
 struct ConvGemmBatch {
   ConvGemmProblem p[kMaxGemmBatch];
@@ -75,6 +79,24 @@ int launch_conv_gemm2(ConvGemmBatch& batch, hipStream_t stream, bool force = fal
 // run conv + bn_maxpool as two launches otherwise
 bool conv_gemm2_would_launch(const ConvGemmBatch& batch);
 int gemm2_min_tiles();   // TACO_GEMM2_MIN_TILES (0 disables gemm2.hip)
+// ---- pre-split weight images (gemm2.hip, round 6).  The bf16x3 form of the NN kernel needs the three bf16 planes (h, m, l) of both
+// operands; splitting the B (weight) tile costs every wave 176 VALU operations per 24 MFMAs, identically in all four waves of a
+// workgroup and in every workgroup that reads the tile.  The weights change once per step, so their planes are formed ONCE per
+// step into an IMAGE the kernel can DMA and read as ready MFMA fragments:
+//   image(W)[n-tile][k-tile it][plane P = h, m, l][sub-tile j][kh][li][q]  (bf16),  k-tile = 16 k-values of one tap, it = tap * kt + k0 / 16,
+//   element = plane P of W[tap][16 kt' + 8 (q >> 2) + 4 kh + (q & 3)][128 n-tile + 4 li + j], zero outside K x N --
+//   12 KB per (n-tile, k-tile), contiguous in `it` (taps, k-split chunks and the conv bank's global tap index are all runs of it).
+// The table is per host thread and is rebuilt by every model-level entry point (taco_forward / taco_backward / taco_infer) from
+// the parameter and workspace pointers of THAT call; the images themselves live in the caller's workspace, are built by
+// taco_forward / taco_infer and stay valid until the parameters change (like the transposed copies in `paramsT`).
+constexpr int kWImgTileBytes = 3 * 16 * 128 * 2;
+int64_t weight_image_bytes(int taps, int K, int N);                          // size of image(W) for W of (taps, K, N)
+void weight_images_clear();                                                  // empties the table (and the queue of unbuilt jobs)
+// registers image(W) at `img` (16-byte aligned, weight_image_bytes large) and queues its build; N = loadable columns of W (<= ldw)
+// src / src_ldw (optional): where the builder reads the values when that is not W itself (a re-pitched copy that is made later)
+int weight_image_add(const float* W, int ldw, int taps, int K, int N, void* img, bool queue_build, const float* src = nullptr, int src_ldw = 0);
+int weight_images_build(hipStream_t s);                                      // one launch per <= 40 queued jobs
+const void* weight_image_find(const float* W, int ldw, int taps, int K, int N, int* its);   // null when W has no (matching) image
 // The CBHG's highway layers as one launch (highway.hip).  Layer l: th[l] = [sigmoid(x Wt+bt) | relu(x Wh+bh)] (M,256),
 // y[l] = H*T + x*(1-T) (M,128) feeds layer l+1.
 struct HighwayStackArgs {

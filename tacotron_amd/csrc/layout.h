@@ -97,9 +97,45 @@ struct WsLayout {
   int64_t post_dpj1, post_dz1, post_dpool, post_dx;
   int64_t enc_dpj1, enc_dz1, enc_dpool, enc_dx, pre_dz2, pre_dz1, pre_demb;   // likewise for the encoder CBHG / pre-net (side-stream weight gradients)   // post-net backward operands that outlive cbhg_bwd (deferred weight gradients)
   int64_t gA, gB, gC, gD, gE, gF, gG, scratch;
+  int64_t wimg = -1;  // pre-split weight images (for_each_weight_image order; each 16-byte aligned)
   int64_t total = 0;  // floats
   std::vector<TacoTensorInfo> rows;
 };
+
+// Which weights get a pre-split bf16 plane image (kernels.h "weight images"): the B operands of the NN launches that run on
+// gemm2.hip's bf16x3 form.  f(key_src, key_off, key_ldw, data_src, data_off, data_ldw, taps, K, N, backward):
+//   *_src: 0 = parameter buffer, 1 = workspace paramsT region, 2 = workspace wd_pad; key = the pointer / pitch the GEMM launch
+//   passes (what the table is searched by), data = where the builder reads the values (post/dense: the parameters themselves --
+//   wd_pad is a re-pitched copy made by a side-stream launch that may not have run yet).  One list for the workspace layout
+//   (sizes) and for model.hip (registration + build), so the two cannot drift apart.
+template <class F>
+inline void for_each_weight_image(const ParamLayout& P, const TransLayout& T, bool train, F f) {
+  const CbhgP* cp[2] = {&P.enc, &P.post};
+  const CbhgT* ct[2] = {&T.enc, &T.post};
+  for (int i = 0; i < 2; ++i) {
+    const CbhgP& c = *cp[i];
+    for (int k = 1; k <= c.K; ++k) f(0, c.bank_w[k - 1], kCb, 0, c.bank_w[k - 1], kCb, k, c.cin, kCb, false);   // conv bank, width k
+    f(0, c.p1_w, c.c1, 0, c.p1_w, c.c1, 3, c.K * kCb, c.c1, false);                                           // proj1 (k-split)
+    const GruP* g[2] = {&c.fw, &c.bw};
+    for (int d = 0; d < 2; ++d) {                                                                           // bi-GRU x-projections
+      f(0, g[d]->wg, 2 * kCb, 0, g[d]->wg, 2 * kCb, 1, kCb, 2 * kCb, false);
+      f(0, g[d]->wc, kCb, 0, g[d]->wc, kCb, 1, kCb, kCb, false);
+    }
+  }
+  f(2, 0, 1028, 0, P.post_dense.w, kFft, 1, 2 * kCb, kFft, false);                                            // final dense layer
+  if (!train) return;
+  for (int i = 0; i < 2; ++i) {
+    const CbhgP& c = *cp[i];
+    const CbhgT& t = *ct[i];
+    f(1, t.bank[0], c.cin, 1, t.bank[0], c.cin, c.K * (c.K + 1) / 2, kCb, c.cin, true);     // bank input gradient: all widths' taps, one reduction
+    f(1, t.p1, c.K * kCb, 1, t.p1, c.K * kCb, 3, c.c1, c.K * kCb, true);                    // proj1 input gradient (d pool)
+    f(1, t.gru_x, kCb, 1, t.gru_x, kCb, 1, 6 * kCb, kCb, true);                             // bi-GRU x-projection input gradient
+  }
+  f(1, T.post_dense, 2 * kCb, 1, T.post_dense, 2 * kCb, 1, 1028, 2 * kCb, true);            // final dense input gradient (K padded to 1028)
+}
+inline int64_t weight_image_floats(int taps, int K, int N) {   // = kernels.h weight_image_bytes / 4 (12 KB per (n-tile, 16-deep k-tile))
+  return (int64_t)((N + 127) / 128) * taps * (((K + 31) / 32) * 2) * 3072;
+}
 
 void build_param_layout(const TacoShape& s, ParamLayout& L);
 void build_trans_layout(const TacoShape& s, const ParamLayout& P, TransLayout& T);

@@ -286,5 +286,10 @@ void build_ws_layout(const TacoShape& s, bool train, const TransLayout& T, WsLay
     W.enc_dpj1 = W.enc_dz1 = W.enc_dpool = W.enc_dx = W.pre_dz2 = W.pre_dz1 = W.pre_demb = -1;
     W.gA = W.gB = W.gC = W.gD = W.gE = W.gF = W.gG = W.scratch = -1;
   }
+  {
+    int64_t fl = 0;
+    for_each_weight_image(P, T, train, [&](int, int64_t, int, int, int64_t, int, int taps, int K, int N, bool) { fl += weight_image_floats(taps, K, N); });
+    W.wimg = a.add("gemm.wimg", {fl});
+  }
   W.total = (a.off + 63) / 64 * 64;
 }

@@ -397,6 +397,29 @@ void note_decoder_fallback(int B, int Tt, int r) {
                     "co-resident): decoder.hip runs the decoder, about 2x slower per step\n", B, Tt, r);
 }
 
+// Pre-split weight images (kernels.h): rebuilds this thread's table for THIS call's parameter / workspace pointers, in the order
+// of for_each_weight_image (= the order the workspace region was sized in).  phase 0: forward weights, phase 1: backward
+// (transposed) weights; `build`: queue the images of that phase for weight_images_build (taco_forward / taco_infer), or only
+// register them (taco_backward: they were built by the taco_forward that ran on this workspace).  TACO_GEMM2_BSPLIT=0: no images.
+static int register_weight_images(const Layouts& L, const WsLayout& W, const float* P, float* ws, bool train, int phase, bool build) {
+  const char* e = getenv("TACO_GEMM2_BSPLIT");
+  if ((e && atoi(e) == 0) || W.wimg < 0) return TACO_OK;
+  int rc = TACO_OK;
+  int64_t off = 0;
+  for_each_weight_image(L.P, L.T, train, [&](int ksrc, int64_t koff, int kld, int dsrc, int64_t doff, int dld, int taps, int K, int N, bool bwd) {
+    const int64_t mine = off;
+    off += weight_image_floats(taps, K, N);
+    if ((bwd ? 1 : 0) != phase || rc != TACO_OK) return;
+    auto at = [&](int src, int64_t o) -> const float* {
+      return src == 0 ? P + o : (src == 1 ? ws + W.paramsT + o : ws + W.wd_pad + o);
+    };
+    const float* key = at(ksrc, koff);
+    const float* data = at(dsrc, doff);
+    rc = weight_image_add(key, kld, taps, K, N, ws + W.wimg + mine, build, data == key && dld == kld ? nullptr : data, dld);
+  });
+  return rc;
+}
+
 // encoder + attention memory + decoder + post-net; shared by train and inference forward.
 int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const float* P, const int32_t* text,
                  const int32_t* text_length, const int32_t* speaker, const float* mel, const uint8_t* ek1, const uint8_t* ek2, const uint8_t* dk1,
@@ -405,6 +428,10 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
   const ParamLayout& PL = L.P;
   const int B = sh.B, Tt = sh.Tt, Td = sh.Td, r = sh.r, R80 = kMel * r;
   const int M1 = B * Tt, M2 = B * Td * r;
+  // pre-split bf16 plane images of the forward weights (gemm2.hip's B-image form): first thing on the main stream
+  weight_images_clear();
+  TACO_TRY(register_weight_images(L, W, P, ws, train, 0, true));
+  TACO_TRY(weight_images_build(s));
   // decoder composites depend on the parameters only: side stream, concurrent with the encoder
   hipStream_t sd = side_fork(s);
   // ONE batched init launch for everything that is a plain copy / zero pad of parameters (side stream, first thing on it):
@@ -430,6 +457,10 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
     // everything the backward pass derives from the parameters alone (transposed / tap-flipped weight copies, transposed
     // composites) is built here, beside the encoder, instead of at the head of taco_backward's critical path
     TACO_TRY(prepare_transposes(P, PL, L.T, ws + W.paramsT, r, sd));
+    // ... and the plane images of the transposed weights the backward GEMMs read as their B operand (same stream, behind the copies;
+    // the final dense layer's three zero pad rows come from the init batch on this stream as well)
+    TACO_TRY(register_weight_images(L, W, P, ws, train, 1, true));
+    TACO_TRY(weight_images_build(sd));
     TACO_TRY(build_dec_composites_bwd(P, PL, W, ws, r, sd));
     // decoder pre_net (tacotron.py:38-44, 64-71) of every TEACHER-FORCED step: its input (the last frame of mel[t]) is known now,
     // so the two layers are two GEMMs over all B*Td frames, straight into the P1 / P2 slots of the decoder stash, beside the
@@ -1032,6 +1063,10 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
   float* PT = ws + W.paramsT;
 
   g_tn_side = nullptr;
+  // the weight-image table of this call (the images themselves were built by the taco_forward that ran on this workspace)
+  weight_images_clear();
+  TACO_TRY(register_weight_images(L, W, P, ws, true, 0, false));
+  TACO_TRY(register_weight_images(L, W, P, ws, true, 1, false));
   // ONE batched init launch for every accumulator of the pass: the gradient buffer, [d keys | E] (one (M1, 512) buffer), the small
   // decoder weight-gradient factors, the two CBHG input-gradient accumulators (when they have buffers of their own) and the
   // decoder exchange area (the forward kernel is long done with it)

@@ -77,6 +77,7 @@ EXPORTS = {
     'taco_workspace_table': (C.c_int, [_SH, _I, C.POINTER(TacoTensorInfo), _I]),
     'taco_conv_gemm': (C.c_int, [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'taco_debug_gemm2_window': (C.c_int, [_I, _I]),
+    'taco_debug_weight_image': (C.c_int64, [_P, _I, _I, _I, _I, _P, C.c_int64, _P]),
     'taco_debug_conv_gemm_nld': (C.c_int, [_P, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     'taco_debug_conv_gemm_ksplit': (C.c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, C.c_int64, _P]),
     'taco_gemm_tn': (C.c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -199,6 +200,21 @@ def gemm_tn(A, dY, dW, M, N, K, taps=1, T=None, pad_l=0, accumulate=False, lda=N
     T = M if T is None else T
     _check(_lib.taco_gemm_tn(ptr(A), lda or K, ptr(dY), ldy or N, ptr(dW), ldw or N, M, N, K, taps, T, pad_l,
                              int(accumulate), stream_ptr()), 'taco_gemm_tn')
+
+
+def weight_image(W=None, taps=1, K=0, N=0, ldw=None):
+    """Op-level door to the pre-split weight images (include/taco_hip.h taco_debug_weight_image).  W None: clear this thread's
+    table.  Otherwise builds and registers the bf16 plane image of W (taps, K, N) and returns the image tensor (keep it alive)."""
+    if W is None:   # -> launches that ran the image form since the previous clear
+        return int(_lib.taco_debug_weight_image(None, 0, 0, 0, 0, None, 0, None))
+    ldw = ldw or N
+    need = _lib.taco_debug_weight_image(ptr(W), ldw, taps, K, N, None, 0, None)
+    if need < 0:
+        raise TacoError('taco_debug_weight_image: %d' % need)
+    img = torch.empty(need // 2, dtype=torch.int16, device=W.device)
+    rc = _lib.taco_debug_weight_image(ptr(W), ldw, taps, K, N, ptr(img), need, stream_ptr())
+    _check(int(rc), 'taco_debug_weight_image')
+    return img
 
 
 def debug_gemm_naive(A, W, C_out, M, N, K, taps=1, T=None, pad_l=0, act=0, bias=None):

@@ -125,6 +125,45 @@ def test_conv_gemm_v2(built_lib, case, variant, monkeypatch):
     test_conv_gemm(built_lib, case)
 
 
+WIMG_CASES = [c for c in V2_CASES if c[7] in ('', 'bias')] + [
+    (1000, 200, 300, 132, 3, 1, 1, 'bias'),      # ragged: N and K tails are zeros of the image
+    (640, 40, 80, 128, 8, 4, 0, ''),             # N = 80 (post-net bank gather's width)
+    (384, 384, 1028, 256, 1, 0, 0, 'bias'),      # nine n-tiles, the last one 4 columns wide
+]
+
+
+@pytest.mark.parametrize('ns', ['3', '4'])
+@pytest.mark.parametrize('case', WIMG_CASES, ids=[str(c[:6]) for c in WIMG_CASES])
+def test_conv_gemm_weight_image(built_lib, case, ns, monkeypatch):
+    """Round 6: the bf16x3 form with the weight operand read from a pre-split plane image (csrc/kernels.h "weight images": planes
+    formed once per weight tensor by weight_image_kernel, DMA'd as 12 KB fragment-ordered tiles, no B split in the GEMM).  The
+    image holds exactly the planes the in-register split forms and the MFMAs run in the same order, so the result must be BIT
+    IDENTICAL to the in-register bf16x3 form (TACO_GEMM2_BSPLIT=0) -- and within the suite's 5e-6 of fp64.  Three- and four-stage
+    rings; K / N tails, taps, several n-tiles."""
+    M, T, N, K, taps, pad_l, act, extras = case
+    monkeypatch.setenv('TACO_GEMM2_MIN_TILES', '1')
+    monkeypatch.setenv('TACO_GEMM2_BF16X', '1')
+    monkeypatch.setenv('TACO_GEMM2_BI_NS', ns)
+    rng = np.random.default_rng(hash(case[:6]) % 2**31)
+    A = rng.standard_normal((M, K))
+    W = rng.standard_normal((taps, K, N)) / np.sqrt(K * taps)
+    bias = rng.standard_normal(N) if 'bias' in extras else None
+    dA, dW, db = dev(A), dev(W), (None if bias is None else dev(bias))
+    ref, _ = conv_ref(A, W, bias, T, pad_l, act)
+    built_lib.weight_image(None)
+    C0 = torch.full((M, N), float('nan'), device='cuda')
+    built_lib.conv_gemm(dA, dW, C0, M, N, K, taps=taps, T=T, pad_l=pad_l, act=act, bias=db)      # no image registered: in-register split
+    assert built_lib.weight_image(None) == 0
+    img = built_lib.weight_image(dW, taps=taps, K=K, N=N)
+    C1 = torch.full((M, N), float('nan'), device='cuda')
+    built_lib.conv_gemm(dA, dW, C1, M, N, K, taps=taps, T=T, pad_l=pad_l, act=act, bias=db)
+    torch.cuda.synchronize()
+    assert built_lib.weight_image(None) == 1, 'the launch did not take the image form'
+    del img
+    assert report('conv_gemm image form %s' % (case[:7],), C1.cpu().numpy(), ref)[0] < 5e-6
+    assert torch.equal(C0, C1), 'image form differs from the in-register split: max |d| = %g' % float((C0 - C1).abs().max())
+
+
 @pytest.mark.parametrize('scale', [1.0, 1e-12, 3e7], ids=['unit', 'tiny', 'huge'])
 def test_bf16x3_products_are_fp32_grade(built_lib, scale, monkeypatch):
     """The bf16x3 form of gemm2.hip against the fp32 MFMA form of the same kernel and an fp64 product: a deep reduction (K = 2048
