@@ -262,6 +262,7 @@ constexpr int kGradSegments = 4;
 struct SideStream {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_img = nullptr;   // the forward weight images are built (recorded on the side stream; the main stream waits in front of the encoder CBHG)
   bool off = false;
   // gradient-segment events of the most recent taco_backward issued by this thread on this device (taco_wait_grad_segment):
   // segment [3] post-net, [2] decoder, [1] encoder projections / highways / bi-GRU, [0] embedding + encoder pre_net + conv bank
@@ -428,12 +429,20 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
   const ParamLayout& PL = L.P;
   const int B = sh.B, Tt = sh.Tt, Td = sh.Td, r = sh.r, R80 = kMel * r;
   const int M1 = B * Tt, M2 = B * Td * r;
-  // pre-split bf16 plane images of the forward weights (gemm2.hip's B-image form): first thing on the main stream
-  weight_images_clear();
-  TACO_TRY(register_weight_images(L, W, P, ws, train, 0, true));
-  TACO_TRY(weight_images_build(s));
   // decoder composites depend on the parameters only: side stream, concurrent with the encoder
   hipStream_t sd = side_fork(s);
+  // pre-split bf16 plane images of the forward weights (gemm2.hip's B-image form): first thing on the side stream, beside the
+  // embedding gather and the encoder pre_net; the main stream waits for them in front of the encoder CBHG (its first gemm2 launch)
+  weight_images_clear();
+  TACO_TRY(register_weight_images(L, W, P, ws, train, 0, true));
+  TACO_TRY(weight_images_build(sd));
+  bool img_event = false;
+  if (sd != s) {
+    SideStream& x = side_stream();
+    if (!x.ev_img && hipEventCreateWithFlags(&x.ev_img, hipEventDisableTiming) != hipSuccess) x.ev_img = nullptr;
+    if (x.ev_img && hipEventRecord(x.ev_img, sd) == hipSuccess) img_event = true;
+    else TACO_TRY(side_join(s, sd));   // (no event: fall back to a full join here)
+  }
   // ONE batched init launch for everything that is a plain copy / zero pad of parameters (side stream, first thing on it):
   //   post/dense (256, 1025) kernel -> pitch 1028 so the W tile loads are 16-byte aligned float4 (pad columns are never stored);
   //   the copied / zero-padded parts of the decoder composites; the pad rows / columns of two transposed backward operands
@@ -504,6 +513,10 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
     TACO_REQUIRE(speaker != nullptr, "num_speakers=%d but no speaker ids were given", sh.S);
     TACO_TRY(launch_embedding(P + PL.spk_embed, speaker, ws + W.spk_e, B, sh.S, s, 16));
     eb.spk_e = ws + W.spk_e;
+  }
+  if (img_event && hipStreamWaitEvent(s, side_stream().ev_img, 0) != hipSuccess) {
+    taco_set_error("forward: cannot wait for the weight images");
+    return TACO_ELAUNCH;
   }
   TACO_TRY(cbhg_fwd(P, PL.enc, ws + W.p2, B, Tt, eb, train, s));
   // attention memory (BahdanauAttention.__init__; tacotron.py:48-52)
