@@ -18,10 +18,20 @@
 // launch; issuing them in three batches behind the next layer's prefetches changed nothing -- it is write bandwidth, not the
 // in-order counter); reading all A fragments of a layer in one burst changed nothing either.
 // Accumulators are split in two independent chains so that back-to-back MFMAs never wait for each other's result.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
 namespace {
+
+template <int I, int N, class F>
+__device__ __forceinline__ void hw_static_for(F&& f) {   // compile-time chunk index: register sets, layers and stages fold per chunk
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    hw_static_for<I + 1, N>(f);
+  }
+}
 
 constexpr int HB = 32;         // rows per workgroup
 constexpr int HC = 128;        // highway width
@@ -29,9 +39,15 @@ constexpr int HPAD = HB + 1;   // activation row pitch, feature-major (conflict-
 constexpr int FCK = 16;        // forward: k-pairs per chunk (32 k-values): 4 chunks per layer
 constexpr int BCK = 32;        // backward: k-pairs per chunk (64 of the 256 k-values): 4 chunks per layer
 
-// forward: grid = ceil(M / 32), block = 256
+// forward: grid = ceil(M / 32), block = 256.
+// AD (round 6; multi-speaker encoder, ops.py:97-107): every layer has an input adapter in front of its gates,
+//   x_l = h_l . Wa_l[:128] + rowb_l[sequence]      (rowb = relu(dense(speaker)) . Wa_l[128:] + ba_l, a per-sequence bias: model.hip),
+// run as one more 128 x 128 GEMM stage per layer inside this launch (its output tile goes to a second LDS buffer and, as the
+// backward pass's stash, to hx[l]); rounds 1-5 ran the speaker model's layers as separate adapter / gate / blend launches.
+template <bool AD>
 __global__ __launch_bounds__(256, 2) void highway_stack_fwd_kernel(HighwayStackArgs a) {
   __shared__ __attribute__((aligned(16))) float hT[HC][HPAD];          // current layer input, feature-major
+  __shared__ __attribute__((aligned(16))) float xT[AD ? HC : 1][HPAD];  // AD: the adapter's output = the gates' input
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lk = lane >> 5, li = lane & 31;
   const int m0 = blockIdx.x * HB;
@@ -52,40 +68,62 @@ __global__ __launch_bounds__(256, 2) void highway_stack_fwd_kernel(HighwayStackA
       hT[k + 3][row] = v.w;
     }
   }
-  // B fragments of chunk (l, c): this lane's [Wt | Wh] values for k = 2 (16 c + j) + lk, column n
+  // B fragments of a chunk: this lane's [Wt | Wh] (or, adapter chunks, Wa) values for k = 2 (16 c + j) + lk, column n
+  constexpr int CPL = AD ? 8 : 4;   // chunks per layer: (AD: 4 adapter chunks, then) 4 gate / candidate chunks
   float wt_r[2][FCK], wh_r[2][FCK];
-  auto load_chunk = [&](float (&t)[FCK], float (&h)[FCK], int l, int c) {
-    const float* wt = a.wt[l] + (2 * c * FCK + lk) * HC + n;
-    const float* wh = a.wh[l] + (2 * c * FCK + lk) * HC + n;
+  auto load_chunk = [&](float (&t)[FCK], float (&h)[FCK], int l, int cc) {
+    const int c = cc & 3;
+    if (AD && cc < 4) {
+      const float* wa = a.wa[l] + (2 * c * FCK + lk) * HC + n;
 #pragma unroll
-    for (int j = 0; j < FCK; ++j) {
-      t[j] = wt[2 * j * HC];
-      h[j] = wh[2 * j * HC];
+      for (int j = 0; j < FCK; ++j) t[j] = wa[2 * j * HC];
+    } else {
+      const float* wt = a.wt[l] + (2 * c * FCK + lk) * HC + n;
+      const float* wh = a.wh[l] + (2 * c * FCK + lk) * HC + n;
+#pragma unroll
+      for (int j = 0; j < FCK; ++j) {
+        t[j] = wt[2 * j * HC];
+        h[j] = wh[2 * j * HC];
+      }
     }
   };
   load_chunk(wt_r[0], wh_r[0], 0, 0);
 
   f32x16 accT[2], accH[2];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {   // chunk i = (layer i >> 2, k-chunk i & 3); fully unrolled: register sets by parity
-    const int l = i >> 2, c = i & 3;
+  for (int i = 0; i < 4 * CPL; ++i) {   // chunk i = (layer i / CPL, chunk i % CPL); fully unrolled: register sets by parity
+    const int l = i / CPL, cc = i % CPL, c = cc & 3;
+    const bool ad = AD && cc < 4;
     if (l >= a.nl) break;
-    if (i + 1 < 16 && ((i + 1) >> 2) < a.nl) load_chunk(wt_r[(i + 1) & 1], wh_r[(i + 1) & 1], (i + 1) >> 2, (i + 1) & 3);
+    if (i + 1 < 4 * CPL && (i + 1) / CPL < a.nl) load_chunk(wt_r[(i + 1) & 1], wh_r[(i + 1) & 1], (i + 1) / CPL, (i + 1) % CPL);
     __builtin_amdgcn_sched_barrier(0);   // the prefetch stays HERE: the scheduler would sink each load to just in front of its MFMA
     if (c == 0) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) accT[0][e] = accT[1][e] = accH[0][e] = accH[1][e] = 0.f;
-      lds_barrier();   // hT holds this layer's input (first layer: the input tile; later: the previous layer's output)
+      lds_barrier();   // the stage's input tile is complete (first layer: the input tile; later: the previous stage's output)
     }
     float av[FCK];
 #pragma unroll
-    for (int j = 0; j < FCK; ++j) av[j] = hT[2 * (c * FCK + j) + lk][li];
+    for (int j = 0; j < FCK; ++j) av[j] = (AD && !ad) ? xT[2 * (c * FCK + j) + lk][li] : hT[2 * (c * FCK + j) + lk][li];
 #pragma unroll
     for (int j = 0; j < FCK; ++j) {
       accT[j & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], wt_r[i & 1][j], accT[j & 1], 0, 0, 0);
-      accH[j & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], wh_r[i & 1][j], accH[j & 1], 0, 0, 0);
+      if (!ad) accH[j & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], wh_r[i & 1][j], accH[j & 1], 0, 0, 0);
     }
-    if (c == 3) {
+    if (c == 3 && ad) {
+      // adapter epilogue: x = h . Wa[:128] + rowb[sequence of the row]; stash (hx) + the gates' input tile.  No barrier in front of the
+      // xT writes: its last readers (the previous layer's gate stage) all passed that stage's epilogue barrier.
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int r = (e & 3) + 8 * (e >> 2) + 4 * lk;
+        const int m = m0 + r;
+        const int mm = m < a.M ? m : a.M - 1;
+        const float x = accT[0][e] + accT[1][e] + a.rowb[l][(int64_t)(mm / a.T) * HC + n];
+        if (m < a.M) a.hx[l][(int64_t)m * HC + n] = x;
+        xT[n][r] = x;
+      }
+    }
+    if (c == 3 && !ad) {
       // epilogue: C layout col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
       const float bT = a.bt[l][n], bH = a.bh[l][n];
       float y[16];
@@ -95,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void highway_stack_fwd_kernel(HighwayStackA
         const int m = m0 + r;
         const float T = sigmoid_fast(accT[0][e] + accT[1][e] + bT);   // v_exp + v_rcp, as in the decoder kernels
         const float H = fmaxf(accH[0][e] + accH[1][e] + bH, 0.f);
-        const float h = hT[n][r];
+        const float h = AD ? xT[n][r] : hT[n][r];
         y[e] = H * T + h * (1.f - T);
         if (m < a.M) {
           if (a.th[l]) {   // gate / candidate stash for the backward pass (null at inference)
@@ -117,7 +155,11 @@ __global__ __launch_bounds__(256, 2) void highway_stack_fwd_kernel(HighwayStackA
 //   dT = g (H - x) T (1 - T);  dH = g T [H > 0];  g' = [dT | dH] . [Wt ; Wh]^T + g (1 - T)
 // wT[l] is the (256, 128) transposed pair [Wt^T ; Wh^T] built by prepare_transposes.  grid = ceil(M / 32), block = 256,
 // dynamic LDS (kHwBwdSmem bytes).
+// AD (round 6, multi-speaker encoder): g' is the gradient of the layer's ADAPTER output x_l; it is stashed in dhx[l] (operand of the
+// adapter's weight gradient and of the per-sequence bias sums) and taken through the adapter, g'' = g' . Wa_l[:128]^T (waT[l], one more
+// 128 x 128 GEMM stage of two chunks), before it becomes the g of the layer below.
 constexpr size_t kHwBwdSmem = sizeof(float) * ((size_t)2 * HC * HPAD + (size_t)HC * HPAD);
+template <bool AD>
 __global__ __launch_bounds__(256, 2) void highway_stack_bwd_kernel(HighwayStackBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float hw_smem[];
   float (*dT)[HPAD] = reinterpret_cast<float (*)[HPAD]>(hw_smem);                                  // [256][33] d[T|H], k-major
@@ -139,10 +181,11 @@ __global__ __launch_bounds__(256, 2) void highway_stack_bwd_kernel(HighwayStackB
     gT[pc4 * 4 + 2][r] = v.z;
     gT[pc4 * 4 + 3][r] = v.w;
   }
-  // B fragments of chunk (l, c): wT[l][k = 2 (32 c + j) + lk][n]
+  // B fragments of a chunk: wT[l][k = 2 (32 c + j) + lk][n] (gate / candidate chunks cc < 4), waT[l][...] (adapter chunks cc = 4, 5)
+  constexpr int CPL = AD ? 6 : 4;
   float w_r[2][BCK];
-  auto load_chunk = [&](float (&w)[BCK], int l, int c) {
-    const float* src = a.wT[l] + (2 * c * BCK + lk) * HC + n;
+  auto load_chunk = [&](float (&w)[BCK], int l, int cc) {
+    const float* src = (AD && cc >= 4) ? a.waT[l] + (2 * (cc - 4) * BCK + lk) * HC + n : a.wT[l] + (2 * cc * BCK + lk) * HC + n;
 #pragma unroll
     for (int j = 0; j < BCK; ++j) w[j] = src[2 * j * HC];
   };
@@ -151,11 +194,17 @@ __global__ __launch_bounds__(256, 2) void highway_stack_bwd_kernel(HighwayStackB
   lds_barrier();
 
   f32x16 acc[2];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {   // chunk i = (layer 3 - (i >> 2), k-chunk i & 3); layers above nl - 1 do not exist
-    const int l = 3 - (i >> 2), c = i & 3;
-    if (l >= nl) continue;
-    if (c == 0) {
+  // chunk i = (layer 3 - i / CPL, chunk i % CPL); layers above nl - 1 do not exist (CPL is even: a skipped layer does not change
+  // the parity of the register sets, so the first executed chunk reads set 0, which the load above filled).
+  static_assert(CPL % 2 == 0, "register-set parity relies on an even number of chunks per layer");
+  hw_static_for<0, 4 * CPL>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int l = 3 - i / CPL, cc = i % CPL;
+    if (l >= nl) return;
+    constexpr int par = i & 1;
+    constexpr bool hw = cc < 4;
+    constexpr int c = hw ? cc : cc - 4;
+    if (hw && c == 0) {
       // ---- pre-processing: d[T|H] of this layer from g, the stashed gates and the layer input ----
       // (all twelve loads first: issued between the stores of the previous rows they would have to queue behind them -- the
       //  compiler cannot prove that dth does not alias th / x, and vector-memory operations complete in order)
@@ -193,21 +242,28 @@ __global__ __launch_bounds__(256, 2) void highway_stack_bwd_kernel(HighwayStackB
       for (int e = 0; e < 16; ++e) acc[0][e] = acc[1][e] = 0.f;
       lds_barrier();
     }
+    if (!hw && c == 0) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[0][e] = acc[1][e] = 0.f;   // (gT holds g' since the barrier behind the gate stage's epilogue)
+    }
     // the next chunk's weights fly under this chunk's MFMAs (the last chunk of a layer fetches the first of the layer below)
-    if (i + 1 < 16) load_chunk(w_r[(i + 1) & 1], 3 - ((i + 1) >> 2), (i + 1) & 3);
+    if constexpr (i + 1 < 4 * CPL) load_chunk(w_r[par ^ 1], 3 - (i + 1) / CPL, (i + 1) % CPL);
     __builtin_amdgcn_sched_barrier(0);   // the prefetch stays HERE (see the forward kernel)
-    // ---- g' = d[T|H] . wT  (K = 256) ----
+    // ---- gate stage: g' = d[T|H] . wT (K = 256); adapter stage: g'' = g' . waT (K = 128) ----
 #pragma unroll
     for (int hhalf = 0; hhalf < 2; ++hhalf) {
       float av[BCK / 2];
 #pragma unroll
-      for (int j = 0; j < BCK / 2; ++j) av[j] = dT[2 * (c * BCK + hhalf * (BCK / 2) + j) + lk][li];
+      for (int j = 0; j < BCK / 2; ++j) {
+        const int k = 2 * (c * BCK + hhalf * (BCK / 2) + j) + lk;
+        av[j] = hw ? dT[k][li] : gT[k][li];
+      }
 #pragma unroll
       for (int j = 0; j < BCK / 2; ++j)
-        acc[j & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], w_r[i & 1][hhalf * (BCK / 2) + j], acc[j & 1], 0, 0, 0);
+        acc[j & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], w_r[par][hhalf * (BCK / 2) + j], acc[j & 1], 0, 0, 0);
     }
-    if (c == 3) {
-      // ---- epilogue: + g (1 - T); the result is the next (lower) layer's g ----
+    if (hw && c == 3) {
+      // ---- epilogue: + g (1 - T); the result is the gradient of the layer's input (AD: of its adapter's output) ----
       float gn[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -221,34 +277,60 @@ __global__ __launch_bounds__(256, 2) void highway_stack_bwd_kernel(HighwayStackB
       for (int e = 0; e < 16; ++e) {
         const int r = (e & 3) + 8 * (e >> 2) + 4 * lk;
         gT[n][r] = gn[e];
-        if (l == 0 && m0 + r < a.M) a.gout[(int64_t)(m0 + r) * HC + n] = gn[e];
+        if (AD) {
+          if (m0 + r < a.M) a.dhx[l][(int64_t)(m0 + r) * HC + n] = gn[e];
+        } else if (l == 0 && m0 + r < a.M) {
+          a.gout[(int64_t)(m0 + r) * HC + n] = gn[e];
+        }
       }
       lds_barrier();
     }
-  }
+    if (!hw && c == 1) {
+      // ---- adapter epilogue: g'' is the g of the layer below (layer 0: the CBHG's residual gradient) ----
+      lds_barrier();   // every wave has read g' from gT
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int r = (e & 3) + 8 * (e >> 2) + 4 * lk;
+        const float v = acc[0][e] + acc[1][e];
+        gT[n][r] = v;
+        if (l == 0 && m0 + r < a.M) a.gout[(int64_t)(m0 + r) * HC + n] = v;
+      }
+      lds_barrier();
+    }
+  });
 }
 
 }  // namespace
 
 int launch_highway_stack_bwd(const HighwayStackBwdArgs& a, hipStream_t s) {
   TACO_REQUIRE(a.M > 0 && a.nl >= 1 && a.nl <= 4 && a.g && a.gout, "highway_stack_bwd: bad arguments");
-  static DynSmemOnce once;
-  TACO_REQUIRE(ensure_dyn_smem(once, reinterpret_cast<const void*>(highway_stack_bwd_kernel), kHwBwdSmem),
+  const bool ad = a.waT[0] != nullptr;
+  TACO_REQUIRE(!ad || (a.nl == 4 && a.waT[1] && a.waT[2] && a.waT[3] && a.dhx[0] && a.dhx[1] && a.dhx[2] && a.dhx[3]),
+               "highway_stack_bwd: the adapter form needs waT / dhx of all four layers");
+  static DynSmemOnce once, once_ad;
+  TACO_REQUIRE(ensure_dyn_smem(ad ? once_ad : once, ad ? reinterpret_cast<const void*>(highway_stack_bwd_kernel<true>)
+                                                       : reinterpret_cast<const void*>(highway_stack_bwd_kernel<false>), kHwBwdSmem),
                "highway_stack_bwd: cannot reserve %zu bytes of LDS", kHwBwdSmem);
   const int pslot = taco_prof_begin(2, s);
-  taco_prof_label(2, pslot, "highway-bwd M=%d nl=%d", a.M, a.nl);
-  hipLaunchKernelGGL(highway_stack_bwd_kernel, dim3(cdiv(a.M, HB)), dim3(256), kHwBwdSmem, s, a);
-  taco_prof_end(2, pslot, s, 2.0 * a.M * HC * 2 * HC * a.nl);
+  taco_prof_label(2, pslot, "highway-bwd M=%d nl=%d%s", a.M, a.nl, ad ? " +adapters" : "");
+  if (ad) hipLaunchKernelGGL(highway_stack_bwd_kernel<true>, dim3(cdiv(a.M, HB)), dim3(256), kHwBwdSmem, s, a);
+  else hipLaunchKernelGGL(highway_stack_bwd_kernel<false>, dim3(cdiv(a.M, HB)), dim3(256), kHwBwdSmem, s, a);
+  taco_prof_end(2, pslot, s, 2.0 * a.M * HC * (ad ? 3 : 2) * HC * a.nl);
   TACO_LAUNCH_CHECK("highway_stack_bwd");
   return TACO_OK;
 }
 
 int launch_highway_stack_fwd(const HighwayStackArgs& a, hipStream_t s) {
   TACO_REQUIRE(a.M > 0 && a.nl >= 1 && a.nl <= 4 && a.x, "highway_stack_fwd: bad arguments");
+  const bool ad = a.wa[0] != nullptr;
+  TACO_REQUIRE(!ad || (a.nl == 4 && a.T > 0 && a.wa[1] && a.wa[2] && a.wa[3] && a.rowb[0] && a.rowb[1] && a.rowb[2] && a.rowb[3] &&
+                       a.hx[0] && a.hx[1] && a.hx[2] && a.hx[3]),
+               "highway_stack_fwd: the adapter form needs wa / rowb / hx of all four layers and the sequence length");
   const int pslot = taco_prof_begin(2, s);
-  taco_prof_label(2, pslot, "highway-fwd M=%d nl=%d", a.M, a.nl);
-  hipLaunchKernelGGL(highway_stack_fwd_kernel, dim3(cdiv(a.M, HB)), dim3(256), 0, s, a);
-  taco_prof_end(2, pslot, s, 2.0 * a.M * HC * 2 * HC * a.nl);
+  taco_prof_label(2, pslot, "highway-fwd M=%d nl=%d%s", a.M, a.nl, ad ? " +adapters" : "");
+  if (ad) hipLaunchKernelGGL(highway_stack_fwd_kernel<true>, dim3(cdiv(a.M, HB)), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(highway_stack_fwd_kernel<false>, dim3(cdiv(a.M, HB)), dim3(256), 0, s, a);
+  taco_prof_end(2, pslot, s, 2.0 * a.M * HC * (ad ? 3 : 2) * HC * a.nl);
   TACO_LAUNCH_CHECK("highway_stack_fwd");
   return TACO_OK;
 }

@@ -105,6 +105,11 @@ struct HighwayStackArgs {
   float* th[4];               // (M,256) [T | H] stash per layer, or null (inference: no backward pass will read it)
   float* y[4];
   int M = 0, nl = 0;
+  // adapter form (multi-speaker encoder; all four layers or none): x_l = h_l . wa[l] + rowb[l][m / T], stashed in hx[l], feeds the gates
+  const float* wa[4] = {nullptr, nullptr, nullptr, nullptr};     // (128,128): rows [0,128) of the layer's adapter kernel
+  const float* rowb[4] = {nullptr, nullptr, nullptr, nullptr};   // (B,128) per-sequence bias
+  float* hx[4] = {nullptr, nullptr, nullptr, nullptr};           // (M,128)
+  int T = 0;                                                     // rows per sequence
 };
 int launch_highway_stack_fwd(const HighwayStackArgs& a, hipStream_t s);
 // prenet.hip: the encoder pre_net (two dense + ReLU + dropout layers) and its activation-gradient chain as one launch each.
@@ -132,6 +137,9 @@ struct HighwayStackBwdArgs {
   float* dth[4];               // (M,256) d[T|H] pre-activation gradients (operands of the weight-gradient GEMMs)
   float* gout = nullptr;       // (M,128) dL/d input of layer 0
   int M = 0, nl = 0;
+  // adapter form: x[l] is the adapter OUTPUT hx[l]; dhx[l] receives dL/d hx[l]; the chain continues through waT[l] = wa[l]^T
+  const float* waT[4] = {nullptr, nullptr, nullptr, nullptr};    // (128,128)
+  float* dhx[4] = {nullptr, nullptr, nullptr, nullptr};          // (M,128)
 };
 int launch_highway_stack_bwd(const HighwayStackBwdArgs& a, hipStream_t s);
 int launch_conv_gemm(const ConvGemmProblem& p, hipStream_t stream);

@@ -73,8 +73,10 @@ struct TransLayout {
 
 struct CbhgWs {
   int64_t bank, pool, pj1pre, pj1, pj2pre, res, hx[4], h[5], th[4], xg, out, ruc;
-  int64_t sv[4], rowb[4], h0;  // speaker sites: relu(dense(spk)) (B,128), per-sequence adapter bias (B,128), GRU init (B,128)
+  int64_t sv[4], rowb[4], h0;  // speaker sites: relu(dense(spk)) (B,128), per-sequence adapter bias (B,128), GRU init (B,128);
+                               // sv[0..3] and h0 are ONE contiguous (5,B,128) block (one ReLU-backward launch over all of it)
   int64_t dh0, dsmall, dsmall2; // backward: (2,B,128), (B,128), (B,128)
+  int64_t dsm[4], dsm2[5], dspk_part;   // backward, round 6: per-layer d rowb (B,128); d[sv | h0] (5,B,128) contiguous; (5,B,16) partial d spk_e
 };
 struct WsLayout {
   // forward

@@ -183,14 +183,26 @@ static void ws_cbhg(Adder& a, const std::string& p, const CbhgP& c, int64_t M, i
   w.xg = a.add(p + "xg", {M, 6 * kCb});
   w.out = a.add(p + "out", {M, 2 * kCb});
   w.ruc = a.add(p + "ruc", {M, 6 * kCb});
-  for (int l = 0; l < 4; ++l) {
-    w.sv[l] = c.spk ? a.add(p + "sv" + std::to_string(l), {B, kCb}) : -1;
-    w.rowb[l] = c.spk ? a.add(p + "rowb" + std::to_string(l), {B, kCb}) : -1;
+  {
+    // speaker sites (ops.py:101-115): sv[0..3] | h0 as ONE (5,B,128) block, likewise their gradients (dsm2) -- the ReLU backward of all
+    // five is one launch; rowb / dsm per layer
+    const int64_t blk = B * kCb;
+    const int64_t svh = c.spk ? a.add(p + "sv_h0", {5, B, kCb}) : -1;
+    const int64_t rb = c.spk ? a.add(p + "rowb", {4, B, kCb}) : -1;
+    for (int l = 0; l < 4; ++l) {
+      w.sv[l] = c.spk ? svh + l * blk : -1;
+      w.rowb[l] = c.spk ? rb + l * blk : -1;
+    }
+    w.h0 = c.spk ? svh + 4 * blk : -1;
+    w.dh0 = c.spk ? a.add(p + "dh0", {2, B, kCb}) : -1;
+    w.dsmall = c.spk ? a.add(p + "dsmall", {B, kCb}) : -1;
+    w.dsmall2 = c.spk ? a.add(p + "dsmall2", {B, kCb}) : -1;
+    const int64_t d1 = c.spk ? a.add(p + "dsm", {4, B, kCb}) : -1;
+    const int64_t d2 = c.spk ? a.add(p + "dsm2", {5, B, kCb}) : -1;
+    for (int l = 0; l < 4; ++l) w.dsm[l] = c.spk ? d1 + l * blk : -1;
+    for (int l = 0; l < 5; ++l) w.dsm2[l] = c.spk ? d2 + l * blk : -1;
+    w.dspk_part = c.spk ? a.add(p + "dspk_part", {5, B, 16}) : -1;
   }
-  w.h0 = c.spk ? a.add(p + "h0", {B, kCb}) : -1;
-  w.dh0 = c.spk ? a.add(p + "dh0", {2, B, kCb}) : -1;
-  w.dsmall = c.spk ? a.add(p + "dsmall", {B, kCb}) : -1;
-  w.dsmall2 = c.spk ? a.add(p + "dsmall2", {B, kCb}) : -1;
 }
 
 void build_ws_layout(const TacoShape& s, bool train, const TransLayout& T, WsLayout& W) {

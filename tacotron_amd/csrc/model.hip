@@ -90,6 +90,7 @@ struct CbhgBufs {
   float *bank, *pool, *pj1pre, *pj1, *pj2pre, *res, *h[5], *hx[4], *th[4], *xg, *out, *ruc, *tapsplit = nullptr;
   int64_t tapsplit_floats = 0;
   float *sv[4], *rowb[4], *h0, *dh0, *dsmall, *dsmall2;   // speaker sites (null without speakers)
+  float *dsm[4], *dsm2[5], *dspk_part;                    // their batched backward (round 6)
   const float* spk_e;   // (B,16) gathered speaker embeddings
   float* dspk_e;        // (B,16) their gradient (accumulated)
 };
@@ -107,6 +108,9 @@ CbhgBufs cbhg_bufs(float* ws, const CbhgWs& w) {
   b.dh0 = w.dh0 >= 0 ? ws + w.dh0 : nullptr;
   b.dsmall = w.dsmall >= 0 ? ws + w.dsmall : nullptr;
   b.dsmall2 = w.dsmall2 >= 0 ? ws + w.dsmall2 : nullptr;
+  for (int l = 0; l < 4; ++l) b.dsm[l] = w.dsm[l] >= 0 ? ws + w.dsm[l] : nullptr;
+  for (int l = 0; l < 5; ++l) b.dsm2[l] = w.dsm2[l] >= 0 ? ws + w.dsm2[l] : nullptr;
+  b.dspk_part = w.dspk_part >= 0 ? ws + w.dspk_part : nullptr;
   b.spk_e = nullptr;
   b.dspk_e = nullptr;
   for (int l = 0; l < 4; ++l) b.th[l] = ws + w.th[l];
@@ -200,7 +204,34 @@ int cbhg_fwd(const float* P, const CbhgP& c, const float* x, int B, int T, const
     }
     TACO_TRY(launch_highway_stack_fwd(ha, s));
   }
-  for (int l = 0; l < 4 && c.spk; ++l) {
+  // TACO_SPK_UNFUSED=1: the per-layer launches of rounds 1-5 (A/B runs, parity of the fused form against them)
+  const bool spk_fused = c.spk && c.has_adapt[0] && c.has_adapt[1] && c.has_adapt[2] && c.has_adapt[3] && !getenv("TACO_SPK_UNFUSED");
+  if (spk_fused) {
+    // multi-speaker encoder (round 6): the speaker sites of all four layers depend on the speaker embedding alone -- two grouped
+    // launches up front (sv_l = relu(dense(spk)), h0 likewise; rowb_l = sv_l . Wa_l[128:] + ba_l) -- and the four layers, adapters
+    // included, are ONE launch (highway.hip, adapter form).  Rounds 1-5: ~5 launch-latency-sized launches per layer.
+    ConvGemmBatch b1;
+    b1.n = 5;
+    for (int l = 0; l < 4; ++l)
+      b1.p[l] = dense_problem(w.spk_e, 16, P + c.spkd[l].w, kCb, P + c.spkd[l].b, w.sv[l], kCb, B, kCb, 16, TACO_ACT_RELU);
+    b1.p[4] = dense_problem(w.spk_e, 16, P + c.gru_init.w, kCb, P + c.gru_init.b, w.h0, kCb, B, kCb, 16, TACO_ACT_RELU);
+    TACO_TRY(launch_conv_gemm_batch(b1, s));
+    ConvGemmBatch b2;
+    b2.n = 4;
+    for (int l = 0; l < 4; ++l)
+      b2.p[l] = dense_problem(w.sv[l], kCb, P + c.adapt[l].w + (int64_t)kCb * kCb, kCb, P + c.adapt[l].b, w.rowb[l], kCb, B, kCb, kCb,
+                              TACO_ACT_NONE);
+    TACO_TRY(launch_conv_gemm_batch(b2, s));
+    HighwayStackArgs ha;
+    ha.x = w.h[0]; ha.M = M; ha.nl = 4; ha.T = T;
+    for (int l = 0; l < 4; ++l) {
+      ha.wa[l] = P + c.adapt[l].w; ha.rowb[l] = w.rowb[l]; ha.hx[l] = w.hx[l];
+      ha.wt[l] = P + c.hwT[l].w; ha.bt[l] = P + c.hwT[l].b; ha.wh[l] = P + c.hwH[l].w; ha.bh[l] = P + c.hwH[l].b;
+      ha.th[l] = keep_ruc ? w.th[l] : nullptr; ha.y[l] = w.h[l + 1];
+    }
+    TACO_TRY(launch_highway_stack_fwd(ha, s));
+  }
+  for (int l = 0; l < 4 && c.spk && !spk_fused; ++l) {
     if (c.has_adapt[l]) {
       if (c.spk) {
         TACO_TRY(launch_conv_gemm(dense_problem(w.spk_e, 16, P + c.spkd[l].w, kCb, P + c.spkd[l].b, w.sv[l], kCb, B, kCb, 16,
@@ -223,7 +254,7 @@ int cbhg_fwd(const float* P, const CbhgP& c, const float* x, int B, int T, const
     TACO_TRY(launch_conv_gemm_batch(batch, s));
     TACO_TRY(launch_highway_combine(w.th[l], w.hx[l], w.h[l + 1], M, s));
   }
-  if (c.spk)   // bi-GRU initial state of both directions (ops.py:111-124)
+  if (c.spk && !spk_fused)   // bi-GRU initial state of both directions (ops.py:111-124)
     TACO_TRY(launch_conv_gemm(dense_problem(w.spk_e, 16, P + c.gru_init.w, kCb, P + c.gru_init.b, w.h0, kCb, B, kCb, 16,
                                             TACO_ACT_RELU), s));
   // bi-GRU: hoisted x-side projections (4 problems) + persistent recurrence (ops.py:117-128)
@@ -783,7 +814,12 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
     p.ldr = 16;
     return launch_conv_gemm(p, s);
   };
-  if (c.spk) {
+  const bool spk_fused = c.spk && c.has_adapt[0] && c.has_adapt[1] && c.has_adapt[2] && c.has_adapt[3] && !getenv("TACO_SPK_UNFUSED");
+  if (spk_fused) {
+    // d h0 = relu'(h0) (dh0[fw] + dh0[bw]) goes into slot 4 of the (5,B,128) gradient block; the ReLU backward of all five slots
+    // and everything behind it is batched after the highway chain below
+    TACO_TRY(launch_add(w.dh0, w.dh0 + (int64_t)B * kCb, w.dsm2[4], (int64_t)B * kCb, s));
+  } else if (c.spk) {
     hipError_t e = hipMemsetAsync(w.dspk_e, 0, (size_t)B * 16 * sizeof(float), s);
     if (e != hipSuccess) {
       taco_set_error("cbhg_bwd: memset: %s", hipGetErrorString(e));
@@ -824,6 +860,59 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
       float* tmp = gh; gh = gh2; gh2 = tmp;
     }
     TACO_TRY(hw_group.flush());
+  } else if (spk_fused) {
+    // multi-speaker encoder, round 6: the four layers' activation-gradient chain THROUGH their adapters is one launch; it leaves
+    // d[T|H] (dth) and the gradients of the adapter outputs (dhx) behind, from which every weight gradient and the speaker sites'
+    // small chains are formed in grouped launches -- 12 launches where rounds 1-5 issued ~50.
+    HighwayStackBwdArgs hb;
+    hb.g = gh; hb.gout = gh2; hb.M = M; hb.nl = 4;
+    for (int l = 0; l < 4; ++l) {
+      hb.wT[l] = PT + t.hw[l]; hb.th[l] = w.th[l]; hb.x[l] = w.hx[l];
+      hb.dth[l] = sc.gA + (int64_t)l * M * 2 * kCb;
+      hb.waT[l] = PT + t.adapt[l];
+      hb.dhx[l] = sc.gA + (int64_t)4 * M * 2 * kCb + (int64_t)l * M * kCb;   // (gA is (M, K*128) = (M, 2048): 1024 + 512 columns used)
+    }
+    TACO_TRY(launch_highway_stack_bwd(hb, s));
+    {
+      TnGroup hw_group(s);
+      for (int l = 0; l < 4; ++l) {
+        TACO_TRY(tn(w.hx[l], kCb, kCb, hb.dth[l], 2 * kCb, kCb, G + c.hwT[l].w, kCb, M, M, 0, s, 1, G + c.hwT[l].b));
+        TACO_TRY(tn(w.hx[l], kCb, kCb, hb.dth[l] + kCb, 2 * kCb, kCb, G + c.hwH[l].w, kCb, M, M, 0, s, 1, G + c.hwH[l].b));
+        // adapter kernel rows [0,128) (the h part) + its bias: d ba = sum over all rows of d hx[l]
+        TACO_TRY(tn(w.h[l], kCb, kCb, hb.dhx[l], kCb, kCb, G + c.adapt[l].w, kCb, M, M, 0, s, 1, G + c.adapt[l].b));
+      }
+      TACO_TRY(hw_group.flush());
+    }
+    // per-sequence bias path: d rowb_l[b] = sum_t d hx[l][b,t]; rowb = sv . Wa[128:] + ba; sv = relu(dense(spk))
+    for (int l = 0; l < 4; ++l) TACO_TRY(launch_colsum_batched(hb.dhx[l], kCb, w.dsm[l], B, T, kCb, s));
+    {
+      TnGroup g2(s);
+      for (int l = 0; l < 4; ++l)
+        TACO_TRY(tn(w.sv[l], kCb, kCb, w.dsm[l], kCb, kCb, G + c.adapt[l].w + (int64_t)kCb * kCb, kCb, B, B, 0, s));
+      TACO_TRY(g2.flush());
+    }
+    ConvGemmBatch b3;
+    b3.n = 4;
+    for (int l = 0; l < 4; ++l)
+      b3.p[l] = dense_problem(w.dsm[l], kCb, PT + t.adapt_s[l], kCb, nullptr, w.dsm2[l], kCb, B, kCb, kCb, TACO_ACT_NONE);
+    TACO_TRY(launch_conv_gemm_batch(b3, s));
+    // ReLU backward of sv[0..3] and h0 in one pass over the contiguous (5,B,128) blocks
+    TACO_TRY(launch_act_bwd(w.sv[0], w.dsm2[0], nullptr, w.dsm2[0], (int64_t)5 * B * kCb, TACO_ACT_RELU, s));
+    const DenseP* dps[5] = {&c.spkd[0], &c.spkd[1], &c.spkd[2], &c.spkd[3], &c.gru_init};
+    const int64_t wTs[5] = {t.spkd[0], t.spkd[1], t.spkd[2], t.spkd[3], t.gru_init};
+    {
+      TnGroup g3(s);
+      for (int q = 0; q < 5; ++q) TACO_TRY(tn(w.spk_e, 16, 16, w.dsm2[q], kCb, kCb, G + dps[q]->w, kCb, B, B, 0, s, 1, G + dps[q]->b));
+      TACO_TRY(g3.flush());
+    }
+    ConvGemmBatch b4;
+    b4.n = 5;
+    for (int q = 0; q < 5; ++q)
+      b4.p[q] = dense_problem(w.dsm2[q], kCb, PT + wTs[q], 16, nullptr, w.dspk_part + (int64_t)q * B * 16, 16, B, 16, kCb, TACO_ACT_NONE);
+    TACO_TRY(launch_conv_gemm_batch(b4, s));
+    TACO_TRY(launch_colsum_batched(w.dspk_part, B * 16, w.dspk_e, 1, 5, B * 16, s));   // d spk_e = sum of the five sites' parts
+    // (gh2 = the gradient of the residual sum `res` = h[0]: nothing in front of the adapters of layer 0)
+    float* tmp = gh; gh = gh2; gh2 = tmp;
   } else {
   TnGroup hw_group(s);
   for (int l = 3; l >= 0; --l) {

@@ -43,8 +43,8 @@ def hip_decisions(R, p, masks, B, Tt, Td, r, speakers):
             d[prefix + 'highway_%d/H' % l] = (R.wsget(pre + '.th%d' % l)[:, 128:] > 0).reshape(B, T, -1)
     if speakers > 1:
         for l in range(4):
-            d['encoder/cbhg/highway_%d/spk' % l] = R.wsget('enc.sv%d' % l) > 0
-        d['encoder/cbhg/gru_init'] = R.wsget('enc.h0') > 0
+            d['encoder/cbhg/highway_%d/spk' % l] = R.wsget('enc.sv_h0')[l] > 0   # (sv[0..3] | h0: one (5,B,128) block since round 6)
+        d['encoder/cbhg/gru_init'] = R.wsget('enc.sv_h0')[4] > 0
     d['encoder/pre_net/l1'] = (R.wsget('enc.p1') > 0).reshape(B, Tt, -1)
     d['encoder/pre_net/l2'] = (R.wsget('enc.p2') > 0).reshape(B, Tt, -1)
     ok['encoder/pre_net/l1'] = np.asarray(masks['enc_keep1']) > 0

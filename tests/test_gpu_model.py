@@ -267,9 +267,13 @@ def test_backward_matches_autograd_golden(built_lib, r):
     assert not bad, bad
 
 
-def test_multi_speaker_forward_backward_infer(built_lib):
+@pytest.mark.parametrize('form', ['fused', 'per-layer'])
+def test_multi_speaker_forward_backward_infer(built_lib, form, monkeypatch):
     """SURVEY §8 a4/a9 / BASELINE config 5: speaker table + encoder CBHG speaker sites, against the committed fixture
-    and torch autograd."""
+    and torch autograd.  `fused` (default since round 6): the four highway layers with their adapters as one launch per direction
+    and the speaker sites' small chains in grouped launches; `per-layer` (TACO_SPK_UNFUSED=1): the launches of rounds 1-5."""
+    if form == 'per-layer':
+        monkeypatch.setenv('TACO_SPK_UNFUSED', '1')
     g, p, inp, masks = golden(2, spk=True)
     B, Tt, Td, V, S = int(g['B']), int(g['Tt']), int(g['Td']), int(g['V']), int(g['num_speakers'])
     R = Runner(built_lib, B, Tt, Td, 2, V, S=S)
