@@ -86,6 +86,11 @@ namespace {
 inline int prof_begin(int which, hipStream_t s) { return taco_prof_begin(which, s); }
 inline void prof_end(int which, int slot, hipStream_t s) { taco_prof_end(which, slot, s, 0.0); }
 
+// multi-speaker encoder: the fused form (adapters inside the highway stack kernels, round 6) unless TACO_SPK_UNFUSED=1
+static bool spk_fused_form(const CbhgP& c) {
+  return c.spk && c.has_adapt[0] && c.has_adapt[1] && c.has_adapt[2] && c.has_adapt[3] && !getenv("TACO_SPK_UNFUSED");
+}
+
 struct CbhgBufs {
   float *bank, *pool, *pj1pre, *pj1, *pj2pre, *res, *h[5], *hx[4], *th[4], *xg, *out, *ruc, *tapsplit = nullptr;
   int64_t tapsplit_floats = 0;
@@ -205,7 +210,7 @@ int cbhg_fwd(const float* P, const CbhgP& c, const float* x, int B, int T, const
     TACO_TRY(launch_highway_stack_fwd(ha, s));
   }
   // TACO_SPK_UNFUSED=1: the per-layer launches of rounds 1-5 (A/B runs, parity of the fused form against them)
-  const bool spk_fused = c.spk && c.has_adapt[0] && c.has_adapt[1] && c.has_adapt[2] && c.has_adapt[3] && !getenv("TACO_SPK_UNFUSED");
+  const bool spk_fused = spk_fused_form(c);
   if (spk_fused) {
     // multi-speaker encoder (round 6): the speaker sites of all four layers depend on the speaker embedding alone -- two grouped
     // launches up front (sv_l = relu(dense(spk)), h0 likewise; rowb_l = sv_l . Wa_l[128:] + ba_l) -- and the four layers, adapters
@@ -814,7 +819,7 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
     p.ldr = 16;
     return launch_conv_gemm(p, s);
   };
-  const bool spk_fused = c.spk && c.has_adapt[0] && c.has_adapt[1] && c.has_adapt[2] && c.has_adapt[3] && !getenv("TACO_SPK_UNFUSED");
+  const bool spk_fused = spk_fused_form(c);
   if (spk_fused) {
     // d h0 = relu'(h0) (dh0[fw] + dh0[bw]) goes into slot 4 of the (5,B,128) gradient block; the ReLU backward of all five slots
     // and everything behind it is batched after the highway chain below
@@ -883,34 +888,38 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
       }
       TACO_TRY(hw_group.flush());
     }
-    // per-sequence bias path: d rowb_l[b] = sum_t d hx[l][b,t]; rowb = sv . Wa[128:] + ba; sv = relu(dense(spk))
-    for (int l = 0; l < 4; ++l) TACO_TRY(launch_colsum_batched(hb.dhx[l], kCb, w.dsm[l], B, T, kCb, s));
+    // per-sequence bias path: d rowb_l[b] = sum_t d hx[l][b,t]; rowb = sv . Wa[128:] + ba; sv = relu(dense(spk)).  Nothing on the
+    // activation-gradient chain reads any of it (it ends in parameter gradients and in d spk_e, which only the speaker table's
+    // scatter at the end of the pass consumes): the whole chain of small launches goes to the weight-gradient stream.
+    hipStream_t q = s;
+    TACO_TRY(tn_route(s, &q));
+    for (int l = 0; l < 4; ++l) TACO_TRY(launch_colsum_batched(hb.dhx[l], kCb, w.dsm[l], B, T, kCb, q));
     {
-      TnGroup g2(s);
+      TnGroup g2(q);
       for (int l = 0; l < 4; ++l)
-        TACO_TRY(tn(w.sv[l], kCb, kCb, w.dsm[l], kCb, kCb, G + c.adapt[l].w + (int64_t)kCb * kCb, kCb, B, B, 0, s));
+        TACO_TRY(tn(w.sv[l], kCb, kCb, w.dsm[l], kCb, kCb, G + c.adapt[l].w + (int64_t)kCb * kCb, kCb, B, B, 0, q));
       TACO_TRY(g2.flush());
     }
     ConvGemmBatch b3;
     b3.n = 4;
     for (int l = 0; l < 4; ++l)
       b3.p[l] = dense_problem(w.dsm[l], kCb, PT + t.adapt_s[l], kCb, nullptr, w.dsm2[l], kCb, B, kCb, kCb, TACO_ACT_NONE);
-    TACO_TRY(launch_conv_gemm_batch(b3, s));
+    TACO_TRY(launch_conv_gemm_batch(b3, q));
     // ReLU backward of sv[0..3] and h0 in one pass over the contiguous (5,B,128) blocks
-    TACO_TRY(launch_act_bwd(w.sv[0], w.dsm2[0], nullptr, w.dsm2[0], (int64_t)5 * B * kCb, TACO_ACT_RELU, s));
+    TACO_TRY(launch_act_bwd(w.sv[0], w.dsm2[0], nullptr, w.dsm2[0], (int64_t)5 * B * kCb, TACO_ACT_RELU, q));
     const DenseP* dps[5] = {&c.spkd[0], &c.spkd[1], &c.spkd[2], &c.spkd[3], &c.gru_init};
     const int64_t wTs[5] = {t.spkd[0], t.spkd[1], t.spkd[2], t.spkd[3], t.gru_init};
     {
-      TnGroup g3(s);
-      for (int q = 0; q < 5; ++q) TACO_TRY(tn(w.spk_e, 16, 16, w.dsm2[q], kCb, kCb, G + dps[q]->w, kCb, B, B, 0, s, 1, G + dps[q]->b));
+      TnGroup g3(q);
+      for (int i = 0; i < 5; ++i) TACO_TRY(tn(w.spk_e, 16, 16, w.dsm2[i], kCb, kCb, G + dps[i]->w, kCb, B, B, 0, q, 1, G + dps[i]->b));
       TACO_TRY(g3.flush());
     }
     ConvGemmBatch b4;
     b4.n = 5;
-    for (int q = 0; q < 5; ++q)
-      b4.p[q] = dense_problem(w.dsm2[q], kCb, PT + wTs[q], 16, nullptr, w.dspk_part + (int64_t)q * B * 16, 16, B, 16, kCb, TACO_ACT_NONE);
-    TACO_TRY(launch_conv_gemm_batch(b4, s));
-    TACO_TRY(launch_colsum_batched(w.dspk_part, B * 16, w.dspk_e, 1, 5, B * 16, s));   // d spk_e = sum of the five sites' parts
+    for (int i = 0; i < 5; ++i)
+      b4.p[i] = dense_problem(w.dsm2[i], kCb, PT + wTs[i], 16, nullptr, w.dspk_part + (int64_t)i * B * 16, 16, B, 16, kCb, TACO_ACT_NONE);
+    TACO_TRY(launch_conv_gemm_batch(b4, q));
+    TACO_TRY(launch_colsum_batched(w.dspk_part, B * 16, w.dspk_e, 1, 5, B * 16, q));   // d spk_e = sum of the five sites' parts
     // (gh2 = the gradient of the residual sum `res` = h[0]: nothing in front of the adapters of layer 0)
     float* tmp = gh; gh = gh2; gh2 = tmp;
   } else {
@@ -1186,7 +1195,7 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
       // (Deterministic mode overwrites the accumulator with a fixed-order chain and keeps the explicit add.)
       if (!taco_deterministic()) TACO_TRY(ib.copy(ws + W.post_dx, ws + W.ds2s, (int64_t)M2 * kMel));
       else TACO_TRY(ib.fill(ws + W.post_dx, (int64_t)M2 * kMel));
-      if (!PL.enc.spk) TACO_TRY(ib.fill(ws + W.enc_dx, (int64_t)M1 * kCb));
+      if (!PL.enc.spk || spk_fused_form(PL.enc)) TACO_TRY(ib.fill(ws + W.enc_dx, (int64_t)M1 * kCb));
     }
     TACO_TRY(launch_init_batch(ib, s));
   }
@@ -1372,7 +1381,8 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
   }
   BwdScratch sce = sc;
   float *pre_dz2 = sc.gD, *pre_dz1 = sc.gE, *pre_demb = sc.gF;
-  if (side_tn && side_stream().side && !PL.enc.spk) {   // (speaker sites: their adapter gradients reuse ping-pong buffers)
+  // (the per-layer speaker form, TACO_SPK_UNFUSED=1, keeps its weight gradients on the main stream: their operands live in ping-pong buffers)
+  if (side_tn && side_stream().side && (!PL.enc.spk || spk_fused_form(PL.enc))) {
     // (the side stream is still busy with the decoder weight gradients forked above; the encoder's queue up behind them)
     sce.alt_dpj1 = ws + W.enc_dpj1; sce.alt_dz1 = ws + W.enc_dz1; sce.alt_dpool = ws + W.enc_dpool;
     dP2 = ws + W.enc_dx;
@@ -1387,7 +1397,11 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     g_tn_side = nullptr;
     return rc_enc;
   }
-  if (PL.enc.spk) TACO_TRY(launch_embedding_bwd(ws + W.dspk_e, speaker, G + PL.spk_embed, B, shape->S, s, 16));
+  if (PL.enc.spk) {   // (fused form: d spk_e was summed on the weight-gradient stream -- the speaker table's scatter follows it there)
+    hipStream_t q = s;
+    if (spk_fused_form(PL.enc)) TACO_TRY(tn_route(s, &q));
+    TACO_TRY(launch_embedding_bwd(ws + W.dspk_e, speaker, G + PL.spk_embed, B, shape->S, q, 16));
+  }
   // ---- encoder pre_net + embedding ----
   float* dz2 = pre_dz2;
   float* dz1 = pre_dz1;
