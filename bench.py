@@ -391,12 +391,17 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         def leg(Td_, speakers, steps=8, warmup=3):
             m = make_model(Td_, speakers)
+            # best of two timed passes: about one host call in a hundred stalls for 80-90 ms (profiles/r03_inference_outlier_probe.txt),
+            # and one such stall inside an 8-step pass reads as +1 ms per step (seen once in round 6: 8.53 instead of 7.45)
             sec, f, b_ = time_steps(m, steps, warmup, barrier, 1)
+            sec2, f2, b2_ = time_steps(m, steps, 0, barrier, 1)
+            if sec2 < sec:
+                sec, f, b_ = sec2, f2, b2_
             m.check()
             fa_, ba_ = sum(f) / max(1, len(f)), sum(b_) / max(1, len(b_))
             del m
             torch.cuda.empty_cache()
-            return {'ms_per_step': sec * 1e3, 'mel_frames_per_s': B * Td_ * 2 / sec, 'steps': steps, 'warmup': warmup,
+            return {'ms_per_step': sec * 1e3, 'mel_frames_per_s': B * Td_ * 2 / sec, 'steps': steps, 'warmup': warmup, 'passes': 'best of 2',
                     'decoder_fwd_ms': fa_, 'decoder_bwd_ms': ba_, 'us_per_decoder_step_fwd': fa_ * 1e3 / Td_,
                     'us_per_decoder_step_bwd': ba_ * 1e3 / Td_, 'train_gflop_per_step': 3 * model_flops(B, Tt, Td_, 2) / 1e9}
         if Td != 500:
