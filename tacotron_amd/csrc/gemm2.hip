@@ -374,7 +374,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
       constexpr int j = decltype(jc)::value;
       static_for<0, 3>([&](auto pc) {
         constexpr int pp = decltype(pc)::value;
+#ifdef GEMM2_LAB_NOBREAD   // timing lab: no B fragment reads (results are garbage)
+        pl[j][pp] = u32x4{(unsigned)bb, 0x3f803f80u, (unsigned)j, (unsigned)pp};
+#else
         pl[j][pp] = __builtin_bit_cast(u32x4, dsr128<(4 * pp + j) * 1024>(bb));
+#endif
       });
     });
     __builtin_amdgcn_sched_barrier(0);
@@ -386,7 +390,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
     }
 #endif
     __builtin_amdgcn_sched_barrier(0);
+#ifdef GEMM2_LAB_NOBREAD
+    wait_lgkm<0>();
+#else
     wait_lgkm<12>();                 // the two A reads were issued first
+#endif
     __builtin_amdgcn_sched_barrier(0);
     mfma6(acc[3], pa_c, qb3_c);      // (still the previous tile's A planes)
     const Pl3 pa_n = split8(ra0[0], ra0[1], ra0[2], ra0[3], ra1[0], ra1[1], ra1[2], ra1[3]);
