@@ -5,6 +5,7 @@
 //   taco_backward = opt.compute_gradients(loss)                        (tacotron.py:172)
 //   taco_infer    = Tacotron.inference(train=False)                    (tacotron.py:107-154, ops.py:5-25)
 #include <cstdarg>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -139,6 +140,12 @@ BiGruWeights bigru_weights(const float* P, const CbhgP& c) {
 }
 
 // ops.CBHG forward (ops.py:48-132).  x (B*T, cin).
+// forward_impl's hook: work to enqueue (on the side stream) at the moment the NEXT cbhg_fwd launches its bi-GRU recurrence -- a
+// 64-workgroup kernel of 150-270 us that leaves 192 CUs idle.  Round 6: everything the backward pass derives from the parameters
+// alone (transposed weights, their plane images, transposed decoder composites) runs there, beside the post-net recurrence,
+// instead of beside the encoder's conv bank and proj1, whose launches it used to slow down by ~30 us.
+thread_local std::function<int(hipStream_t)>* g_pre_bigru_hook = nullptr;
+
 int cbhg_fwd(const float* P, const CbhgP& c, const float* x, int B, int T, const CbhgBufs& w, bool keep_ruc,
              hipStream_t s) {
   const int M = B * T, KC = c.K * kCb;
@@ -274,6 +281,11 @@ int cbhg_fwd(const float* P, const CbhgP& c, const float* x, int B, int T, const
                                          6 * kCb, M, kCb, kCb, TACO_ACT_NONE);
     }
     TACO_TRY(launch_conv_gemm_batch(batch, s));
+  }
+  if (g_pre_bigru_hook) {
+    std::function<int(hipStream_t)>* h = g_pre_bigru_hook;
+    g_pre_bigru_hook = nullptr;
+    TACO_TRY((*h)(s));
   }
   TACO_TRY(launch_bigru_fwd(w.xg, bigru_weights(P, c), c.spk ? w.h0 : nullptr, w.out, keep_ruc ? w.ruc : nullptr, B, T, s));
   return TACO_OK;
@@ -501,12 +513,13 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
   if (train) {
     // everything the backward pass derives from the parameters alone (transposed / tap-flipped weight copies, transposed
     // composites) is built here, beside the encoder, instead of at the head of taco_backward's critical path
-    TACO_TRY(prepare_transposes(P, PL, L.T, ws + W.paramsT, r, sd));
-    // ... and the plane images of the transposed weights the backward GEMMs read as their B operand (same stream, behind the copies;
-    // the final dense layer's three zero pad rows come from the init batch on this stream as well)
-    TACO_TRY(register_weight_images(L, W, P, ws, train, 1, true));
-    TACO_TRY(weight_images_build(sd));
-    TACO_TRY(build_dec_composites_bwd(P, PL, W, ws, r, sd));
+    // (round 6: enqueued beside the POST-NET bi-GRU recurrence instead -- `bwd_prep` below; TACO_BWD_PREP_EARLY=1: here, as in rounds 2-5)
+    if (getenv("TACO_BWD_PREP_EARLY")) {
+      TACO_TRY(prepare_transposes(P, PL, L.T, ws + W.paramsT, r, sd));
+      TACO_TRY(register_weight_images(L, W, P, ws, train, 1, true));
+      TACO_TRY(weight_images_build(sd));
+      TACO_TRY(build_dec_composites_bwd(P, PL, W, ws, r, sd));
+    }
     // decoder pre_net (tacotron.py:38-44, 64-71) of every TEACHER-FORCED step: its input (the last frame of mel[t]) is known now,
     // so the two layers are two GEMMs over all B*Td frames, straight into the P1 / P2 slots of the decoder stash, beside the
     // encoder.  The decoder kernel loads P2 on teacher-forced steps and runs (and overwrites) the pre-net only where a step is
@@ -619,7 +632,24 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
   CbhgBufs pb = cbhg_bufs(ws, W.post);
   pb.tapsplit = ws + W.tapsplit;
   pb.tapsplit_floats = W.tapsplit_floats;
-  TACO_TRY(cbhg_fwd(P, PL.post, s2s, B, Td * r, pb, train, s));
+  // transposed / tap-flipped weight copies, their plane images (B operand of the backward GEMMs; same stream, behind the copies) and
+  // the transposed decoder composites: side stream, forked where the post-net's bi-GRU recurrence starts
+  std::function<int(hipStream_t)> bwd_prep = [&](hipStream_t at) -> int {
+    hipStream_t q = side_fork(at);
+    TACO_TRY(prepare_transposes(P, PL, L.T, ws + W.paramsT, r, q));
+    TACO_TRY(register_weight_images(L, W, P, ws, train, 1, true));
+    TACO_TRY(weight_images_build(q));
+    TACO_TRY(build_dec_composites_bwd(P, PL, W, ws, r, q));
+    if (q != at && sl == s) sl = q;   // (make sure the join below covers it)
+    return TACO_OK;
+  };
+  const bool late_prep = train && !getenv("TACO_BWD_PREP_EARLY");
+  if (late_prep) g_pre_bigru_hook = &bwd_prep;
+  const int rc_post = cbhg_fwd(P, PL.post, s2s, B, Td * r, pb, train, s);
+  if (g_pre_bigru_hook) {   // (not reached: cbhg_fwd failed before its recurrence)
+    g_pre_bigru_hook = nullptr;
+  }
+  TACO_TRY(rc_post);
   {
     // output rows are 1025 floats apart: gemm2.hip writes them with its shifted float4 epilogue (92 vs 105 us with scalar stores)
     ConvGemmProblem p = dense_problem(pb.out, 2 * kCb, ws + W.wd_pad, 1028, P + PL.post_dense.b, output, kFft, M2, kFft,
