@@ -209,6 +209,32 @@ def ab_gemm(model, rounds=3, steps=8):
             'median_ms': {k: med(v) for k, v in out.items()}, 'gain_ms': med(out['fp32_mfma']) - med(out['bf16x3'])}
 
 
+def ab_env(model, var, on, off, names, what, rounds=3, steps=8):
+    """In-run A/B of a launch-time switch of the library (read at every launch / call): `var` = `on` vs `off`, alternated in THIS process."""
+    out = {names[0]: [], names[1]: []}
+    prev = os.environ.get(var)
+    try:
+        for _ in range(rounds):
+            for name, v in ((names[0], on), (names[1], off)):
+                os.environ[var] = v
+                for _ in range(2):
+                    model.step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    model.step()
+                torch.cuda.synchronize()
+                out[name].append((time.perf_counter() - t0) / steps * 1e3)
+    finally:
+        if prev is None:
+            os.environ.pop(var, None)
+        else:
+            os.environ[var] = prev
+    med = lambda x: sorted(x)[len(x) // 2]   # noqa: E731
+    return {'what': what, 'ms_per_step': {k: [round(x, 3) for x in v] for k, v in out.items()},
+            'median_ms': {k: med(v) for k, v in out.items()}, 'gain_ms': med(out[names[1]]) - med(out[names[0]])}
+
+
 def ab_decoder(rounds=3):
     """In-run A/B of decoder builds: the product library against libtaco_prevdec.so (the same sources with the previous decoder
     form: -DTACO_NO_RS -DTACO_NO_POLL128 -DTACO_NO_SHADOW -DTACO_NO_GROUPED_FANDQ -DTACO_NO_UNIPOLL -DTACO_NO_TANH_SPLIT), alternated `rounds` times on this box
@@ -351,7 +377,10 @@ def main():
     fam = ab = None
     if rank == 0 and world == 1 and not args.no_extras:
         fam = family_profile(model)
-        ab = {'gemm': ab_gemm(model)}
+        ab = {'gemm': ab_gemm(model),
+              'weight_images': ab_env(model, 'TACO_GEMM2_BSPLIT', '1', '0', ('image_form', 'split_in_registers'),
+                                      'S1 train step, ms: weight operand of the big NN GEMMs read from pre-split bf16 plane images (default, round 6) '
+                                      'vs split in registers in every wave (round 5), alternated in this run; results are bit-identical')}
     del model
     torch.cuda.empty_cache()
 
