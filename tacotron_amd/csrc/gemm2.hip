@@ -1206,7 +1206,7 @@ int launch_conv_gemm2(ConvGemmBatch& batch, hipStream_t stream, bool force) {
       img = p.Wimg != nullptr;
     }
     if (img) {
-      ++g_img_launches;
+      __atomic_fetch_add(&g_img_launches, (int64_t)1, __ATOMIC_RELAXED);
       // 20 KB per stage: three stages = 60 KB (two workgroups per CU), four = 80 KB (2 x 80 = the CU's whole 160 KB)
       static const int bi_ns = [] { const char* e = getenv("TACO_GEMM2_BI_NS"); return e ? atoi(e) : 3; }();
       if (bi_ns == 4) return launch_variant<16, 4, 2>(g, tiles, stream);

@@ -458,6 +458,11 @@ static int register_weight_images(const Layouts& L, const WsLayout& W, const flo
   for_each_weight_image(L.P, L.T, train, [&](int ksrc, int64_t koff, int kld, int dsrc, int64_t doff, int dld, int taps, int K, int N, bool bwd) {
     const int64_t mine = off;
     off += weight_image_floats(taps, K, N);
+    if (rc == TACO_OK && weight_image_bytes(taps, K, N) != 4 * weight_image_floats(taps, K, N)) {   // (layout.h and gemm2.hip must agree)
+      taco_set_error("weight images: layout.h sizes an image of (%d, %d, %d) at %lld floats, gemm2.hip at %lld bytes", taps, K, N,
+                     (long long)weight_image_floats(taps, K, N), (long long)weight_image_bytes(taps, K, N));
+      rc = TACO_EINVAL;
+    }
     if ((bwd ? 1 : 0) != phase || rc != TACO_OK) return;
     auto at = [&](int src, int64_t o) -> const float* {
       return src == 0 ? P + o : (src == 1 ? ws + W.paramsT + o : ws + W.wd_pad + o);
