@@ -522,13 +522,14 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': sec_per_step * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'dtype_note': 'fp32 operands, fp32 accumulation everywhere.  The big GEMM launches form each fp32 product from six bf16 plane '
-                          'products on the matrix pipe (bf16x3, exact three-way operand split) for accumulation chains of <= 2048 products '
-                          '(every launch of this step); deeper chains run v_mfma_f32_32x32x2_f32.  Against fp64 that form measures 0.9-1.2 x '
-                          'the fp32 instruction on mixed-sign operands (Gaussian, post-ReLU x glorot, heavy-tailed) at every depth; on '
-                          'same-signed operands with all mantissa bits set -- its worst case -- 3.8e-7 / 8.5e-7 / 1.9e-6 rel-L2 at chains of '
-                          '256 / 1024 / 2048 against 2e-8 of the fp32 instruction (inside the 5e-6 the GEMM tests state, NOT inside a 4e-7 '
-                          'bar; profiles/r06_bf16x3_chain.txt, tests/test_gpu_ops.py::test_bf16x3_adversarial_operands).  The strict '
-                          'fp32-instruction step time is ab.gemm.median_ms.fp32_mfma',
+                          'products on the matrix pipe (bf16x3, exact three-way operand split; the five low-order products in an accumulator '
+                          'of their own) for accumulation chains of <= 2048 products (every launch of this step); deeper chains run '
+                          'v_mfma_f32_32x32x2_f32.  Against fp64 that form measures 0.3-0.4 x the error of the fp32 INSTRUCTION on mixed-sign '
+                          'operands (Gaussian, post-ReLU x glorot) at every depth, ~1.0 x on heavy-tailed ones; on same-signed operands with '
+                          'all mantissa bits set -- its worst case -- 1.4e-7 / 1.8e-7 / 3.2e-7 rel-L2 at chains of 256 / 1024 / 2048 against '
+                          '2e-8 of the fp32 instruction: inside a 4e-7 bar, asserted by tests/test_gpu_ops.py::test_bf16x3_adversarial_operands '
+                          '(profiles/r06_bf16x3_acc2.txt; one accumulator, as in round 5: 1.9e-6 at 2048).  The strict fp32-instruction step '
+                          'time is ab.gemm.median_ms.fp32_mfma',
             'config': {'workload': 'Nancy-shaped train step (BASELINE configs[1]): B=%d/GPU, r=%d, Tt=%d chars, Td=%d steps '
                                    '(%d mel frames/utt), sched-sampling 0.5, dropout 0.5, V=60, speakers=%d, fwd+bwd+clip+Adam'
                                    % (B, c.r, Tt, Td, Td * c.r, args.speakers),

@@ -63,6 +63,22 @@ __device__ __forceinline__ void mfma6(f32x16& acc, const Pl3& a, const Pl3& b) {
   acc = mfma_bf(a.h, b.m, acc);
   acc = mfma_bf(a.h, b.h, acc);
 }
+// Two-accumulator form (round 6, the default of both kernels; -DTACO_BF16X_ACC1 = one accumulator, rounds 5 / early 6): the five
+// low-order plane products go to `lo`, h h to `hi`; the kernels add the two once behind their k-loop.  The matrix pipe rounds every
+// product onto the grid of the accumulator it is added to (bf16x_max_chain below): against `lo` -- ~2^-7 of `hi` -- the l h / h l
+// products (2^-16 of a product) keep ~20 more bits than against the full sum, and `hi` only ever receives 16-bit products.
+// Measured (profiles/r06_bf16x3_acc2.txt): mixed-sign operands 0.3-0.4 x the error of the fp32 INSTRUCTION at every depth (one
+// accumulator: 0.9-1.2 x); same-signed full mantissas 1.4e-7 / 1.8e-7 / 3.2e-7 at chains of 256 / 1024 / 2048 (3.8e-7 / 8.5e-7 /
+// 1.9e-6), 2.4e-6 at 6144 (1.7e-5); cost: 64 accumulator registers (the NN kernel: 229 -> 242 VGPRs, still two workgroups per CU),
+// +0.5-1 % kernel time.
+__device__ __forceinline__ void mfma6_2(f32x16& hi, f32x16& lo, const Pl3& a, const Pl3& b) {
+  lo = mfma_bf(a.l, b.h, lo);
+  hi = mfma_bf(a.h, b.h, hi);
+  lo = mfma_bf(a.h, b.l, lo);
+  lo = mfma_bf(a.m, b.m, lo);
+  lo = mfma_bf(a.m, b.h, lo);
+  lo = mfma_bf(a.h, b.m, lo);
+}
 __device__ __forceinline__ Pl3 zero_pl3() {
   Pl3 p;
   p.h = u32x4{0, 0, 0, 0}; p.m = p.h; p.l = p.h;
@@ -80,18 +96,17 @@ inline bool env_bf16x() {
 
 // Longest accumulation CHAIN (k-products added into one accumulator register) a launch may have on the bf16x3 form; longer chains
 // take the fp32 MFMA form.  Why (round 6; tools/micro/mfma_bf16_probe.hip, tools/bf16x3_chain_probe.py, profiles/r06_mfma_probe.txt,
-// r06_bf16x3_chain.txt): the matrix pipe rounds every PRODUCT by itself onto the accumulator's grid (2^-26 of its leading bit; both
-// instructions do: 16 products of 1/16 ulp(C) each vanish although their sum is a whole ulp) before adding.  For the fp32 instruction
-// that is an eighth of an ulp per product.  For the split form it means the low-order plane products (l h, h l: 2^-16 of a product)
-// drop out entirely once the accumulator exceeds ~2^11 products' worth -- invisible with mixed signs (accumulators stay small, the
-// losses cancel: Gaussian / post-ReLU x glorot / heavy-tailed operands measure 0.9-1.2 x the fp32 form at every depth up to 6144),
-// but with same-signed operands the accumulator grows linearly and the loss is one-sided: all-ones mantissas, one sign:
-// 3.8e-7 / 8.5e-7 / 1.9e-6 at chains of 256 / 1024 / 2048, then 8.7e-6 at 4096 and 1.7e-5 at 6144 (fp32 form: 2-5e-8).
-// Up to 2048 every case stays inside the 5e-6 the GEMM tests state; beyond it the bf16x3 form is not fp32-grade in the worst
-// case, so it is not used there.  Every launch of the train step is inside the bound (deepest: encoder conv bank width 16 =
-// 16 x 128 = 2048; the deeper reductions -- proj1, the bank input gradient -- are k-split into chains of 768-1741, the weight
-// gradients into row ranges of 320-720); what the bound catches is a plain deep call (taco_conv_gemm with K x taps > 2048) and
-// TACO_DETERMINISTIC=1's one-workgroup-per-tile weight gradients.  TACO_BF16X_MAX_CHAIN overrides (probing).
+// r06_bf16x3_chain.txt, r06_bf16x3_acc2.txt): the matrix pipe rounds every PRODUCT by itself onto the accumulator's grid (2^-26 of
+// its leading bit; both instructions do: 16 products of 1/16 ulp(C) each vanish although their sum is a whole ulp) before adding.
+// For the fp32 instruction that is an eighth of an ulp per product.  For the split form it means that low-order plane products
+// (l h, h l: 2^-16 of a product) added into the FULL sum drop out entirely once that sum exceeds ~2^11 products' worth -- invisible
+// with mixed signs, one-sided with same-signed operands (one accumulator, all-ones mantissas: 1.9e-6 at a chain of 2048, 1.7e-5 at
+// 6144; fp32 form 2-5e-8).  The second accumulator (mfma6_2) removes most of it -- 3.2e-7 at 2048, i.e. inside a 4e-7 bar -- but at
+// 4096 / 6144 the same-signed worst case is still 1.3e-6 / 2.4e-6, so beyond 2048 the bf16x3 form is not used.  Every launch of the
+// train step is inside the bound (deepest: encoder conv bank width 16 = 16 x 128 = 2048; the deeper reductions -- proj1, the bank
+// input gradient -- are k-split into chains of 768-1741, the weight gradients into row ranges of 320-720); what the bound catches is
+// a plain deep call (taco_conv_gemm with K x taps > 2048) and TACO_DETERMINISTIC=1's one-workgroup-per-tile weight gradients.
+// TACO_BF16X_MAX_CHAIN overrides (probing).
 inline int bf16x_max_chain() {
   const char* e = getenv("TACO_BF16X_MAX_CHAIN");
   return e ? atoi(e) : 2048;

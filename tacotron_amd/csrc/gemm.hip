@@ -414,6 +414,15 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTnArgs& P, const int bx, 
     for (int j = 0; j < WN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#ifndef TACO_BF16X_ACC1
+  f32x16 acc_lo[BX ? WM : 1][BX ? WN : 1];   // bf16x3: the low-order plane products' own accumulators (bf16x3.h mfma6_2)
+#pragma unroll
+  for (int i = 0; i < (BX ? WM : 1); ++i)
+#pragma unroll
+    for (int j = 0; j < (BX ? WN : 1); ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc_lo[i][j][e] = 0.f;
+#endif
 
   load_tile(0);
   store_tile(0);
@@ -442,7 +451,13 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTnArgs& P, const int bx, 
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < WN; ++j) mfma6(acc[i][j], pa[i], pb[j]);
+        for (int j = 0; j < WN; ++j) {
+#ifndef TACO_BF16X_ACC1
+          mfma6_2(acc[i][j], acc_lo[i][j], pa[i], pb[j]);
+#else
+          mfma6(acc[i][j], pa[i], pb[j]);
+#endif
+        }
       if (it + 1 < nit) store_tile(buf ^ 1);
       __syncthreads();
       continue;
@@ -472,6 +487,14 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTnArgs& P, const int bx, 
     __syncthreads();
   }
 
+#ifndef TACO_BF16X_ACC1
+  if constexpr (BX) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) acc[i][j] += acc_lo[i][j];
+  }
+#endif
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
 #pragma unroll

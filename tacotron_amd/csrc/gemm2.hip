@@ -259,6 +259,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#ifndef TACO_BF16X_ACC1
+  f32x16 acc_lo[BX ? 4 : 1];   // bf16x3: the five low-order plane products of every sub-tile (bf16x3.h mfma6_2); added to acc behind the k-loop
+#pragma unroll
+  for (int j = 0; j < (BX ? 4 : 1); ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc_lo[j][e] = 0.f;
+#define MF6(j, a, b) mfma6_2(acc[j], acc_lo[j], a, b)
+#else
+#define MF6(j, a, b) mfma6(acc[j], a, b)
+#endif
 
   const int li = lane & 31, kh = lane >> 5;
   const int arow = wave * 32 + li;
@@ -321,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
       rb[q] = dsr128<(8 * (q >> 2) + (q & 3)) * TN * 4>(bb);
     });
     __builtin_amdgcn_sched_barrier(0);
-    mfma6(acc[2], pa_c, pb2_c);
+    MF6(2, pa_c, pb2_c);
 #ifndef GEMM2_LAB_NODMA
     if (fill) {
 #pragma unroll
@@ -331,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
     __builtin_amdgcn_sched_barrier(0);
     wait_lgkm<0>();
     __builtin_amdgcn_sched_barrier(0);
-    mfma6(acc[3], pa_c, pb3_c);   // (still the previous tile's A planes: pa_n takes over below)
+    MF6(3, pa_c, pb3_c);   // (still the previous tile's A planes: pa_n takes over below)
     const Pl3 pa_n = split8(ra0[0], ra0[1], ra0[2], ra0[3], ra1[0], ra1[1], ra1[2], ra1[3]);
     const Pl3 p0 = split8(rb[0][0], rb[1][0], rb[2][0], rb[3][0], rb[4][0], rb[5][0], rb[6][0], rb[7][0]);
 #pragma unroll
@@ -341,10 +351,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
     }
     __builtin_amdgcn_sched_barrier(0);
     pa_c = pa_n;
-    mfma6(acc[0], pa_c, p0);
+    MF6(0, pa_c, p0);
     const Pl3 p1 = split8(rb[0][1], rb[1][1], rb[2][1], rb[3][1], rb[4][1], rb[5][1], rb[6][1], rb[7][1]);
     __builtin_amdgcn_sched_barrier(0);
-    mfma6(acc[1], pa_c, p1);
+    MF6(1, pa_c, p1);
     pb2_c = split8(rb[0][2], rb[1][2], rb[2][2], rb[3][2], rb[4][2], rb[5][2], rb[6][2], rb[7][2]);
     pb3_c = split8(rb[0][3], rb[1][3], rb[2][3], rb[3][3], rb[4][3], rb[5][3], rb[6][3], rb[7][3]);
     // one MFMA, then its share of the 88 split instructions (left alone hipcc issues the six MFMAs back to back and sinks the
@@ -382,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
       });
     });
     __builtin_amdgcn_sched_barrier(0);
-    mfma6(acc[2], pa_c, qb2_c);
+    MF6(2, pa_c, qb2_c);
 #ifndef GEMM2_LAB_NODMA
     if (fill) {
 #pragma unroll
@@ -396,7 +406,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
     wait_lgkm<12>();                 // the two A reads were issued first
 #endif
     __builtin_amdgcn_sched_barrier(0);
-    mfma6(acc[3], pa_c, qb3_c);      // (still the previous tile's A planes)
+    MF6(3, pa_c, qb3_c);      // (still the previous tile's A planes)
     const Pl3 pa_n = split8(ra0[0], ra0[1], ra0[2], ra0[3], ra1[0], ra1[1], ra1[2], ra1[3]);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {    // one MFMA, then its share of the 44 split instructions
@@ -410,8 +420,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
     Pl3 q0, q1;
     q0.h = pl[0][0]; q0.m = pl[0][1]; q0.l = pl[0][2];
     q1.h = pl[1][0]; q1.m = pl[1][1]; q1.l = pl[1][2];
-    mfma6(acc[0], pa_c, q0);
-    mfma6(acc[1], pa_c, q1);
+    MF6(0, pa_c, q0);
+    MF6(1, pa_c, q1);
     qb2_c.h = pl[2][0]; qb2_c.m = pl[2][1]; qb2_c.l = pl[2][2];
     qb3_c.h = pl[3][0]; qb3_c.m = pl[3][1]; qb3_c.l = pl[3][2];
     asm volatile("" : "+v"(qb2_c.h), "+v"(qb2_c.m), "+v"(qb2_c.l), "+v"(qb3_c.h), "+v"(qb3_c.m), "+v"(qb3_c.l));
@@ -454,13 +464,20 @@ __global__ __launch_bounds__(256, 2) void conv_gemm2_kernel(Gemm2Args G) {
     run_tile(it % NS, 0, std::false_type{});
   }
   if constexpr (BX == 1) {   // the last tile's sub-tiles 2 / 3
-    mfma6(acc[2], pa_c, pb2_c);
-    mfma6(acc[3], pa_c, pb3_c);
+    MF6(2, pa_c, pb2_c);
+    MF6(3, pa_c, pb3_c);
   }
   if constexpr (BX == 2) {
-    mfma6(acc[2], pa_c, qb2_c);
-    mfma6(acc[3], pa_c, qb3_c);
+    MF6(2, pa_c, qb2_c);
+    MF6(3, pa_c, qb3_c);
   }
+#ifndef TACO_BF16X_ACC1
+  if constexpr (BX != 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] += acc_lo[j];
+  }
+#endif
+#undef MF6
   wait_vm<0>();   // (nothing outstanding by construction; keeps the invariant explicit before the epilogue's ordinary loads)
 
   // ---- epilogue.  C/D layout of v_mfma_f32_32x32x2: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5);
