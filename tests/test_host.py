@@ -294,3 +294,29 @@ def test_bench_self_launch_command(monkeypatch):
     assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if not __import__('torch').cuda.is_available():
         assert bench.self_launch(argparse.Namespace(gpus=8, rehearse_shared_device=False)) == 2
+
+
+def test_device_feeder_keeps_raising_after_its_worker_died():
+    """once the DeviceFeeder worker has died with an exception, EVERY later next() re-raises it (the first form raised once
+    and then blocked forever on the empty queue); close() still returns."""
+    import time
+    from tacotron_amd.data import DeviceFeeder
+    data = {'x': np.arange(40, dtype=np.float32).reshape(20, 2)}
+    calls = {'n': 0}
+
+    def draw(step):
+        calls['n'] += 1
+        if step >= 2:
+            raise RuntimeError('corpus went away at step %d' % step)
+        return np.arange(4) + step
+
+    f = DeviceFeeder(data, 4, device='cpu', depth=1, draw=draw)
+    a = f.next()['x'].clone()
+    b = f.next()['x'].clone()
+    assert a[0, 0] == 0 and b[0, 0] == 2          # rows 0.. and rows 1.. of the (20, 2) ramp
+    t0 = time.perf_counter()
+    for _ in range(3):
+        with pytest.raises(RuntimeError, match='corpus went away'):
+            f.next()
+    assert time.perf_counter() - t0 < 5.0          # (promptly: no blocking get on a queue nobody fills any more)
+    f.close()
