@@ -765,7 +765,7 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
   constexpr int NCL = 8;
   const int cl = blockIdx.x % NCL, peer = blockIdx.x / NCL;
   const int B = a.B, Tt = a.Tt, Td = a.Td;
-  const int ncl_used = (B + R - 1) / R;
+  const int ncl_used = (B - a.row0 + R - 1) / R;   // (a launch covers rows [row0, row0 + 8 R) of the batch)
   constexpr int R80 = D::R80, KA = D::KA, NO = D::NO;
   float* const U0 = smem + D::o_u0;
   float* const XS = smem + D::o_xs;
@@ -810,7 +810,7 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
   RV brow, len, valid;
   static_for<R>([&](auto Q) {
     constexpr int q = decltype(Q)::value;
-    const int b = cl * R + q;
+    const int b = a.row0 + cl * R + q;
     valid.template at<q>() = b < B;
     brow.template at<q>() = b < B ? b : B - 1;
     const int l = a.text_length[brow.template get<q>()];
@@ -1485,7 +1485,7 @@ __device__ __forceinline__ void decoder3_bwd_body(const DecBwdArgs& a) {
   constexpr int NCL = 8;
   const int cl = blockIdx.x % NCL, peer = blockIdx.x / NCL;
   const int B = a.B, Tt = a.Tt, Td = a.Td;
-  const int ncl_used = (B + R - 1) / R;
+  const int ncl_used = (B - a.row0 + R - 1) / R;   // (a launch covers rows [row0, row0 + 8 R) of the batch)
   constexpr int R80 = D::R80;
   float* const VO = smem + D::o_vo;
   float* const DCP = smem + D::o_dcp;
@@ -1511,7 +1511,7 @@ __device__ __forceinline__ void decoder3_bwd_body(const DecBwdArgs& a) {
   RV brow, len, valid;
   static_for<R>([&](auto Q) {
     constexpr int q = decltype(Q)::value;
-    const int b = cl * R + q;
+    const int b = a.row0 + cl * R + q;
     valid.template at<q>() = b < B;
     brow.template at<q>() = b < B ? b : B - 1;
     const int l = a.text_length[brow.template get<q>()];
@@ -2052,7 +2052,7 @@ template <int R, int RR>
 __global__ __launch_bounds__(NT) void decoder3_bwd_kernel(DecBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int cl = blockIdx.x % 8;
-  if (cl >= (a.B + R - 1) / R) return;   // clusters beyond the batch take no part in any rendezvous or exchange
+  if (cl >= (a.B - a.row0 + R - 1) / R) return;   // clusters beyond the batch take no part in any rendezvous or exchange
   const int where = __builtin_amdgcn_readfirstlane(placement_rendezvous(a.xchg, a.xcc_table_ofs, cl, a.err, smem));
   if (where == 0) return;                 // not co-resident: error word raised
   if (where == 2 && a.fast_ok) decoder3_bwd_body<R, RR, true>(a);
@@ -2164,34 +2164,59 @@ extern "C" int taco_decoder_mode(int mode) {
 int launch_decoder3_bwd(DecBwdArgs a, hipStream_t s) {
   const char* env = getenv("TACO_DEC_V3");
   if (dec_mode() >= 2 || (env && atoi(env) == 1)) return TACO_ENOTFOUND;   // TACO_DEC_V3=1: forward only (A/B runs)
-  if (a.Tt > TTP || a.B > 32 || a.B < 1 || (a.r != 2 && a.r != 5)) return TACO_ENOTFOUND;
+  if (a.Tt > TTP || a.B < 1 || (a.r != 2 && a.r != 5)) return TACO_ENOTFOUND;
   if (!a.hoisted || (a.trace && !kProbes3)) return TACO_ENOTFOUND;
-  const int R = a.B > 16 ? 4 : (a.B > 8 ? 2 : 1);
-  const int ncl = (a.B + R - 1) / R;
-  if ((int64_t)ncl * R * kX3Row * 8 + 1024 > decoder_xchg_bytes(a.B, a.Tt)) return TACO_ENOTFOUND;
+  {
+    const int R0 = a.B > 16 ? 4 : (a.B > 8 ? 2 : 1);   // rows the widest launch's clusters span (whole clusters)
+    const int rows = a.B > 32 ? 32 : (a.B + R0 - 1) / R0 * R0;
+    if ((int64_t)rows * kX3Row * 8 + 1024 > decoder_xchg_bytes(a.B, a.Tt)) return TACO_ENOTFOUND;
+  }
   a.xcc_table_ofs = (int)(decoder_xchg_bytes(a.B, a.Tt) / 4 - 256);
   a.fast_ok = (dec_mode() == 0 && xcd_local_exchange_allowed()) ? 1 : 0;
   a.fakew = kProbes3 ? ((getenv("TACO_DEC_FAKEX") ? 2 : 0)) : 0;
   a.P = P3;
   decoder_note_cluster(1, P3);
-  if (a.r == 2) return R == 4 ? launch3b<4, 2>(a, s) : (R == 2 ? launch3b<2, 2>(a, s) : launch3b<1, 2>(a, s));
-  return R == 4 ? launch3b<4, 5>(a, s) : (R == 2 ? launch3b<2, 5>(a, s) : launch3b<1, 5>(a, s));
+  // B > 32 (round 6): consecutive launches over rows [row0, row0 + 32) -- every launch is the full 8 x 32 grid, the exchange area
+  // (granule epochs, placement table) is zeroed again in front of each launch after the first
+  for (int row0 = 0; row0 < a.B; row0 += 32) {
+    const int nb = a.B - row0 < 32 ? a.B - row0 : 32;
+    const int R = nb > 16 ? 4 : (nb > 8 ? 2 : 1);
+    a.row0 = row0;
+    if (row0 > 0) a.xchg_zeroed = 0;
+    int rc;
+    if (a.r == 2) rc = R == 4 ? launch3b<4, 2>(a, s) : (R == 2 ? launch3b<2, 2>(a, s) : launch3b<1, 2>(a, s));
+    else rc = R == 4 ? launch3b<4, 5>(a, s) : (R == 2 ? launch3b<2, 5>(a, s) : launch3b<1, 5>(a, s));
+    if (rc != TACO_OK) return rc;
+  }
+  return TACO_OK;
 }
 
 // Returns TACO_ENOTFOUND (nothing enqueued) when the shape is outside this kernel's scope; the caller then takes decoder.hip.
 int launch_decoder3_fwd(DecFwdArgs a, hipStream_t s) {
   if (dec_mode() >= 2) return TACO_ENOTFOUND;
-  if (a.Tt > TTP || a.B > 32 || a.B < 1 || (a.r != 2 && a.r != 5)) return TACO_ENOTFOUND;
+  if (a.Tt > TTP || a.B < 1 || (a.r != 2 && a.r != 5)) return TACO_ENOTFOUND;
   if (a.mel && !a.pre2) return TACO_ENOTFOUND;   // training needs the hoisted pre-net
   if (a.trace && !kProbes3) return TACO_ENOTFOUND;   // (the production build carries no stamps; decoder.hip's trace then)
-  const int R = a.B > 16 ? 4 : (a.B > 8 ? 2 : 1);
-  const int ncl = (a.B + R - 1) / R;
-  if ((int64_t)ncl * R * kX3Row * 8 + 1024 > decoder_xchg_bytes(a.B, a.Tt)) return TACO_ENOTFOUND;
+  {
+    const int R0 = a.B > 16 ? 4 : (a.B > 8 ? 2 : 1);   // rows the widest launch's clusters span (whole clusters)
+    const int rows = a.B > 32 ? 32 : (a.B + R0 - 1) / R0 * R0;
+    if ((int64_t)rows * kX3Row * 8 + 1024 > decoder_xchg_bytes(a.B, a.Tt)) return TACO_ENOTFOUND;
+  }
   a.xcc_table_ofs = (int)(decoder_xchg_bytes(a.B, a.Tt) / 4 - 256);   // last 1 KB of the exchange area
   a.fast_ok = (dec_mode() == 0 && xcd_local_exchange_allowed()) ? 1 : 0;
   a.P = P3;
   a.fakew = kProbes3 ? ((getenv("TACO_DEC_FAKEX") ? 2 : 0)) : 0;
   decoder_note_cluster(0, P3);
-  if (a.r == 2) return R == 4 ? launch3<4, 2>(a, ncl, s) : (R == 2 ? launch3<2, 2>(a, ncl, s) : launch3<1, 2>(a, ncl, s));
-  return R == 4 ? launch3<4, 5>(a, ncl, s) : (R == 2 ? launch3<2, 5>(a, ncl, s) : launch3<1, 5>(a, ncl, s));
+  for (int row0 = 0; row0 < a.B; row0 += 32) {   // (B > 32: see launch_decoder3_bwd)
+    const int nb = a.B - row0 < 32 ? a.B - row0 : 32;
+    const int R = nb > 16 ? 4 : (nb > 8 ? 2 : 1);
+    const int ncl = (nb + R - 1) / R;
+    a.row0 = row0;
+    if (row0 > 0) a.xchg_zeroed = 0;
+    int rc;
+    if (a.r == 2) rc = R == 4 ? launch3<4, 2>(a, ncl, s) : (R == 2 ? launch3<2, 2>(a, ncl, s) : launch3<1, 2>(a, ncl, s));
+    else rc = R == 4 ? launch3<4, 5>(a, ncl, s) : (R == 2 ? launch3<2, 5>(a, ncl, s) : launch3<1, 5>(a, ncl, s));
+    if (rc != TACO_OK) return rc;
+  }
+  return TACO_OK;
 }

@@ -357,12 +357,14 @@ struct DecFwdArgs {
   int xchg_zeroed = 0;       // 1: the caller's batched init launch has zeroed the exchange area already (decoder3.hip only)
   int xcc_table_ofs = 0;     // decoder3.hip: int offset, inside the exchange area, of the 256-entry placement table
   int fast_ok = 1;           // decoder3.hip: 0 forces the placement-independent (agent-scope) publish form (TACO_DEC_V3_AGENT=1)
+  int row0 = 0;              // decoder3.hip: first batch row of this launch (B > 32 runs as consecutive launches of <= 32 rows, round 6)
 };
 int64_t decoder_xchg_bytes(int B, int Tt);
 int decoder_last_cluster(int which);   // cluster width (workgroups per row) of the last forward (0) / backward (1) launch
 int launch_decoder_fwd(DecFwdArgs a, hipStream_t s);
 // decoder3.hip: clusters of 32 workgroups x up to 4 rows with register-resident weights.  TACO_ENOTFOUND (nothing enqueued) when
-// the shape is outside its scope (Tt > 256, B > 32, r not in {2, 5}) or TACO_DEC_V3=0: the caller then takes launch_decoder_fwd.
+// the shape is outside its scope (Tt > 256, r not in {2, 5}) or TACO_DEC_V3=0: the caller then takes launch_decoder_fwd.  B > 32 (round 6):
+// consecutive launches of <= 32 rows each (DecFwdArgs::row0), i.e. the step cost per 32 rows stays what it is at B = 32.
 int launch_decoder3_fwd(DecFwdArgs a, hipStream_t s);
 void decoder_note_cluster(int which, int P);
 
@@ -392,7 +394,7 @@ struct DecBwdArgs {
   int P;
   int fakew = 0;
   int lres0 = 0, lres1 = 0;  // launch-resident weight rows (LDS) of the GRU-3 / GRU-2 gate mat-vecs; chosen by launch_decoder_bwd
-  int xcc_table_ofs = 0, fast_ok = 1;   // decoder3.hip (see DecFwdArgs)
+  int xcc_table_ofs = 0, fast_ok = 1, row0 = 0;   // decoder3.hip (see DecFwdArgs)
   int xchg_zeroed = 0;       // 1: the caller has zeroed the exchange area on this stream already (taco_backward's batched init launch)
   int hoisted = 0;           // 1: the pre-net gradients of the teacher-forced steps are formed after the launch (model.hip); the kernel
                              //    runs the pre-net backward only where a step was fed by the previous output

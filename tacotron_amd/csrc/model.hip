@@ -429,7 +429,7 @@ int prepare_transposes(const float* P, const ParamLayout& L, const TransLayout& 
 int build_dec_composites_bwd(const float* P, const ParamLayout& PL, const WsLayout& W, float* ws, int r, hipStream_t s);
 
 // One line on stderr, once per shape, when a launch takes decoder.hip instead of decoder3.hip: Config.validate accepts shapes
-// (r = 1, 3, 4, B > 32, Tt > 256) that the fast kernels do not cover, and the fallback costs about 2x per decoder step.
+// (r = 1, 3, 4, Tt > 256) that the fast kernels do not cover, and the fallback costs about 2x per decoder step.
 void note_decoder_fallback(int B, int Tt, int r) {
   static std::mutex mu;
   static std::map<std::tuple<int, int, int>, bool> seen;
@@ -442,7 +442,7 @@ void note_decoder_fallback(int B, int Tt, int r) {
     fprintf(stderr, "taco: decoder mode %d (TACO_DEC_V3=0 or escalated after an exchange time-out): decoder.hip runs the decoder "
                     "(about 2x slower per step than decoder3.hip)\n", mode);
   else
-    fprintf(stderr, "taco: B=%d Tt=%d r=%d is outside decoder3.hip's scope (B <= 32, Tt <= 256, r in {2, 5}, all 256 workgroups "
+    fprintf(stderr, "taco: B=%d Tt=%d r=%d is outside decoder3.hip's scope (Tt <= 256, r in {2, 5}, all 256 workgroups "
                     "co-resident): decoder.hip runs the decoder, about 2x slower per step\n", B, Tt, r);
 }
 

@@ -956,14 +956,17 @@ def test_inference_is_graph_capturable(built_lib):
 
 
 @pytest.mark.parametrize('B,mode,r', [(11, 'default', 2), (12, 'agent', 2), (20, 'default', 2), (5, 'v3_off', 2), (32, 'agent', 2),
-                                      (20, 'default', 5), (9, 'default', 5)])
+                                      (20, 'default', 5), (9, 'default', 5), (40, 'default', 2), (48, 'default', 2), (50, 'default', 2), (64, 'default', 2),
+                                      (70, 'default', 5)])
 def test_decoder3_cluster_geometries(built_lib, B, mode, r, monkeypatch):
     """decoder3.hip (clusters of 32 workgroups x R rows, register-resident weights): R = 1 / 2 / 4 rows per cluster incl. a
     partially filled last cluster (B = 11: six clusters of two rows, the last with one valid row; B = 20: five clusters of
     four), the placement-independent agent-scope exchange forced (TACO_DEC_V3_AGENT=1: what a cluster that straddles XCDs
     uses), and the decoder.hip fall-back (TACO_DEC_V3=0) -- forward, backward and inference against the fp64 restatement.
     r = 5 (BASELINE configs[0]'s reduction factor) at four and two rows per cluster: the widest instantiations of both kernels
-    (400 output columns per step; 7 d-out prefetch jobs per loader thread, 252 VGPRs in the backward kernel)."""
+    (400 output columns per step; 7 d-out prefetch jobs per loader thread, 252 VGPRs in the backward kernel).  B > 32 (round 6): the
+    batch runs as consecutive decoder3 launches of <= 32 rows (B = 40: 32 rows at R = 4 + 8 at R = 1; B = 50: 32 + 18 at R = 4
+    with a half-filled last cluster; B = 70: 32 + 32 + 6) instead of falling to decoder.hip."""
     if mode == 'agent':
         monkeypatch.setenv('TACO_DEC_V3_AGENT', '1')
     if mode == 'v3_off':
@@ -984,6 +987,21 @@ def test_decoder3_cluster_geometries(built_lib, B, mode, r, monkeypatch):
     assert report('align', R.al.cpu().numpy(), a2)[1] < 1e-6
     assert abs(R.loss[0].item() - lt) <= 1e-5 * lt
     bad = check_grads(R, ref)
+    if bad and B > 32:
+        # more rows = more ReLU / max-pool decisions = a fair chance that fp32 and fp64 take ONE of them differently (a pre-activation
+        # within rounding of its boundary), which moves the small tensors below it by a few 1e-4 (tests/test_gpu_sizes.py exhibits
+        # this at full size).  The flips are read back from the workspace, each must sit within rounding of its boundary, every
+        # DECODER tensor must meet the tolerance as it is, and with the HIP path's decisions imposed on the fp64 graph every tensor does.
+        from tests.decisions import as_force, flips, hip_decisions
+        hip, ok, how = hip_decisions(R, p, masks, B, Tt, Td, r, 1)
+        dec = ot.Decisions()
+        ot.loss_and_grads(p, f64(adj), r, Td, f64(masks), dec=dec)
+        fl = flips(hip, ok, dec)
+        print('  B=%d: %d decision flip(s) vs fp64: %s; tensors off without forcing: %s' % (B, len(fl), fl[:6], bad))
+        assert 1 <= len(fl) <= 16 and all(mg <= 1e-5 for _, _, mg in fl), fl
+        assert not [n for n, _ in bad if n.startswith('decoder')], bad
+        ref_forced = ot.loss_and_grads(p, f64(adj), r, Td, f64(masks), dec=ot.Decisions(as_force(hip)))[4]
+        bad = check_grads(R, ref_forced)
     assert not bad, bad
     Ri = Runner(built_lib, B, Tt, Td, r, V, train=False)
     Ri.set(p, {'text': inp['text'], 'text_length': inp['text_length']})
