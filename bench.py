@@ -346,10 +346,10 @@ def main():
         if world > 1 or forced:
             torch.distributed.barrier()
 
-    def make_model(Td_, speakers):
+    def make_model(Td_, speakers, B_=None):
         cc = Config()
         cc.r, cc.vocab_size, cc.num_speakers = 2, 60, speakers
-        batch = synthetic_batch(B, Tt, Td_, cc.r, cc.vocab_size, seed=1234, rank=rank, num_speakers=speakers)
+        batch = synthetic_batch(B_ or B, Tt, Td_, cc.r, cc.vocab_size, seed=1234, rank=rank, num_speakers=speakers)
         # same initial parameters on every rank (seed 0); the mask streams are offset by the reducer's rank (model.py)
         return Tacotron(cc, batch, train=True, seed=0, reducer=reducer)
 
@@ -416,10 +416,10 @@ def main():
         infer['shape'] = 'Tt=140, Td=%d steps (r=2 -> %d frames/utt), full forward incl. post-net + linear' % (Td, Td * 2)
 
     # ---- the other measured configurations (rank 0 of a 1-GPU run only; the driver's scaling runs skip them) ----
-    s2 = vctk = None
+    s2 = vctk = b64 = None
     if rank == 0 and world == 1 and not args.no_extras:
-        def leg(Td_, speakers, steps=8, warmup=3):
-            m = make_model(Td_, speakers)
+        def leg(Td_, speakers, steps=8, warmup=3, B_=None):
+            m = make_model(Td_, speakers, B_)
             # best of two timed passes: about one host call in a hundred stalls for 80-90 ms (profiles/r03_inference_outlier_probe.txt),
             # and one such stall inside an 8-step pass reads as +1 ms per step (seen once in round 6: 8.53 instead of 7.45)
             sec, f, b_ = time_steps(m, steps, warmup, barrier, 1)
@@ -430,12 +430,17 @@ def main():
             fa_, ba_ = sum(f) / max(1, len(f)), sum(b_) / max(1, len(b_))
             del m
             torch.cuda.empty_cache()
-            return {'ms_per_step': sec * 1e3, 'mel_frames_per_s': B * Td_ * 2 / sec, 'steps': steps, 'warmup': warmup, 'passes': 'best of 2',
+            return {'ms_per_step': sec * 1e3, 'mel_frames_per_s': (B_ or B) * Td_ * 2 / sec, 'steps': steps, 'warmup': warmup, 'passes': 'best of 2',
                     'decoder_fwd_ms': fa_, 'decoder_bwd_ms': ba_, 'us_per_decoder_step_fwd': fa_ * 1e3 / Td_,
-                    'us_per_decoder_step_bwd': ba_ * 1e3 / Td_, 'train_gflop_per_step': 3 * model_flops(B, Tt, Td_, 2) / 1e9}
+                    'us_per_decoder_step_bwd': ba_ * 1e3 / Td_, 'train_gflop_per_step': 3 * model_flops(B_ or B, Tt, Td_, 2) / 1e9}
         if Td != 500:
             s2 = leg(500, args.speakers)
             s2['workload'] = 'S2 envelope: B=%d, Tt=%d, Td=500 (1000 mel frames/utt), r=2' % (B, Tt)
+        if args.speakers == 1 and B == 32:
+            # off-metric (BASELINE quotes batch = 32 per GPU): a batch of 64 per GPU on the same kernels -- the decoder runs it as two
+            # consecutive launches of 32 rows (rounds 1-5: the decoder.hip fallback, 2.35 x slower per decoder step)
+            b64 = leg(Td, 1, B_=64)
+            b64['workload'] = 'OFF-METRIC: B=64 per GPU, Tt=%d, Td=%d, r=2 (decoder3.hip in two launches of 32 rows)' % (Tt, Td)
         if args.speakers == 1:
             vctk = leg(Td, 109)
             vctk['workload'] = 'VCTK-shaped (BASELINE configs[4], 1 GPU): 109 speakers, B=%d, Tt=%d, Td=%d, r=2' % (B, Tt, Td)
@@ -566,6 +571,8 @@ def main():
             res['s2'] = s2
         if vctk:
             res['vctk'] = vctk
+        if b64:
+            res['b64'] = b64
         if infer:
             res['inference'] = infer
         if world == 1 and not args.no_cpu_baseline:
