@@ -2,6 +2,9 @@
 (data_input.py:87-108).  I/O of real corpora (data_input.load_from_npy, preprocess.py) is out of scope."""
 from __future__ import annotations
 
+import queue
+import threading
+
 import numpy as np
 import torch
 
@@ -83,8 +86,6 @@ class DeviceFeeder:
     `next()` call that retired it.  With device='cpu' (tests) the same rotation runs synchronously without pinning."""
 
     def __init__(self, data, batch_size, device='cuda', depth=2, seed=1000, draw=None):
-        import queue
-        import threading
         self.data = {k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v))) for k, v in data.items()}
         self.n = len(next(iter(self.data.values())))
         self.B, self.depth = int(batch_size), int(depth)

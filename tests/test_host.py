@@ -314,6 +314,17 @@ def test_device_feeder_keeps_raising_after_its_worker_died():
     a = f.next()['x'].clone()
     b = f.next()['x'].clone()
     assert a[0, 0] == 0 and b[0, 0] == 2          # rows 0.. and rows 1.. of the (20, 2) ramp
+    # a worker that is merely SLOW (longer than next()'s 1 s liveness poll) is waited for, not mistaken for a dead one
+    slow = {'n': 0}
+
+    def slow_draw(step):
+        slow['n'] += 1
+        if step == 1:
+            time.sleep(1.6)
+        return np.arange(4) + step
+    g = DeviceFeeder(data, 4, device='cpu', depth=1, draw=slow_draw)
+    assert g.next()['x'][0, 0] == 0 and g.next()['x'][0, 0] == 2
+    g.close()
     t0 = time.perf_counter()
     for _ in range(3):
         with pytest.raises(RuntimeError, match='corpus went away'):
