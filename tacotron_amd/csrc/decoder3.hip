@@ -194,6 +194,11 @@ constexpr bool kShadowC = true;       // rounds G1 / G2 of the forward kernel: i
 #else
 constexpr bool kShadowC = false;
 #endif
+#if !defined(TACO_NO_SHADOW_O) && !defined(TACO_NO_BWD_SHADOW) && !defined(TACO_NO_SHADOW)
+constexpr bool kBwdShadowO = true;    // BPTT round DQ's gather: the d out / dx rows of round OUT's mat-vec in its shadow (round 6, late)
+#else
+constexpr bool kBwdShadowO = false;
+#endif
 #if !defined(TACO_NO_PIN_SHADOW)
 constexpr bool kPinShadow = true;     // -DTACO_NO_PIN_SHADOW: A/B builds
 #else
@@ -1562,6 +1567,8 @@ struct BDims {
   static constexpr int KO = R80 + 2 * kAtt + kDec;            // [d out ; dq ; d p1 ; dx]
   static constexpr int KPL_O = (KO + 63) / 64;
   static constexpr int KOP = KPL_O * 64;
+  static constexpr int J_A = R80 / 64;                        // weight registers [0, J_A): rows of d out only; [J_B, KPL_O): rows of dx only
+  static constexpr int J_B = (R80 + 2 * kAtt + 63) / 64;
   // LDS (floats)
   static constexpr int o_vo = 0;                              // [KOP][R]   (zero padded)
   static constexpr int o_dcp = o_vo + KOP * R;                // [256][R]
@@ -1691,7 +1698,9 @@ __device__ __forceinline__ void decoder3_bwd_body(const DecBwdArgs& a) {
   dvu.zero();
   __syncthreads();
 
-  const float km1c = a.keep1 ? 2.f : 1.f, km2c = a.keep2 ? 2.f : 1.f;
+  // (wave-uniform launch constants, held in SGPRs on purpose: as VGPR copies they were the first values the allocator spilled)
+  const float km1c = __int_as_float(__builtin_amdgcn_readfirstlane(a.keep1 ? 0x40000000 : 0x3f800000)),
+              km2c = __int_as_float(__builtin_amdgcn_readfirstlane(a.keep2 ? 0x40000000 : 0x3f800000));
   const float* const stash = a.stash;
   // batch row this lane stores for as a result lane of a valid row (see the forward kernel), else -1
   int sb64, sb32;
@@ -1807,6 +1816,9 @@ __device__ __forceinline__ void decoder3_bwd_body(const DecBwdArgs& a) {
   if (loader) prefetch(Td - 1);
 
   Acc<R> gdp;   // partial sum formed in a poll shadow (see the forward kernel)
+  constexpr bool kShO = kBwdShadowO && (R < 4 || RR == 2);   // (R = 4, r = 5: the partial sum's four registers cost 14 scratch reloads per step)
+  Acc<R> aop;   // round OUT's d out / dx rows, formed in the shadow of round DQ's gather (kBwdShadowO)
+  aop.zero();
   gdp.zero();
   for (int t = Td - 1; t >= 0; --t) {
     X.epoch = (unsigned)(Td - t);
@@ -1871,6 +1883,7 @@ __device__ __forceinline__ void decoder3_bwd_body(const DecBwdArgs& a) {
           put_granule<R>(X, Y3_DP2, n4, L.rho, g);
         }
       }
+      tstamp(X);   // FAN: computed + published
       // one poll loop for the round's two vectors (adjacent regions): d alignments of every slot (nobody scores positions past
       // text_length) and, behind them, the other peers' d p2 columns
       gather<R, ((TTP + kPre2) * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(
@@ -1978,6 +1991,7 @@ __device__ __forceinline__ void decoder3_bwd_body(const DecBwdArgs& a) {
           pass(std::false_type{}, qv);
         }
       }
+      tstamp(X);   // DQ: energy backward done
       float dqv = 0.f;
       if constexpr (kGroupedFanDq) {
         col_sum_all<R, 64>(dq);   // (one reduce-scatter of the R row sums instead of R wave sums with a readlane broadcast each)
@@ -1994,22 +2008,45 @@ __device__ __forceinline__ void decoder3_bwd_body(const DecBwdArgs& a) {
       if (has_next) {
         Acc<R> ap;
         ap.zero();
-        float pp1 = own(D::w_p1, L.wave, L.rho), pnf = smem[D::o_nf + L.rho];
         mv<R, 2, 64>(wdp1, smem + D::o_dp2, L.lane, ap);
-        if constexpr (kEpiPreload) keep_alive(pp1, pnf);
         col_sum_all<R, 64>(ap);
         if (L.res) {
-          g1 = pp1 > 0.f ? km1c * pick<R>(ap, L.rho) : 0.f;
-          g1 = pnf != 0.f ? g1 : 0.f;    // d p1pre of step t+1 reaches this step's output only where that step was fed by it (sampled)
+          g1 = own(D::w_p1, L.wave, L.rho) > 0.f ? km1c * pick<R>(ap, L.rho) : 0.f;
+          g1 = smem[D::o_nf + L.rho] != 0.f ? g1 : 0.f;    // d p1pre of step t+1 reaches this step's output only where that step was fed by it (sampled)
           VO[(R80 + kAtt + u) * R + L.rho] = g1;
           put_granule<R>(X, Y3_DP1, u, L.rho, g1);
         }
       }
+      tstamp(X);   // DQ: dq + d p1 published
       // one poll loop: dq (region Y3_DQ) and, behind it, d p1 (Y3_DP1) -- adjacent regions, adjacent segments of the OUT input
-      // (polled by waves 0-3 for the whole workgroup: the loader waves' prefetch stays in flight across this round)
-      gather<R, (512 * (R >= 2 ? R / 2 : 1) + NT / 2 - 1) / (NT / 2), NT / 2>(
-          X, Y3_DQ, has_next ? 512 : 256, [&](int n) { return ((n & 255) >> 3) == peer; },
-          [&](int n, int q, float v) { VO[(R80 + n) * R + q] = v; });
+      // Round 6 (late): EVERY wave polls.  Rounds 4-5 let waves 0-3 poll for the whole workgroup so that the loader waves' prefetch
+      // (issued behind round FAN) stayed in flight across this round -- four units per polling thread, and the gather was the
+      // longest of the step (0.8-0.9 us against 0.3-0.45).  With eight waves the loader waves wait for their prefetch first (one
+      // in-order counter), which by now has had the softmax backward and the energy backward to land: BPTT 10.63 -> 10.34 us per
+      // step, same box (profiles/r06_dec_chain_ab.txt).  Issuing the prefetch at the step start and sitting out round FAN's
+      // polling instead is slower (10.72).  -DTACO_DQ_HALFPOLL: the previous form (A/B builds).
+#ifndef TACO_DQ_HALFPOLL
+      constexpr int NPQ = NT;
+#else
+      constexpr int NPQ = NT / 2;
+#endif
+      if constexpr (!kShO) {
+        gather<R, (512 * (R >= 2 ? R / 2 : 1) + NPQ - 1) / NPQ, NPQ>(
+            X, Y3_DQ, has_next ? 512 : 256, [&](int n) { return ((n & 255) >> 3) == peer; },
+            [&](int n, int q, float v) { VO[(R80 + n) * R + q] = v; });
+      } else {
+        constexpr int MU = (512 * (R >= 2 ? R / 2 : 1) + NPQ - 1) / NPQ;
+        auto S = gather_begin<R, MU, NPQ>(X, OneRegion{Y3_DQ}, has_next ? 512 : 256, [&](int n) { return ((n & 255) >> 3) == peer; });
+        if constexpr (kShO) {   // round OUT's rows that are final already: d out (step inputs) and dx_{t+1} (previous round G0)
+          aop.zero();
+          mv_part<R, D::KPL_O, 64, 0, D::J_A>(wout, VO, L.lane, aop);
+          mv_part<R, D::KPL_O, 64, D::J_B, D::KPL_O>(wout, VO, L.lane, aop);
+          pin<R>(aop);
+        }
+        // (the loader waves do not touch the vector-memory counter: their prefetch stays in flight across this round)
+        if (L.tid < NPQ) gather_end<R, MU, NPQ>(X, S, OneRegion{Y3_DQ}, [&](int n, int q, float v) { VO[(R80 + n) * R + q] = v; });
+      }
+      tstamp(X);   // DQ: gathered
       if (sb64 >= 0) {
         float* gr = gst + (unsigned)(sb64 * Td + t) * kGsRec;
         gr[kGsQ + u] = dqv;
@@ -2046,10 +2083,12 @@ __device__ __forceinline__ void decoder3_bwd_body(const DecBwdArgs& a) {
       const int u = peer * 8 + L.wave;
       Acc<R> ao;
       ao.zero();
+      if constexpr (kShO) ao = aop;
       // (epilogue operands in front of the mat-vec: kEpiPreload)
       float pdh = own(D::w_dh + 2, L.wave, L.rho), puu = own(D::w_rec + 4 * 2 + 1, L.wave, L.rho), pc = own(D::w_rec + 4 * 2 + 2, L.wave, L.rho),
             php = own(D::w_rec + 4 * 2 + 3, L.wave, L.rho);
-      mv<R, D::KPL_O, 64>(wout, VO, L.lane, ao);
+      if constexpr (kShO) mv_part<R, D::KPL_O, 64, D::J_A, D::J_B>(wout, VO, L.lane, ao);
+      else mv<R, D::KPL_O, 64>(wout, VO, L.lane, ao);
       if constexpr (kEpiPreload) keep_alive(pdh, puu, pc, php);
       col_sum_all<R, 64>(ao);
       if (L.res) {
@@ -2057,7 +2096,9 @@ __device__ __forceinline__ void decoder3_bwd_body(const DecBwdArgs& a) {
         own(D::w_dy, L.wave, L.rho) = dy;
         gru_elem(2, L.wave, L.rho, pdh + dy, u, (unsigned)(sb64 * Td + t) * kGsRec, sb64 >= 0, puu, pc, php);
       }
+      tstamp(X);   // OUT: computed + published
       gather<R, (512 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(X, Y3_CG + 2 * 512, 512, [&](int n) { return ((n & 255) >> 3) == peer; }, cg_put(2));
+      tstamp(X);   // OUT: gathered
     }
     lds_barrier();
     tstamp(X);   // 5: OUT done
@@ -2087,6 +2128,7 @@ __device__ __forceinline__ void decoder3_bwd_body(const DecBwdArgs& a) {
             own(D::w_dhp, M.wave, M.rho) = pdht * uu + y * rr;   // partial new carry: dht u + d(rh) r
           }
         }
+        tstamp(X);   // C_l: computed + published
         {
           constexpr int MU = (256 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT;
           auto S = gather_begin<R, MU>(X, OneRegion{Y3_GR + l * 256}, 256, [&](int n) { return (n >> 3) == peer; });
@@ -2100,6 +2142,7 @@ __device__ __forceinline__ void decoder3_bwd_body(const DecBwdArgs& a) {
           }
           gather_end<R, MU>(X, S, OneRegion{Y3_GR + l * 256}, [&](int n, int q, float v) { smem[o_dgp + n * R + q] = v; });
         }
+        tstamp(X);   // C_l: gathered
         if (sb32 >= 0 && M.lane >= 32) gst[(unsigned)(sb32 * Td + t) * kGsRec + kGsG + l * 512 + u] = gr;
       }
       lds_barrier();
@@ -2138,6 +2181,7 @@ __device__ __forceinline__ void decoder3_bwd_body(const DecBwdArgs& a) {
             own(D::w_dh + l, M.wave, M.rho) = pa + y;                                               // new carried dL/dh_l
           }
         }
+        tstamp(X);   // G_l: computed + published
         if (l > 0) {
           gather<R, (512 * (R >= 2 ? R / 2 : 1) + NT - 1) / NT>(X, Y3_CG + (l - 1) * 512, 512, [&](int n) { return ((n & 255) >> 3) == peer; },
                                                                cg_put(l - 1));
@@ -2149,6 +2193,7 @@ __device__ __forceinline__ void decoder3_bwd_body(const DecBwdArgs& a) {
                                                                });
           if (sb32 >= 0 && M.lane < 32) gst[(unsigned)(sb32 * Td + t) * kGsRec + kGsX + u] = dxv;
         }
+        tstamp(X);   // G_l: gathered
       }
       lds_barrier();
       tstamp(X);   // G_l done

@@ -44,7 +44,10 @@ if not infer:
     tb = m.workspace[o + 16 + 256:o + 16 + 256 + 2 * 64].view(torch.int64).cpu().numpy()
     nb = int(tb[63])
     tt = [(x - tb[0]) / 2400.0 for x in tb[:nb]]
-    names = ['inputs landed', 'FAN (d alignments + d p2)', 'softmax backward', 'DQ (energy backward + dq + d p1)', 'OUT', 'C2', 'G2', 'C1', 'G1', 'C0', 'G0']
+    names = ['inputs landed', 'FAN computed + published', 'FAN gathered + barrier', 'softmax backward + barrier', 'DQ energy backward', 'DQ dq + d p1 published',
+             'DQ gathered', 'DQ stores + barrier', 'OUT computed + published', 'OUT gathered', 'OUT barrier']
+    for l in (2, 1, 0):
+        names += ['C%d computed + published' % l, 'C%d gathered' % l, 'C%d store + barrier' % l, 'G%d computed + published' % l, 'G%d gathered' % l, 'G%d barrier' % l]
     print('BACKWARD step (us at 2.4 GHz), section durations:')
     for i in range(1, nb):
         print('  %-36s %6.2f' % (names[i - 1] if i - 1 < len(names) else '?', tt[i] - tt[i - 1]))
