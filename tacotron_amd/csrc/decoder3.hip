@@ -445,6 +445,20 @@ __device__ __forceinline__ void gather2(Xc& X, int reg1, int N1, int reg2, int N
   gather_end<R, MAXU>(X, S, TwoRegions{reg1, N1, reg2}, put, need);
 }
 
+// wave_max (common.h) with the DPP operand folded into the instruction: one v_max_f32_dpp per step instead of v_mov_dpp + two v_max
+// (the compiler canonicalises fmaxf's operands); same result for the finite / -inf inputs of the softmax
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  asm volatile(
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+      : "+v"(v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // ---- register-resident mat-vec: column `col` of W (K x N, pitch ldw) split over LPC lanes; lane lk holds rows lk + LPC*j ----
 template <int KPL>
 struct WReg {
@@ -961,6 +975,20 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
     if (kNoStash) sb64 = sb32 = sbO = -1;   // timing probe: no stash / output stores at all (results are garbage)
   }
   const unsigned ldp2 = (unsigned)a.ldpre2;
+  // Stash stores through a buffer descriptor (round 6, late): the lane's launch-constant byte offset in a VGPR (a lane that stores
+  // nothing carries an out-of-range offset: the store is dropped, no exec masking), step and field in the SGPR offset -- instead
+  // of 64-bit address arithmetic and a branch per store (~7 instructions per store, ~25 stores per wave and step).
+  // (the launcher keeps B Td kStRec 4 below 2^31)
+  constexpr int kOOBs = (int)0x80000000;
+  const __amdgpu_buffer_rsrc_t rs_st = __builtin_amdgcn_make_buffer_rsrc((void*)a.stash, 0, TR ? B * Td * (kStRec * 4) : 0, 0x00020000);
+  int vo64 = kOOBs, vo32 = kOOBs, vo32h = kOOBs;
+  if (TR) {
+    const int n8w = peer * 8 + wave;
+    if (sb64 >= 0) vo64 = (sb64 * Td * kStRec + n8w) * 4;
+    if (sb32 >= 0) vo32 = (sb32 * Td * kStRec + n8w + (lane < 32 ? kStR : kStU)) * 4;   // gate columns: r (lanes 0-31) / u (lanes 32-63)
+    if (sb32 >= 0 && lane < 32) vo32h = (sb32 * Td * kStRec + n8w + kStRH) * 4;
+  }
+  auto st_store = [&](float v, int vo, int so) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_st, vo, so, 0); };
 
   // ---- step 0 pre-net ----
   // training: p2 of every teacher-forced step comes from the hoisted GEMMs (a.pre2); inference: the first input frame is zeros
@@ -1145,12 +1173,10 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
             if (n < 256) smem[D::o_xs + n * R + q] = v;
           });
       if (TR) {   // stash stores after the polls: they then fly under the next round instead of in front of this round's loads
-        if (sb64 >= 0) stash[(unsigned)(sb64 * Td + t) * kStRec + kStX + n8] = yx;
-        if (sb32 >= 0) {
-          float* st = stash + (unsigned)(sb32 * Td + t) * kStRec;
-          if (M.lane < 32) { st[kStR + n8] = gg; st[kStRH + n8] = gv; }
-          else st[kStU + n8] = gg;
-        }
+        const int so = t * (kStRec * 4);
+        st_store(yx, vo64, so + kStX * 4);
+        st_store(gg, vo32, so);       // r | u
+        st_store(gv, vo32h, so);      // r h
       }
       tstamp(X);   // G0: gathered
     }
@@ -1199,10 +1225,10 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
           gather_end<R, MU>(X, S, OneRegion{X3_G + (l - 1) * 512},
                             [&](int n, int q, float v) { smem[(l == 1 ? D::o_catd : D::o_catc) + (kDec + n) * R + q] = v; });
         }
-        if (TR && sb32 >= 0) {
-          float* st = stash + (unsigned)(sb32 * Td + t) * kStRec;
-          if (M.lane < 32) { st[kStR + l * kDec + n8] = gg; st[kStRH + l * kDec + n8] = gv; }
-          else st[kStU + l * kDec + n8] = gg;
+        if (TR) {
+          const int so = t * (kStRec * 4) + l * (kDec * 4);
+          st_store(gg, vo32, so);
+          st_store(gv, vo32h, so);
         }
         tstamp(X);
         lds_barrier();
@@ -1283,11 +1309,11 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
             gather_end<R, MU>(X, S, OneRegion{X3_C + l * 256}, hput);
           }
         }
-        if (TR && sb64 >= 0) {
-          float* st = stash + (unsigned)(sb64 * Td + t) * kStRec;
-          st[kStC + l * kDec + n8] = cc;
-          st[kStH + l * kDec + n8] = hn;
-          if (l == 2) st[kStY + n8] = yy;
+        if (TR) {
+          const int so = t * (kStRec * 4) + l * (kDec * 4);
+          st_store(cc, vo64, so + kStC * 4);
+          st_store(hn, vo64, so + kStH * 4);
+          if (l == 2) st_store(yy, vo64, t * (kStRec * 4) + kStY * 4);
         }
         tstamp(X);
       }
@@ -1362,8 +1388,7 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
           if (TR && a.prein && has_next && rsel<R>(from_out, O.rho) && c >= kMel * (RR - 1)) a.prein[(bt + 1) * kMel + c - kMel * (RR - 1)] = yo;
         }
       }
-      if (TR && has_next && sb64 >= 0 && rsel<R>(from_out, L.rho))
-        stash[(unsigned)(sb64 * Td + t + 1) * kStRec + kStP1 + n8] = yp;   // record of step t+1
+      if (TR && has_next) st_store(yp, rsel<R>(from_out, L.rho) ? vo64 : kOOBs, (t + 1) * (kStRec * 4) + kStP1 * 4);   // record of step t+1
       tstamp(X);
     }
     lds_barrier();
@@ -1485,8 +1510,8 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
 #else
       if (TR && has_next) {
 #endif
-        if (sb64 >= 0 && L.wave < 4 && rsel<R>(from_out, L.rho))
-          stash[(unsigned)(sb64 * Td + t + 1) * kStRec + kStP2 + n4] = y2;
+        // (column n4 = peer 4 + wave of the wave's unit slot 8 peer + wave: shift the lane's offset by the difference)
+        if (L.wave < 4) st_store(y2, (sb64 >= 0 && rsel<R>(from_out, L.rho)) ? vo64 - (peer * 4) * 4 : kOOBs, (t + 1) * (kStRec * 4) + kStP2 * 4);
       }
       park_next(t + 2);
       tstamp(X);
@@ -1502,12 +1527,14 @@ __global__ __launch_bounds__(NT) void decoder3_fwd_kernel(DecFwdArgs a) {
         float ev[4];
         float m = -INFINITY;
 #pragma unroll
+        for (int j = 0; j < 4; ++j) ev[j] = ES[q * TTP + L.lane + 64 * j];   // (all four reads at once; positions past the text hold finite stale values)
+#pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int sx = L.lane + 64 * j;
-          ev[j] = sx < ln ? ES[q * TTP + sx] : -INFINITY;
+          ev[j] = sx < ln ? ev[j] : -INFINITY;
           m = fmaxf(m, ev[j]);
         }
-        m = wave_max(m);
+        m = wave_max_dpp(m);
         float z = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -2369,6 +2396,7 @@ int launch_decoder3_fwd(DecFwdArgs a, hipStream_t s) {
   if (a.Tt > TTP || a.B < 1 || (a.r != 2 && a.r != 5)) return TACO_ENOTFOUND;
   if (a.mel && !a.pre2) return TACO_ENOTFOUND;   // training needs the hoisted pre-net
   if (a.trace && !kProbes3) return TACO_ENOTFOUND;   // (the production build carries no stamps; decoder.hip's trace then)
+  if ((int64_t)a.B * a.Td * kStRec * 4 >= (int64_t)1 << 31) return TACO_ENOTFOUND;   // (stash stores carry 31-bit byte offsets)
   {
     const int R0 = a.B > 16 ? 4 : (a.B > 8 ? 2 : 1);   // rows the widest launch's clusters span (whole clusters)
     const int rows = a.B > 32 ? 32 : (a.B + R0 - 1) / R0 * R0;
