@@ -330,12 +330,21 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTnArgs& P, const int bx, 
   constexpr int kOOB = (int)0x80000000;
   __amdgpu_buffer_rsrc_t rsA, rsY;
   int a_vo[A_PER], a_t[A_PER], b_vo[B_PER];
+  int sh_t = sh;   // row shift of this thread's A columns (merged taps: the tap its columns belong to)
   if constexpr (VA) {
-    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + (int64_t)sh * P.lda), 0, 0x7fffffff, 0x00020000);
+    int kcol = k0 + a_c4 * 4;
+    if (P.ktap > 0) {
+      const int tc = kcol / P.ktap;
+      kcol -= tc * P.ktap;
+      sh_t = tc - P.pad_l;
+    }
+    // (the descriptor starts 16 rows in front of A so that a negative shift keeps the byte offset positive; rows outside their
+    //  sequence are masked by `ok` below whatever the offset)
+    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A - (int64_t)16 * P.lda), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
       const int r = a_r + i * A_RSTEP, k = k0 + a_c4 * 4;
-      a_vo[i] = (r < BK && k < P.K) ? ((m_begin + r) * P.lda + k) * 4 : kOOB;
+      a_vo[i] = (r < BK && k < P.K) ? ((m_begin + r + sh_t + 16) * P.lda + kcol) * 4 : kOOB;
       a_t[i] = (m_begin + r) % P.T;
     }
   }
@@ -357,7 +366,7 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTnArgs& P, const int bx, 
       const int m = mm0 + r;
       const int k = k0 + a_c4 * 4;
       if constexpr (VA) {
-        const bool ok = m < m_end && (unsigned)(a_t[i] + sh) < (unsigned)P.T;
+        const bool ok = m < m_end && (unsigned)(a_t[i] + sh_t) < (unsigned)P.T;
         v = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? a_vo[i] : kOOB, it * (BK * 4) * P.lda, 0));
         a_t[i] += BK;
         if (P.T >= BK) a_t[i] = a_t[i] >= P.T ? a_t[i] - P.T : a_t[i];
@@ -799,11 +808,19 @@ static int plan_gemm_tn(GemmTnArgs& a, bool force_small, dim3& grid, int64_t gro
   if (a.Nld <= 0) a.Nld = (a.N % 4 == 0) ? a.N : 0;
   // (the vector paths address an operand with 32-bit byte offsets against one buffer descriptor: its extent must stay below 2 GiB)
   const int64_t lim31 = (int64_t)1 << 31;
-  if (a.lda % 4 == 0 && aligned16(a.A) && a.strideA % 4 == 0 && a.K % 4 == 0 && ((int64_t)a.M + a.taps + 16) * a.lda * 4 < lim31)
+  if (a.lda % 4 == 0 && aligned16(a.A) && a.strideA % 4 == 0 && a.K % 4 == 0 && ((int64_t)a.M + a.taps + 48) * a.lda * 4 < lim31)
     a.flags |= 1;
   if (a.ldy % 4 == 0 && aligned16(a.Y) && a.strideY % 4 == 0 && a.Nld > 0 && a.Nld % 4 == 0 && a.Nld <= a.ldy &&
       ((int64_t)a.M + 16) * a.ldy * 4 < lim31)
     a.flags |= 2;
+  // taps merged into K where K is no multiple of the 64-row tile (kernels.h GemmTnArgs::ktap; vector A operand only; |shift| <= 16)
+  const char* em = getenv("TACO_TN_MERGE_TAPS");   // (0: one tile row per tap, rounds 1-6; read per launch so that a test can cover both)
+  const bool merge_taps = !(em && atoi(em) == 0);
+  if (merge_taps && a.ktap == 0 && (a.flags & 1) && a.taps > 1 && a.taps <= 17 && a.K % 64 != 0 && a.pad_l <= 16 && a.taps - 1 - a.pad_l <= 16) {
+    a.ktap = a.K;
+    a.K *= a.taps;
+    a.taps = 1;
+  }
   // TACO_TN_BM=64|128 forces the tile (tuning harness); TACO_TN_BIG_TILES = least number of 128 x 128 tiles for the big tile
   static const int force_bm = [] { const char* e = getenv("TACO_TN_BM"); return e ? atoi(e) : 0; }();
   static const int big_tiles = [] { const char* e = getenv("TACO_TN_BIG_TILES"); return e ? atoi(e) : 128; }();

@@ -67,6 +67,9 @@ struct GemmTnArgs {
   int splits = 1, chunk = 0, flags = 0;
   int Nld = 0;   // loadable Y columns (>= N, multiple of 4, <= ldy) when Y rows are zero-padded; 0 = derive from N
   int xcd = 0;   // 1: XCD-aware block order (set by the launcher, gemm.hip `tn_xcd_order`)
+  int ktap = 0;  // > 0 (set by the launcher): the taps are MERGED into the K dimension -- K holds taps * ktap, column kk of a tile is
+                 // column kk % ktap of tap kk / ktap (its rows shifted accordingly), taps == 1.  For K that is no multiple of the 64-row
+                 // tile (post-net conv bank: K = 80 -> 2 tiles of 64 per tap, 37.5 % of them padding; merged: 640 rows = 10 tiles for 8 taps)
 };
 
 int launch_conv_gemm_batch(ConvGemmBatch& batch, hipStream_t stream);

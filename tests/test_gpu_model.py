@@ -515,7 +515,7 @@ def test_pooled_bank_epilogue_tile_edges(built_lib, B, Tt, Td, monkeypatch):
 
 
 @pytest.mark.parametrize('knob', ['TACO_NO_BANK_GATHER=1', 'TACO_GEMM2_XCD=0', 'TACO_GEMM2_BF16X=0', 'TACO_DEC_NO_LRES=1',
-                                  'TACO_TN_XCD=0', 'TACO_GEMM2_BANK_XCD=0', 'TACO_GEMM2_BSPLIT=0'])
+                                  'TACO_TN_XCD=0', 'TACO_GEMM2_BANK_XCD=0', 'TACO_GEMM2_BSPLIT=0', 'TACO_TN_MERGE_TAPS=0'])
 def test_medium_shape_with_optional_paths(built_lib, knob, monkeypatch):
     """The fallback / A-B switches of the train step keep parity: the conv bank's input gradient as K atomic-accumulating problems
     (TACO_NO_BANK_GATHER=1: the path taken when the slabs do not fit or the kernels are not contiguous), gemm2's plain tile order

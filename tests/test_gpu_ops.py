@@ -348,7 +348,9 @@ TN_CASES = [(128, 128, 128, 128, 1, 0), (360, 36, 80, 128, 3, 1), (5760, 180, 25
             (90, 9, 128, 128, 16, 7), (512, 512, 1025, 256, 1, 0), (77, 77, 20, 36, 1, 0),
             # second-generation kernel (gemm2.hip gemm_tn2: M >= 512, K, N >= 96, vector contract)
             (1600, 200, 128, 128, 16, 7), (1200, 40, 132, 260, 3, 1), (1440, 360, 256, 1024, 3, 1), (2000, 2000, 100, 96, 1, 0),
-            (640, 20, 128, 128, 8, 4)]
+            (640, 20, 128, 128, 8, 4),
+            # K no multiple of the 64-row tile: the taps are merged into K (GemmTnArgs::ktap); post-net conv bank shapes
+            (720, 360, 128, 80, 8, 3), (800, 200, 128, 80, 5, 2), (360, 90, 80, 36, 2, 0)]
 
 
 @pytest.mark.parametrize('tn2', ['0', '1'], ids=['gemm_tn', 'opt-in-tn2'])
