@@ -23,7 +23,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default)
 
-#define TACO_VERSION 117
+#define TACO_VERSION 118
 
 #define TACO_OK 0
 #define TACO_EINVAL (-1)   /* bad argument / unsupported shape   */
@@ -177,18 +177,21 @@ int taco_clear_error(const TacoShape* shape, int train, void* workspace, void* s
 int taco_decoder_mode(int mode);
 
 /* ---- data-parallel overlap (no reference counterpart: train.py:24 is a single Session) ---------------- */
-/* The flat gradient buffer becomes final in FOUR contiguous segments, in this order during taco_backward:
- *   segment 3 = [bounds[3], bounds[4])  post-net CBHG + final dense   (final before the decoder BPTT; ANNOUNCED right after it)
- *   segment 2 = [bounds[2], bounds[3])  attention memory layer + decoder
- *   segment 1 = [bounds[1], bounds[2])  encoder CBHG without its conv bank: projections, highways, bi-GRU
- *   segment 0 = [bounds[0], bounds[1])  embedding(s) + encoder pre_net + encoder conv bank   (end of taco_backward)
- * taco_grad_segments fills bounds[5] (float offsets) and returns 4.  taco_wait_grad_segment makes `stream` wait (device
+/* The flat gradient buffer becomes final in FIVE contiguous segments, in this order during taco_backward:
+ *   segment 4 = [bounds[4], bounds[5])  post-net CBHG + final dense   (final before the decoder BPTT; ANNOUNCED right after it)
+ *   segment 3 = [bounds[3], bounds[4])  attention memory layer + decoder
+ *   segment 2 = [bounds[2], bounds[3])  encoder CBHG without its conv bank: projections, highways, bi-GRU
+ *   segment 1 = [bounds[1], bounds[2])  encoder conv bank   (behind its grouped weight-gradient launch, the last big one of the pass)
+ *   segment 0 = [bounds[0], bounds[1])  embedding(s) + encoder pre_net   (end of taco_backward)
+ * taco_grad_segments fills bounds[6] (float offsets) and returns 5 (version 117 and earlier: four segments, the conv bank in
+ * segment 0).  taco_wait_grad_segment makes `stream` wait (device
  * side, hipStreamWaitEvent) until segment `seg` of the most recent taco_backward enqueued by the calling thread on the
  * current device is final, so an all-reduce enqueued on `stream` afterwards overlaps the rest of the backward pass.
- * Segment 3 is announced AFTER the decoder BPTT kernel although it is final before it: that kernel is a persistent launch
+ * Segment 4 is announced AFTER the decoder BPTT kernel although it is final before it: that kernel is a persistent launch
  * whose 256 workgroups must all be co-resident (one per CU), so no collective is ever allowed to compete with it for CUs;
- * segments 3 and 2 (13.7 MB) travel under the encoder backward, segment 1 (4.7 MB) under the encoder conv-bank gradients, and
- * only segment 0 (9.4 MB, of which the conv bank -- the last 0.6 ms of the pass -- is 8.9 MB) is exposed. */
+ * segments 4 and 3 (13.7 MB) travel under the encoder backward, segment 2 (4.7 MB) under the encoder conv-bank gradients,
+ * segment 1 (8.9 MB) under the step's tail (bank input gradient, pre_net chain, embedding scatter: ~0.1 ms), and only
+ * segment 0 (0.5 MB) is exposed in full. */
 int taco_grad_segments(const TacoShape* shape, int64_t* bounds);
 int taco_wait_grad_segment(int seg, void* stream);
 /* Communication-kernel stand-in for the co-residency tests (tests/test_gpu_dist.py): `blocks` workgroups x `threads` threads, `lds_bytes` of LDS each, spinning

@@ -306,16 +306,16 @@ DecWeights dec_weights(const float* P, const ParamLayout& L) {
 // Side stream: work that is independent of the main chain runs here while a 64-workgroup recurrent kernel (bi-GRU) or the
 // encoder leaves most of the chip idle.  side_fork(): the side stream waits for everything enqueued on `s` so far;
 // side_join(): `s` waits for the side work.  No host synchronisation; TACO_NO_OVERLAP=1 keeps everything on `s`.
-constexpr int kGradSegments = 4;
+constexpr int kGradSegments = 5;
 struct SideStream {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev_img = nullptr;   // the forward weight images are built (recorded on the side stream; the main stream waits in front of the encoder CBHG)
   bool off = false;
   // gradient-segment events of the most recent taco_backward issued by this thread on this device (taco_wait_grad_segment):
-  // segment [3] post-net, [2] decoder, [1] encoder projections / highways / bi-GRU, [0] embedding + encoder pre_net + conv bank
-  // of the flat gradient buffer is final
-  hipEvent_t ev_seg[kGradSegments] = {nullptr, nullptr, nullptr, nullptr};
+  // segment [4] post-net, [3] decoder, [2] encoder projections / highways / bi-GRU, [1] encoder conv bank, [0] embedding + encoder
+  // pre_net of the flat gradient buffer is final
+  hipEvent_t ev_seg[kGradSegments] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   bool seg_recorded = false;
 };
 SideStream& side_stream() {
@@ -816,8 +816,11 @@ struct BwdScratch {
 // x is the CBHG input.  Scratch: gA/gB (M, K*128), gC (M,768), gD..gG (M,256).
 // seg_after_p1 >= 0: that gradient segment (projections, highways, bi-GRU -- everything of this CBHG except the conv bank) is
 // announced as soon as its last contributor, proj1's weight gradient, has been enqueued.
+// seg_after_bank >= 0 (round 6, late): likewise the conv bank's own range [bank_w[0], p1_w) behind its grouped weight-gradient launch
+// (its BN gradients come out of the pooled backward epilogue before that): 8.9 MB of the encoder's last segment no longer wait for the
+// step's tail (bank input gradient, pre_net chain, embedding scatter) before they can travel.
 int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const CbhgT& t, const float* x, const float* dOut,
-             int B, int T, const CbhgBufs& w, const BwdScratch& sc, float* dx_out, int seg_after_p1, hipStream_t s) {
+             int B, int T, const CbhgBufs& w, const BwdScratch& sc, float* dx_out, int seg_after_p1, int seg_after_bank, hipStream_t s) {
   const int M = B * T, KC = c.K * kCb;
   // ---- bi-GRU ----
   float* dxg = sc.gC;   // (M,768)
@@ -1062,6 +1065,11 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
       }
     }
     TACO_TRY(bank_group.flush());
+    if (seg_after_bank >= 0) {
+      hipStream_t q;
+      TACO_TRY(tn_route(s, &q));
+      TACO_TRY(record_segment(seg_after_bank, q));
+    }
     if (taco_deterministic()) {
       // fixed order: the K transposed convolutions run one after the other, each adding to dx_out through the residual input
       for (int i = c.K - 1; i >= 0; --i) {   // batch.p[K - 1] is the k = 1 problem carrying the dres residual
@@ -1263,7 +1271,7 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
   }
   pb.tapsplit = ws + W.tapsplit;   // (free in the backward pass: the conv-bank input gradient's partial tiles)
   pb.tapsplit_floats = W.tapsplit_floats;
-  const int rc_post = cbhg_bwd(P, PT, G, PL.post, TL.post, seq2seq_output, dPostOut, B, F, pb, scp, dPostIn, -1, s);
+  const int rc_post = cbhg_bwd(P, PT, G, PL.post, TL.post, seq2seq_output, dPostOut, B, F, pb, scp, dPostIn, -1, -1, s);
   g_tn_side = nullptr;
   TACO_TRY(rc_post);
   // d seq2seq_output = sign(s2s - mel) + post-net path
@@ -1271,7 +1279,7 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
   if (side_tn && own_dx && !taco_deterministic()) dS2S = dPostIn;   // (accumulated on top of the L1 term, see the init launch)
   else TACO_TRY(launch_add(ws + W.ds2s, dPostIn, dS2S, (int64_t)MD * R80, s));
   TACO_TRY(side_join(s, side));
-  // Gradient segment 3 (post-net CBHG + final dense) is final HERE, but it is ANNOUNCED only after the BPTT kernel below: that
+  // Gradient segment 4 (post-net CBHG + final dense) is final HERE, but it is ANNOUNCED only after the BPTT kernel below: that
   // kernel is a persistent launch that needs all 256 workgroups co-resident, one per CU, and a collective's kernel that took
   // CUs first would leave part of every cluster spinning on peers that cannot start.  The bytes travel under the encoder
   // backward instead -- 1.5 ms of ordinary kernels.
@@ -1304,7 +1312,7 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
     if (rc == TACO_ENOTFOUND) rc = launch_decoder_bwd(a, s);
     TACO_TRY(rc);
     prof_end(1, slot, s);
-    TACO_TRY(record_segment(3, s));
+    TACO_TRY(record_segment(4, s));
   }
   // ---- attention memory.  The kernel never forms the context or its gradient (decoder.hip); everything they carried follows
   //      from E[b] = sum_t alignments[b,t-1]^T dx[b,t]  (Tt x 256 per row; one batched launch):
@@ -1403,9 +1411,9 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
                             kPre1, TACO_ACT_NONE);
     b2.p[1].residual = G + PL.out_proj.b + (R80 - kMel); b2.p[1].ldr = R80;
     TACO_TRY(launch_conv_gemm_batch(b2, s));
-    // gradient segment 2 (memory layer + decoder) is final here: everything the main stream contributed (memory-layer
+    // gradient segment 3 (memory layer + decoder) is final here: everything the main stream contributed (memory-layer
     // kernel, attention_v from the BPTT kernel) was enqueued before this side stream forked
-    TACO_TRY(record_segment(2, s));
+    TACO_TRY(record_segment(3, s));
   }
   // ---- encoder CBHG ----
   float* dP2 = sc.gC;       // (M1,128)
@@ -1427,7 +1435,7 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
   }
   eb.tapsplit = ws + W.tapsplit;
   eb.tapsplit_floats = W.tapsplit_floats;
-  int rc_enc = cbhg_bwd(P, PT, G, PL.enc, TL.enc, ws + W.p2, dEnc, B, Tt, eb, sce, dP2, 1, s);
+  int rc_enc = cbhg_bwd(P, PT, G, PL.enc, TL.enc, ws + W.p2, dEnc, B, Tt, eb, sce, dP2, 2, 1, s);
   if (rc_enc != TACO_OK) {
     g_tn_side = nullptr;
     return rc_enc;
@@ -1472,10 +1480,11 @@ extern "C" int taco_grad_segments(const TacoShape* shape, int64_t* bounds) {
   TACO_REQUIRE(bounds != nullptr, "taco_grad_segments: null bounds");
   const ParamLayout& PL = layouts_for(*shape).P;
   bounds[0] = 0;
-  bounds[1] = PL.enc.p1_w;         // [0, enc proj1): embedding(s) + encoder pre_net + encoder conv bank (final LAST)
-  bounds[2] = PL.mem_w;            // [enc proj1, mem_w): encoder projections, highways, bi-GRU
-  bounds[3] = PL.post.bank_w[0];   // [mem_w, post): attention memory layer + decoder
-  bounds[4] = PL.total;            // [post, total): post-net CBHG + final dense (final FIRST)
+  bounds[1] = PL.enc.bank_w[0];    // [0, enc bank): embedding(s) + encoder pre_net (final LAST)
+  bounds[2] = PL.enc.p1_w;         // [enc bank, enc proj1): encoder conv bank (its weight gradients: the last big launch of the pass)
+  bounds[3] = PL.mem_w;            // [enc proj1, mem_w): encoder projections, highways, bi-GRU
+  bounds[4] = PL.post.bank_w[0];   // [mem_w, post): attention memory layer + decoder
+  bounds[5] = PL.total;            // [post, total): post-net CBHG + final dense (final FIRST)
   return kGradSegments;
 }
 

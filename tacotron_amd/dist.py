@@ -4,7 +4,7 @@ One process per GPU; each rank runs forward+backward on its own minibatch; ONE e
 flat fp32 gradient buffer (loss is a plain sum, so SUM -- not mean -- reproduces the N*B-batch gradient exactly), then
 every rank applies the same clip + Adam update, so replicas stay identical.  Backend "nccl" is RCCL on ROCm (xGMI);
 "gloo" is used by the CPU tests.  The buffer is reduced in a few large buckets issued back-to-back (xGMI rings are
-per-link bound, so few large messages beat many small ones): 10 MB buckets make each of the four segments ONE collective."""
+per-link bound, so few large messages beat many small ones): 10 MB buckets make each of the five segments ONE collective."""
 from __future__ import annotations
 
 import os
@@ -57,14 +57,15 @@ def _comm_priority():
     return -1 if lib.effective_hw_queues() >= 8 else 0
 
 
-SEGMENT_NAMES = {3: 'post-net', 2: 'decoder', 1: 'encoder projections+highways+bi-GRU', 0: 'embedding+encoder pre_net+conv bank'}
+SEGMENT_NAMES = {4: 'post-net', 3: 'decoder', 2: 'encoder projections+highways+bi-GRU', 1: 'encoder conv bank', 0: 'embedding+encoder pre_net'}
 
 
 class GradReducer:
     """SUM all-reduce of the flat gradient buffer, overlapped with the backward pass.
 
-    `taco_backward` finalises the buffer in four contiguous segments (`lib.grad_segments`: post-net 7.3 MB, decoder 6.4 MB,
-    encoder without its conv bank 4.7 MB, embedding + encoder pre_net + conv bank 9.4 MB) and records a HIP event per segment.
+    `taco_backward` finalises the buffer in five contiguous segments (`lib.grad_segments`: post-net 7.3 MB, decoder 6.4 MB,
+    encoder without its conv bank 4.7 MB, encoder conv bank 8.9 MB, embedding + encoder pre_net 0.5 MB) and records a HIP event
+    per segment.
     `reduce_after_backward` enqueues, on a high-priority communication stream, a device-side wait for each event followed by
     that segment's bucketed all-reduce, so the bytes travel while the rest of the backward pass runs and the host never
     blocks.
@@ -72,8 +73,9 @@ class GradReducer:
     No collective ever runs beside the decoder BPTT: that kernel is a persistent launch whose 256 workgroups must all be
     co-resident (one per CU, ~110 KB of LDS each); an RCCL kernel dispatched first would hold CUs that part of every cluster
     needs, and that part's peers would spin until it gets them.  The library therefore announces the post-net segment only
-    AFTER the BPTT kernel: segments 3 and 2 (13.7 MB) reduce under the encoder backward (1.5 ms of ordinary kernels),
-    segment 1 under the encoder's conv-bank gradients (the last 0.6 ms), and only segment 0 is exposed.  (Rounds 2-3 had an
+    AFTER the BPTT kernel: segments 4 and 3 (13.7 MB) reduce under the encoder backward (1.5 ms of ordinary kernels),
+    segment 2 under the encoder's conv-bank gradients (the last 0.6 ms), segment 1 (the conv bank itself, final behind its
+    weight-gradient launch; round 6) under the step's tail (~0.1 ms), and only segment 0 (0.5 MB) is exposed in full.  (Rounds 2-3 had an
     opt-in mode that reduced the post-net segment underneath the older, slower BPTT kernel; it cost more than it hid and was
     removed in round 4.)
 

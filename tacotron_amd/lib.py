@@ -266,8 +266,8 @@ def clear_error(shape, train, workspace):
 
 
 def grad_segments(shape):
-    """Float offsets [b0 .. b4] of the four gradient segments (0 embedding + encoder pre_net + conv bank, 1 rest of the
-    encoder, 2 decoder, 3 post-net); they become final in the order 3, 2, 1, 0 during taco_backward."""
+    """Float offsets [b0 .. b5] of the five gradient segments (0 embedding + encoder pre_net, 1 encoder conv bank, 2 rest of the
+    encoder, 3 decoder, 4 post-net); they become final in the order 4, 3, 2, 1, 0 during taco_backward."""
     b = (C.c_int64 * 8)()
     n = _lib.taco_grad_segments(C.byref(shape), b)
     if n < 1 or n > 7:

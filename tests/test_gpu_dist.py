@@ -152,6 +152,6 @@ def test_bench_self_launches_n_ranks_from_the_plain_command(built_lib):
           % (j['n_gpus'], j['ms_per_step'], j['allreduce']['backend'], j['allreduce']['world'], j['per_rank']))
     assert j['n_gpus'] == 2 and j['steps'] == 3 and j['scaling'] == 'weak' and 'rehearsal' in j
     assert j['config']['global_batch'] == 2 * 4 and j['config']['parallelism'] == 'dp2'
-    assert j['allreduce']['world'] == 2 and j['allreduce']['backend'] == 'gloo' and len(j['allreduce']['segments']) == 4
+    assert j['allreduce']['world'] == 2 and j['allreduce']['backend'] == 'gloo' and len(j['allreduce']['segments']) == 5
     assert [p['rank'] for p in j['per_rank']] == [0, 1] and all(p['us_per_decoder_step_fwd'] > 0 for p in j['per_rank'])
     assert j['value'] > 0 and np.isfinite(j['final_loss'])

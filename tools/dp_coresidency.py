@@ -30,7 +30,7 @@ def build_model(B=32, Tt=200, Td=180):
 
 
 def one(m, masks, order, spin_us, comm):
-    """order: None (no stand-in), 'segment' (on the communication stream behind taco_wait_grad_segment(3), i.e. exactly where
+    """order: None (no stand-in), 'segment' (on the communication stream behind taco_wait_grad_segment(post-net), i.e. exactly where
     GradReducer enqueues the post-net all-reduce)."""
     from tacotron_amd import lib
     m.forward(masks)
@@ -45,7 +45,7 @@ def one(m, masks, order, spin_us, comm):
     b1.record(main)
     if order == 'segment':
         with torch.cuda.stream(comm):
-            lib.wait_grad_segment(3, comm)
+            lib.wait_grad_segment(len(lib.grad_segments(m.shape)) - 2, comm)   # the post-net segment: the first one announced
             e0.record(comm)
             lib.debug_spin(SPIN_BLOCKS, SPIN_THREADS, SPIN_LDS, spin_us, comm)
             e1.record(comm)
