@@ -67,3 +67,20 @@ def test_error_behaviour(built_lib):
     with pytest.raises(built_lib.TacoError):
         built_lib.workspace_bytes(built_lib.make_shape(2, 10, 6, 9, 60), True)
     assert 'r=9' in built_lib.last_error()
+
+
+@pytest.mark.parametrize('S', [1, 109])
+def test_gradient_segments_cover_the_buffer(built_lib, S):
+    """taco_grad_segments (include/taco_hip.h, version 118): five contiguous segments that tile the flat gradient buffer; the
+    encoder conv bank is a segment of its own (K = 16 widths: 136 taps x 128 x 128 kernels + 16 biases + BN gamma / beta), and
+    every segment has a name in the reducer's report."""
+    from tacotron_amd.dist import SEGMENT_NAMES
+    shape = built_lib.make_shape(32, 200, 180, 2, 60, S)
+    b = built_lib.grad_segments(shape)
+    assert len(b) == 6 and b[0] == 0 and b[-1] == built_lib.param_count(shape)
+    assert all(b[i] < b[i + 1] for i in range(5))
+    assert set(SEGMENT_NAMES) == set(range(5))
+    table = {name: (off, size) for name, off, size, _ in built_lib.param_table(shape)}
+    assert b[1] == table['encoder/cbhg/bank_1/kernel'][0] and b[2] == table['encoder/cbhg/proj1/kernel'][0]
+    assert b[2] - b[1] == 136 * 128 * 128 + 16 * 128 + 2 * 16 * 128
+    assert b[4] == table['post/cbhg/bank_1/kernel'][0]
