@@ -74,7 +74,7 @@ struct Xc {
 __device__ __forceinline__ void tstamp(Xc& X) {
   if (kProbes3 && X.trace) {
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): attribute LDS time to the section that issued it
-    if (threadIdx.x == 0) X.trace[X.tslot] = clock64();
+    if (threadIdx.x == 0) X.trace[X.tslot] = (clock64() & 0x00ffffffffffffffll) | ((long long)(X.polls & 0xff) << 56);   // (+ wave 0's poll count so far)
     X.tslot++;
   }
 }

@@ -21,7 +21,8 @@ else:
 torch.cuda.synchronize()
 tab = {n: (o, s) for n, o, s, d in lib.workspace_table(m.shape, not infer)}
 o, s = tab['dec.err']
-tr = m.workspace[o + 16:o + 16 + 2 * 64].view(torch.int64).cpu().numpy()
+tr = m.workspace[o + 16:o + 16 + 2 * 64].view(torch.int64).cpu().numpy().copy()
+n_ = int(tr[63]); pol = [(int(x) >> 56) & 0xff for x in tr[:n_]]; tr[:n_] &= 0x00ffffffffffffff
 n = int(tr[63]); polls = int(tr[62]); print('poll iterations of the E gather (max over the traced workgroup, summed over launches):', int(tr[61]) & 0xffffffff)
 t = [(x - tr[0]) / 2400.0 for x in tr[:n]]      # shader clock ~2.4 GHz (reported in us at that nominal rate)
 names = ['G0', 'C0', 'G1', 'C1', 'G2', 'C2', 'OUT']
@@ -37,12 +38,13 @@ for nm in names:
 rest = t[i:]
 print('E / softmax stamps since the OUT barrier [energies published, p2 rider done, gathered, deferred stores + next-step loads issued, barrier, softmax + barrier]:', ['%.2f' % (x - t[i - 1]) for x in rest])
 print('sum over G0..OUT: compute %.2f gather %.2f barrier %.2f; whole step %.2f us' % (tot[0], tot[1], tot[2], t[n - 1]))
+print('poll-loop passes of wave 0 at each stamp (cumulative; a gather that hits on its first check adds 1):', pol)
 
 if not infer:
     m.backward()
     torch.cuda.synchronize()
-    tb = m.workspace[o + 16 + 256:o + 16 + 256 + 2 * 64].view(torch.int64).cpu().numpy()
-    nb = int(tb[63])
+    tb = m.workspace[o + 16 + 256:o + 16 + 256 + 2 * 64].view(torch.int64).cpu().numpy().copy()
+    nb = int(tb[63]); polb = [(int(x) >> 56) & 0xff for x in tb[:nb]]; tb[:nb] &= 0x00ffffffffffffff
     tt = [(x - tb[0]) / 2400.0 for x in tb[:nb]]
     names = ['inputs landed', 'FAN computed + published', 'FAN gathered + barrier', 'softmax backward + barrier', 'DQ energy backward', 'DQ dq + d p1 published',
              'DQ gathered', 'DQ stores + barrier', 'OUT computed + published', 'OUT gathered', 'OUT barrier']
@@ -52,3 +54,4 @@ if not infer:
     for i in range(1, nb):
         print('  %-36s %6.2f' % (names[i - 1] if i - 1 < len(names) else '?', tt[i] - tt[i - 1]))
     print('  whole step %.2f us' % tt[nb - 1])
+    print('  poll-loop passes of wave 0 at each stamp (cumulative):', polb)

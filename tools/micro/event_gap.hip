@@ -1,0 +1,84 @@
+// event_gap.hip -- what a cross-stream dependency costs the PRODUCING stream on gfx950 / ROCm 7.2.
+// A chain of N short kernels on stream A; between consecutive kernels one of:
+//   plain      nothing
+//   record     hipEventRecord(ev, A)                       (hipEventDisableTiming)              -- what side_fork / tn_route do
+//   nofence    the same, event created with hipEventDisableSystemFence
+//   todevice   the same, event created with hipEventReleaseToDevice
+//   extstop    no marker: the event rides on the kernel's own packet (hipExtLaunchKernelGGL stopEvent)
+//   *+wait     ... and stream B waits for the event and runs a short kernel (the realistic fork)
+//   joinold    A waits for an event recorded on B long ago (the realistic late join)
+// Prints the chain's wall time per kernel minus the kernel's own spin time.
+// build: hipcc --offload-arch=gfx950 -O3 tools/micro/event_gap.hip -o build/event_gap
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <cstdio>
+#include <vector>
+#include <chrono>
+
+__global__ void spin_kernel(long long ticks, float* out) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) { }
+  if (threadIdx.x == 0) out[blockIdx.x] = (float)t0;
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+int main() {
+  const int N = 40, REP = 5;
+  hipStream_t A, B;
+  CK(hipStreamCreateWithFlags(&A, hipStreamNonBlocking));
+  CK(hipStreamCreateWithFlags(&B, hipStreamNonBlocking));
+  float* out;
+  CK(hipMalloc(&out, 4096 * 4));
+  const long long ticks = 2000;   // wall_clock64 runs at 100 MHz: 20 us
+  const dim3 grid(256), block(256);
+  struct Case { const char* name; unsigned flags; int mode; bool wait; };   // mode 0 plain, 1 record, 2 ext stop event, 3 join old
+  const Case cases[] = {
+      {"plain", 0, 0, false},
+      {"record", hipEventDisableTiming, 1, false},
+      {"record+wait", hipEventDisableTiming, 1, true},
+      {"nofence", hipEventDisableTiming | hipEventDisableSystemFence, 1, false},
+      {"nofence+wait", hipEventDisableTiming | hipEventDisableSystemFence, 1, true},
+      {"todevice", hipEventDisableTiming | hipEventReleaseToDevice, 1, false},
+      {"todevice+wait", hipEventDisableTiming | hipEventReleaseToDevice, 1, true},
+      {"extstop", hipEventDisableTiming, 2, false},
+      {"extstop+wait", hipEventDisableTiming, 2, true},
+      {"extstop-nofence+wait", hipEventDisableTiming | hipEventDisableSystemFence, 2, true},
+      {"joinold", hipEventDisableTiming, 3, false},
+      {"joinold-nofence", hipEventDisableTiming | hipEventDisableSystemFence, 3, false},
+  };
+  for (const Case& c : cases) {
+    std::vector<hipEvent_t> ev(N);
+    for (auto& e : ev) CK(hipEventCreateWithFlags(&e, c.flags ? c.flags : hipEventDisableTiming));
+    double best = 1e30;
+    for (int rep = 0; rep < REP; ++rep) {
+      if (c.mode == 3) {   // events recorded on B up front, long done when A reaches its waits
+        for (int i = 0; i < N; ++i) {
+          hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, B, 10LL, out + 2048);
+          CK(hipEventRecord(ev[i], B));
+        }
+        CK(hipStreamSynchronize(B));
+      }
+      CK(hipDeviceSynchronize());
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int i = 0; i < N; ++i) {
+        if (c.mode == 3) CK(hipStreamWaitEvent(A, ev[i], 0));
+        if (c.mode == 2) hipExtLaunchKernelGGL(spin_kernel, grid, block, 0, A, nullptr, ev[i], 0, ticks, out);
+        else hipLaunchKernelGGL(spin_kernel, grid, block, 0, A, ticks, out);
+        if (c.mode == 1) CK(hipEventRecord(ev[i], A));
+        if (c.wait) {
+          CK(hipStreamWaitEvent(B, ev[i], 0));
+          hipLaunchKernelGGL(spin_kernel, dim3(8), dim3(64), 0, B, 200LL, out + 1024);
+        }
+      }
+      CK(hipStreamSynchronize(A));
+      const auto t1 = std::chrono::steady_clock::now();
+      CK(hipDeviceSynchronize());
+      const double us = std::chrono::duration<double, std::micro>(t1 - t0).count();
+      if (us < best) best = us;
+    }
+    printf("%-24s %7.2f us per kernel (spin 20.00)  -> overhead %6.2f us\n", c.name, best / N, best / N - 20.0);
+    for (auto& e : ev) (void)hipEventDestroy(e);
+  }
+  return 0;
+}
