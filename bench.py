@@ -380,7 +380,11 @@ def main():
         ab = {'gemm': ab_gemm(model),
               'weight_images': ab_env(model, 'TACO_GEMM2_BSPLIT', '1', '0', ('image_form', 'split_in_registers'),
                                       'S1 train step, ms: weight operand of the big NN GEMMs read from pre-split bf16 plane images (default, round 6) '
-                                      'vs split in registers in every wave (round 5), alternated in this run; results are bit-identical')}
+                                      'vs split in registers in every wave (round 5), alternated in this run; results are bit-identical'),
+              'tail_events': ab_env(model, 'TACO_TAIL_EVENTS', '1', '0', ('stop_event_on_the_launch', 'recorded_marker'),
+                                    'S1 train step, ms: cross-stream forks / joins wait for the stop event riding on the producing '
+                                    "stream's last launch (default, round 6 late) vs a recorded marker packet between two kernels of the "
+                                    'producing stream (rounds 1-6), alternated in this run; same kernels, same order')}
     del model
     torch.cuda.empty_cache()
 

@@ -332,7 +332,7 @@ int launch_bigru_fwd(const float* xg, const BiGruWeights& w, const float* h0, fl
   TACO_REQUIRE(B > 0 && T > 0, "bigru_fwd: bad dims");
   long long* trace = nullptr;
   const int pslot = taco_prof_begin(3, s);
-  hipLaunchKernelGGL(bigru_fwd_kernel, dim3(B, 2), dim3(NTG), 0, s, xg, w, h0, out, ruc, B, T, trace);
+  TACO_KLAUNCH(bigru_fwd_kernel, dim3(B, 2), dim3(NTG), 0, s, xg, w, h0, out, ruc, B, T, trace);
   taco_prof_end(3, pslot, s, 2.0 * B * T * 2 * (kCb * 2 * kCb + kCb * kCb));   // the h-side mat-vecs of both directions
   TACO_LAUNCH_CHECK("bigru_fwd");
   return TACO_OK;
@@ -349,7 +349,7 @@ int launch_bigru_bwd(const float* dout, const float* out, const float* ruc, cons
   const size_t pad = ensure_dyn_smem(once, reinterpret_cast<const void*>(bigru_bwd_kernel), want) ? want : (size_t)0;
   // (only while the recurrence leaves CUs free for those GEMMs: with more sequences it needs every CU slot itself)
   const int pslot = taco_prof_begin(3, s);
-  hipLaunchKernelGGL(bigru_bwd_kernel, dim3(B, 2), dim3(NTG), 2 * B <= 128 ? pad : 0, s, dout, out, ruc, w, h0, dxg, rh, dh0, B, T);
+  TACO_KLAUNCH(bigru_bwd_kernel, dim3(B, 2), dim3(NTG), 2 * B <= 128 ? pad : 0, s, dout, out, ruc, w, h0, dxg, rh, dh0, B, T);
   taco_prof_end(3, pslot, s, 2.0 * B * T * 2 * (kCb * 2 * kCb + kCb * kCb));
   TACO_LAUNCH_CHECK("bigru_bwd");
   return TACO_OK;

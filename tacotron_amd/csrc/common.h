@@ -1,6 +1,7 @@
 // common.h -- shared host/device helpers for libtaco_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -115,6 +116,31 @@ static inline bool ensure_dyn_smem(DynSmemOnce& done, const void* func, size_t b
   if (dev >= 0 && dev < 32) done.ok[dev] = true;
   return true;
 }
+
+// ---- tail events (layout.hip): cross-stream dependencies without marker packets --------------------------------------
+// A fork / join between two streams used to be hipEventRecord on the producing stream + hipStreamWaitEvent on the consuming one.
+// The record is a marker packet with a system-scope release BETWEEN two kernels of the producing stream: 7-12 us of bubble per
+// fork in the step's timeline (~17 of them on the critical path), 4.6 us with empty kernels in tools/micro/event_gap.hip
+// (profiles/r06_event_gap.txt: record + wait 6.5 us per kernel vs 1.9 plain; hipExtLaunchKernelGGL's stop event + wait 3.0).
+// While a TailScope is open (taco_forward / taco_backward / taco_infer; not while the stream is being captured), every launch
+// of the library carries a stop event of a per-stream ring on its OWN dispatch packet; "everything enqueued on s so far" is then
+// the event of the last kernel launched on s (streams are in order), and a fork / join waits for that -- no marker.  Whatever
+// else is enqueued on a stream (memset, event wait) "touches" it: its tail event no longer covers the stream and the next
+// fork falls back to a recorded event.  TACO_TAIL_EVENTS=0: recorded events everywhere (A/B runs).
+hipEvent_t taco_tail_take(hipStream_t s);      // the event the NEXT launch on s carries (nullptr: tracking is off)
+hipEvent_t taco_tail_event(hipStream_t s);     // the event of the LAST launch on s if it still covers the stream, else nullptr
+hipEvent_t taco_tail_steal(hipStream_t s, hipEvent_t give);   // tail event taken OUT of the ring (caller owns it; `give` refills the slot), or nullptr
+void taco_tail_touch(hipStream_t s);           // something that is not a library launch was enqueued on s
+void taco_tail_open(uint64_t key);              // opens the scope of one C-ABI call; key = kind + shape of the call (its launch plan, layout.hip)
+void taco_tail_close();
+bool taco_tail_wait(hipStream_t waiter, hipStream_t producer);   // waiter waits for producer's tail event; false: caller records an event
+
+#define TACO_KLAUNCH(kernel, grid, block, smem, stream, ...)                                                        \
+  do {                                                                                                              \
+    hipEvent_t tev__ = taco_tail_take(stream);                                                                      \
+    if (tev__) hipExtLaunchKernelGGL(kernel, grid, block, smem, stream, nullptr, tev__, 0, __VA_ARGS__);            \
+    else hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);                                        \
+  } while (0)
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1426,12 +1426,13 @@ int launch_decoder_fwd(DecFwdArgs a, hipStream_t s) {
   a.fakew = probe_bits();
   if (a.P > 1) {
     hipError_t e = hipMemsetAsync(a.xchg, 0, (size_t)decoder_xchg_bytes(a.B, a.Tt), s);
+    taco_tail_touch(s);
     if (e != hipSuccess) {
       taco_set_error("decoder_fwd: memset: %s", hipGetErrorString(e));
       return TACO_ELAUNCH;
     }
   }
-  hipLaunchKernelGGL(kern, dim3(a.B * a.P), dim3(NT), smem, s, a);
+  TACO_KLAUNCH(kern, dim3(a.B * a.P), dim3(NT), smem, s, a);
   TACO_LAUNCH_CHECK("decoder_fwd");
   return TACO_OK;
 }
@@ -1457,12 +1458,13 @@ int launch_decoder_bwd(DecBwdArgs a, hipStream_t s) {
   a.fakew = probe_bits();
   if (a.P > 1 && !a.xchg_zeroed) {
     hipError_t e = hipMemsetAsync(a.xchg, 0, (size_t)decoder_xchg_bytes(a.B, a.Tt), s);
+    taco_tail_touch(s);
     if (e != hipSuccess) {
       taco_set_error("decoder_bwd: memset: %s", hipGetErrorString(e));
       return TACO_ELAUNCH;
     }
   }
-  hipLaunchKernelGGL(kern, dim3(a.B * a.P), dim3(NT), smem, s, a);
+  TACO_KLAUNCH(kern, dim3(a.B * a.P), dim3(NT), smem, s, a);
   TACO_LAUNCH_CHECK("decoder_bwd");
   return TACO_OK;
 }

@@ -2279,12 +2279,13 @@ int launch3(DecFwdArgs& a, int ncl, hipStream_t s) {
   if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, NT, smem);
   if (e != hipSuccess || (int64_t)cus * per_cu < (int64_t)8 * P3) return TACO_ENOTFOUND;
   if (!a.xchg_zeroed) e = hipMemsetAsync(a.xchg, 0, (size_t)decoder_xchg_bytes(a.B, a.Tt), s);
+  taco_tail_touch(s);
   if (e != hipSuccess) {
     taco_set_error("decoder3_fwd: memset: %s", hipGetErrorString(e));
     return TACO_ELAUNCH;
   }
   (void)ncl;
-  hipLaunchKernelGGL(kern, dim3(8 * P3), dim3(NT), smem, s, a);
+  TACO_KLAUNCH(kern, dim3(8 * P3), dim3(NT), smem, s, a);
   TACO_LAUNCH_CHECK("decoder3_fwd");
   return TACO_OK;
 }
@@ -2310,11 +2311,12 @@ int launch3b(DecBwdArgs& a, hipStream_t s) {
   if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, NT, smem);
   if (e != hipSuccess || (int64_t)cus * per_cu < (int64_t)8 * P3) return TACO_ENOTFOUND;
   if (!a.xchg_zeroed) e = hipMemsetAsync(a.xchg, 0, (size_t)decoder_xchg_bytes(a.B, a.Tt), s);
+  taco_tail_touch(s);
   if (e != hipSuccess) {
     taco_set_error("decoder3_bwd: memset: %s", hipGetErrorString(e));
     return TACO_ELAUNCH;
   }
-  hipLaunchKernelGGL(kern, dim3(8 * P3), dim3(NT), smem, s, a);
+  TACO_KLAUNCH(kern, dim3(8 * P3), dim3(NT), smem, s, a);
   TACO_LAUNCH_CHECK("decoder3_bwd");
   return TACO_OK;
 }

@@ -591,7 +591,7 @@ __global__ void bernoulli_kernel(uint8_t* __restrict__ out, int64_t n, uint32_t 
 
 #define EW_LAUNCH(kernel, n_items, stream, ...)                                                        \
   do {                                                                                                 \
-    hipLaunchKernelGGL(kernel, dim3(grid_for(n_items)), dim3(kThreads), 0, stream, __VA_ARGS__);      \
+    TACO_KLAUNCH(kernel, dim3(grid_for(n_items)), dim3(kThreads), 0, stream, __VA_ARGS__);      \
     TACO_LAUNCH_CHECK(#kernel);                                                                        \
   } while (0)
 
@@ -605,13 +605,13 @@ int launch_embedding_bwd(const float* dout, const int32_t* ids, float* dtable, i
   int segs = taco_deterministic() ? 1 : (int)std::min<int64_t>(32, (rows + 255) / 256);
   if (segs < 1) segs = 1;
   const int64_t rps = (rows + segs - 1) / segs;
-  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(V, segs), dim3(256), 0, s, dout, ids, dtable, rows, V, width, rps);
+  TACO_KLAUNCH(embedding_bwd_kernel, dim3(V, segs), dim3(256), 0, s, dout, ids, dtable, rows, V, width, rps);
   TACO_LAUNCH_CHECK("embedding_bwd");
   return TACO_OK;
 }
 int launch_center_rows(const float* x, const int32_t* len, float* out, int B, int T, int C, hipStream_t s) {
   TACO_REQUIRE(C % 4 == 0, "center_rows: C %% 4 != 0");
-  hipLaunchKernelGGL(center_rows_kernel, dim3((C + 255) / 256, B, 4), dim3(256), 0, s, x, len, out, T, C);
+  TACO_KLAUNCH(center_rows_kernel, dim3((C + 255) / 256, B, 4), dim3(256), 0, s, x, len, out, T, C);
   TACO_LAUNCH_CHECK("center_rows");
   return TACO_OK;
 }
@@ -620,7 +620,7 @@ int launch_mask_pos(float* g, int ldg, const float* y, int ldy, int64_t rows, in
   return TACO_OK;
 }
 int launch_colsum_batched(const float* x, int ld, float* out, int B, int T, int N, hipStream_t s) {
-  hipLaunchKernelGGL(colsum_batched_kernel, dim3((N + 63) / 64, B), dim3(64, 4), 0, s, x, ld, out, T, N);
+  TACO_KLAUNCH(colsum_batched_kernel, dim3((N + 63) / 64, B), dim3(64, 4), 0, s, x, ld, out, T, N);
   TACO_LAUNCH_CHECK("colsum_batched");
   return TACO_OK;
 }
@@ -644,7 +644,7 @@ int launch_bn_maxpool_bwd(const float* x, const float* gamma, const float* beta,
   TACO_REQUIRE(C % 4 == 0, "bn_maxpool_bwd: C %% 4 != 0");
   col_grid((int64_t)B * T, C, grid, rpb);
   grid.x = (C / 4 + 63) / 64;
-  hipLaunchKernelGGL(bn_maxpool_bwd_kernel, grid, dim3(64, 4), 0, s, x, gamma, beta, dy, dx, dgamma, dbeta, B, T, C, rpb);
+  TACO_KLAUNCH(bn_maxpool_bwd_kernel, grid, dim3(64, 4), 0, s, x, gamma, beta, dy, dx, dgamma, dbeta, B, T, C, rpb);
   TACO_LAUNCH_CHECK("bn_maxpool_bwd");
   return TACO_OK;
 }
@@ -666,7 +666,7 @@ int launch_affine_act_bwd(const float* pre, const float* gamma, const float* dy,
   dim3 grid;
   int rpb;
   col_grid(M, N, grid, rpb);
-  hipLaunchKernelGGL(affine_act_bwd_kernel, grid, dim3(64, 4), 0, s, pre, gamma, dy, dz, dgamma, dbeta, M, N, act, rpb);
+  TACO_KLAUNCH(affine_act_bwd_kernel, grid, dim3(64, 4), 0, s, pre, gamma, dy, dz, dgamma, dbeta, M, N, act, rpb);
   TACO_LAUNCH_CHECK("affine_act_bwd");
   return TACO_OK;
 }
@@ -682,13 +682,13 @@ int launch_add(const float* a, const float* b, float* y, int64_t n, hipStream_t 
 int launch_l1(const float* a, const float* b, float* grad, int ldg, float* loss_parts, int64_t M, int N, hipStream_t s) {
   TACO_REQUIRE(ldg >= N, "l1: ldg < N");
   // exactly kLossParts blocks: block i leaves its partial in loss_parts[i] (blocks without work write 0)
-  hipLaunchKernelGGL(l1_kernel, dim3(kLossParts), dim3(1024), 0, s,   // 16 waves per workgroup: the kernel is latency bound, the partial count is fixed
+  TACO_KLAUNCH(l1_kernel, dim3(kLossParts), dim3(1024), 0, s,   // 16 waves per workgroup: the kernel is latency bound, the partial count is fixed
                      a, b, grad, ldg, loss_parts, M, N);
   TACO_LAUNCH_CHECK("l1");
   return TACO_OK;
 }
 int launch_finish_loss(float* loss, const float* parts, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(finish_loss_kernel, dim3(1), dim3(kThreads), 0, s, loss, parts, out);
+  TACO_KLAUNCH(finish_loss_kernel, dim3(1), dim3(kThreads), 0, s, loss, parts, out);
   TACO_LAUNCH_CHECK("finish_loss");
   return TACO_OK;
 }
@@ -699,7 +699,7 @@ int launch_transpose_batch(TransposeBatch& b, hipStream_t s) {
     b.j[i].tile0 = tiles;
     tiles += b.j[i].taps * ((b.j[i].N + 31) / 32) * ((b.j[i].K + 31) / 32);
   }
-  hipLaunchKernelGGL(transpose_batch_kernel, dim3(tiles), dim3(32, 8), 0, s, b);
+  TACO_KLAUNCH(transpose_batch_kernel, dim3(tiles), dim3(32, 8), 0, s, b);
   TACO_LAUNCH_CHECK("transpose_batch");
   return TACO_OK;
 }
@@ -707,7 +707,7 @@ int launch_denorm_unframe(const float* out, const float* mean, const float* stdv
                           int r, int C, hipStream_t s) {
   const int F = (Td / 4) * 4 * r;
   TACO_REQUIRE(F > 0, "denorm_unframe: Td=%d holds no whole chunk of 4 steps", Td);
-  hipLaunchKernelGGL(denorm_unframe_kernel, dim3((C + 31) / 32, (F + 31) / 32, B), dim3(32, 8), 0, s, out, mean, stdv, spec,
+  TACO_KLAUNCH(denorm_unframe_kernel, dim3((C + 31) / 32, (F + 31) / 32, B), dim3(32, 8), 0, s, out, mean, stdv, spec,
                      mag_t, Td, r, C, F);
   TACO_LAUNCH_CHECK("denorm_unframe");
   return TACO_OK;
@@ -715,7 +715,7 @@ int launch_denorm_unframe(const float* out, const float* mean, const float* stdv
 int launch_sumsq(const float* x, int64_t n, float* out, hipStream_t s) {
   TACO_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "sumsq: x must be 16-byte aligned");
   // one block per CU, one partial each
-  hipLaunchKernelGGL(sumsq_kernel, dim3(kSumsqParts), dim3(kThreads), 0, s, x, n, out);
+  TACO_KLAUNCH(sumsq_kernel, dim3(kSumsqParts), dim3(kThreads), 0, s, x, n, out);
   TACO_LAUNCH_CHECK("sumsq");
   return TACO_OK;
 }
@@ -723,7 +723,7 @@ int launch_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, fl
                      const float* sumsq, float* gnorm_out, const int32_t* err, hipStream_t s) {
   const double b1 = 0.9, b2 = 0.999;
   const double lr_t = (double)lr * sqrt(1.0 - pow(b2, (double)step)) / (1.0 - pow(b1, (double)step));
-  hipLaunchKernelGGL(clip_adam_kernel, dim3(grid_for(n, kThreads, 2048)), dim3(kThreads), 0, s, p, g, m, v, n,
+  TACO_KLAUNCH(clip_adam_kernel, dim3(grid_for(n, kThreads, 2048)), dim3(kThreads), 0, s, p, g, m, v, n,
                      (float)lr_t, cap, sumsq, gnorm_out, err);
   TACO_LAUNCH_CHECK("clip_adam");
   return TACO_OK;
@@ -731,7 +731,7 @@ int launch_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, fl
 int launch_bernoulli(uint8_t* out, int64_t n, float p_one, uint64_t seed, hipStream_t s) {
   double t = (double)p_one * 4294967296.0;
   uint32_t thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (t <= 0 ? 0u : (uint32_t)t);
-  hipLaunchKernelGGL(bernoulli_kernel, dim3(grid_for((n + 1) / 2)), dim3(kThreads), 0, s, out, n, thresh, seed);
+  TACO_KLAUNCH(bernoulli_kernel, dim3(grid_for((n + 1) / 2)), dim3(kThreads), 0, s, out, n, thresh, seed);
   TACO_LAUNCH_CHECK("bernoulli");
   return TACO_OK;
 }
@@ -761,7 +761,7 @@ int launch_spin(int blocks, int threads, int lds_bytes, int usec, hipStream_t s)
   int dev = 0;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, dev);
   if (rate_khz <= 0) rate_khz = 100000;
-  hipLaunchKernelGGL(spin_kernel, dim3(blocks), dim3(threads), (size_t)lds_bytes, s, (long long)usec * rate_khz / 1000, lds_bytes / 4);
+  TACO_KLAUNCH(spin_kernel, dim3(blocks), dim3(threads), (size_t)lds_bytes, s, (long long)usec * rate_khz / 1000, lds_bytes / 4);
   TACO_LAUNCH_CHECK("debug_spin");
   return TACO_OK;
 }
@@ -789,7 +789,7 @@ int launch_clock_probe(long long* out, int iters, hipStream_t s) {
   TACO_REQUIRE(out && iters > 0, "clock_probe: bad arguments");
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  hipLaunchKernelGGL(clock_probe_kernel, dim3(cus > 0 ? cus : 256), dim3(512), 0, s, out, iters, 0.999f, 0.001f);
+  TACO_KLAUNCH(clock_probe_kernel, dim3(cus > 0 ? cus : 256), dim3(512), 0, s, out, iters, 0.999f, 0.001f);
   TACO_LAUNCH_CHECK("clock_probe");
   return TACO_OK;
 }
@@ -892,7 +892,7 @@ __global__ __launch_bounds__(64) void fabric_probe_kernel(long long* out, fp_u64
 }
 int launch_fabric_probe(long long* out32, void* gran4k, const void* scratch, int64_t scratch_bytes, int iters, hipStream_t s) {
   TACO_REQUIRE(out32 && gran4k && scratch && scratch_bytes >= (32 << 20) && iters > 0, "fabric_probe: bad arguments");
-  hipLaunchKernelGGL(fabric_probe_kernel, dim3(64), dim3(64), 0, s, out32, reinterpret_cast<fp_u64*>(gran4k),
+  TACO_KLAUNCH(fabric_probe_kernel, dim3(64), dim3(64), 0, s, out32, reinterpret_cast<fp_u64*>(gran4k),
                      reinterpret_cast<const unsigned*>(scratch), (long long)(scratch_bytes / 4), iters);
   TACO_LAUNCH_CHECK("fabric_probe");
   return TACO_OK;
@@ -933,7 +933,7 @@ int launch_init_batch(InitBatch& b, hipStream_t s) {
     nb = nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
     blocks += (int)nb;
   }
-  hipLaunchKernelGGL(init_batch_kernel, dim3(blocks), dim3(256), 0, s, b);
+  TACO_KLAUNCH(init_batch_kernel, dim3(blocks), dim3(256), 0, s, b);
   TACO_LAUNCH_CHECK("init_batch");
   b.n = 0;
   return TACO_OK;

@@ -614,10 +614,10 @@ void conv_gemm_set_flags(ConvGemmProblem& p) {
 template <int WM, int WN>
 static void dispatch_nn(int flags, dim3 grid, hipStream_t s, ConvGemmBatch& batch) {
   switch (flags & 3) {
-    case 3: hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, true, true>), grid, dim3(256), 0, s, batch); break;
-    case 1: hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, true, false>), grid, dim3(256), 0, s, batch); break;
-    case 2: hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, false, true>), grid, dim3(256), 0, s, batch); break;
-    default: hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, false, false>), grid, dim3(256), 0, s, batch); break;
+    case 3: TACO_KLAUNCH((conv_gemm_kernel<WM, WN, true, true>), grid, dim3(256), 0, s, batch); break;
+    case 1: TACO_KLAUNCH((conv_gemm_kernel<WM, WN, true, false>), grid, dim3(256), 0, s, batch); break;
+    case 2: TACO_KLAUNCH((conv_gemm_kernel<WM, WN, false, true>), grid, dim3(256), 0, s, batch); break;
+    default: TACO_KLAUNCH((conv_gemm_kernel<WM, WN, false, false>), grid, dim3(256), 0, s, batch); break;
   }
 }
 
@@ -684,7 +684,7 @@ int launch_conv_gemm_slab_sum(const ConvGemmProblem& p, const float* slabs, int 
   TACO_REQUIRE(slabs && n >= 1 && p.M > 0 && p.N > 0 && p.N % 4 == 0 && p.C, "conv_gemm_slab_sum: bad arguments");
   const int64_t total4 = (int64_t)p.M * p.N / 4;
   const int grid = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
-  hipLaunchKernelGGL(conv_gemm_tapsum_kernel, dim3(grid), dim3(256), 0, stream, p, slabs, n);
+  TACO_KLAUNCH(conv_gemm_tapsum_kernel, dim3(grid), dim3(256), 0, stream, p, slabs, n);
   TACO_LAUNCH_CHECK("conv_gemm_slab_sum");
   return TACO_OK;
 }
@@ -735,7 +735,7 @@ int launch_conv_gemm_tapsplit(const ConvGemmProblem& p, float* slabs, int64_t sl
         if (rc == TACO_OK) {
           const int64_t total4 = mn / 4;
           const int grid = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
-          hipLaunchKernelGGL(conv_gemm_tapsum_kernel, dim3(grid), dim3(256), 0, stream, p, slabs, bestS);
+          TACO_KLAUNCH(conv_gemm_tapsum_kernel, dim3(grid), dim3(256), 0, stream, p, slabs, bestS);
           taco_prof_end(2, pslot, stream, 2.0 * p.M * p.N * p.K * p.taps);
           TACO_LAUNCH_CHECK("conv_gemm2 k-split");
           return TACO_OK;
@@ -763,7 +763,7 @@ int launch_conv_gemm_tapsplit(const ConvGemmProblem& p, float* slabs, int64_t sl
   TACO_TRY(launch_conv_gemm_batch(b, stream));
   const int64_t total4 = slab / 4;
   const int grid = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
-  hipLaunchKernelGGL(conv_gemm_tapsum_kernel, dim3(grid), dim3(256), 0, stream, p, slabs, p.taps);
+  TACO_KLAUNCH(conv_gemm_tapsum_kernel, dim3(grid), dim3(256), 0, stream, p, slabs, p.taps);
   TACO_LAUNCH_CHECK("conv_gemm_tapsum");
   return TACO_OK;
 }
@@ -780,12 +780,12 @@ static void dispatch_tn(int flags, dim3 grid, hipStream_t s, const GemmTnArgs& a
   switch (flags & 3) {
     case 3:
       // (bf16x3 only for row ranges inside the chain bound, bf16x3.h bf16x_max_chain: TACO_DETERMINISTIC=1's single-workgroup row ranges are not)
-      if (env_bf16x() && a.chunk <= bf16x_max_chain()) hipLaunchKernelGGL((gemm_tn_kernel<WM, WN, true, true, true>), grid, dim3(256), 0, s, a);
-      else hipLaunchKernelGGL((gemm_tn_kernel<WM, WN, true, true>), grid, dim3(256), 0, s, a);
+      if (env_bf16x() && a.chunk <= bf16x_max_chain()) TACO_KLAUNCH((gemm_tn_kernel<WM, WN, true, true, true>), grid, dim3(256), 0, s, a);
+      else TACO_KLAUNCH((gemm_tn_kernel<WM, WN, true, true>), grid, dim3(256), 0, s, a);
       break;
-    case 1: hipLaunchKernelGGL((gemm_tn_kernel<WM, WN, true, false>), grid, dim3(256), 0, s, a); break;
-    case 2: hipLaunchKernelGGL((gemm_tn_kernel<WM, WN, false, true>), grid, dim3(256), 0, s, a); break;
-    default: hipLaunchKernelGGL((gemm_tn_kernel<WM, WN, false, false>), grid, dim3(256), 0, s, a); break;
+    case 1: TACO_KLAUNCH((gemm_tn_kernel<WM, WN, true, false>), grid, dim3(256), 0, s, a); break;
+    case 2: TACO_KLAUNCH((gemm_tn_kernel<WM, WN, false, true>), grid, dim3(256), 0, s, a); break;
+    default: TACO_KLAUNCH((gemm_tn_kernel<WM, WN, false, false>), grid, dim3(256), 0, s, a); break;
   }
 }
 
@@ -938,8 +938,8 @@ int launch_gemm_tn_batch(GemmTnBatch& b, hipStream_t stream) {
                     grouped.p[0].taps);
     int max_chunk = 0;
     for (int i = 0; i < grouped.n; ++i) max_chunk = grouped.p[i].chunk > max_chunk ? grouped.p[i].chunk : max_chunk;
-    if (env_bf16x() && max_chunk <= bf16x_max_chain()) hipLaunchKernelGGL(gemm_tn_batch_kernel<true>, dim3(blocks), dim3(256), 0, stream, grouped);
-    else hipLaunchKernelGGL(gemm_tn_batch_kernel<false>, dim3(blocks), dim3(256), 0, stream, grouped);
+    if (env_bf16x() && max_chunk <= bf16x_max_chain()) TACO_KLAUNCH(gemm_tn_batch_kernel<true>, dim3(blocks), dim3(256), 0, stream, grouped);
+    else TACO_KLAUNCH(gemm_tn_batch_kernel<false>, dim3(blocks), dim3(256), 0, stream, grouped);
     taco_prof_end(2, pslot, stream, flops);
     TACO_LAUNCH_CHECK("gemm_tn_batch");
   }
@@ -949,7 +949,7 @@ int launch_gemm_tn_batch(GemmTnBatch& b, hipStream_t stream) {
 
 int launch_gemm_naive(const ConvGemmProblem& p, hipStream_t stream) {
   const int64_t n = (int64_t)p.M * p.N;
-  hipLaunchKernelGGL(gemm_naive_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, p);
+  TACO_KLAUNCH(gemm_naive_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, p);
   TACO_LAUNCH_CHECK("gemm_naive");
   return TACO_OK;
 }

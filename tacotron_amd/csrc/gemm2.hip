@@ -970,7 +970,7 @@ int launch_variant(const Gemm2Args& g, int tiles, hipStream_t s) {
   static DynSmemOnce once;
   TACO_REQUIRE(ensure_dyn_smem(once, reinterpret_cast<const void*>(conv_gemm2_kernel<BK, NS, BX>), smem),
                "conv_gemm2: cannot reserve %zu bytes of LDS", smem);
-  hipLaunchKernelGGL((conv_gemm2_kernel<BK, NS, BX>), dim3(tiles), dim3(256), smem, s, g);
+  TACO_KLAUNCH((conv_gemm2_kernel<BK, NS, BX>), dim3(tiles), dim3(256), smem, s, g);
   return TACO_OK;
 }
 
@@ -1051,7 +1051,7 @@ int weight_images_build(hipStream_t s) {
     j.first = blocks;
     blocks += cdiv(j.N, 128) * j.taps * j.kt;
   }
-  hipLaunchKernelGGL(weight_image_kernel, dim3(blocks), dim3(256), 0, s, g_wimg_q);
+  TACO_KLAUNCH(weight_image_kernel, dim3(blocks), dim3(256), 0, s, g_wimg_q);
   TACO_LAUNCH_CHECK("weight_image_kernel");
   g_wimg_q.n = 0;
   return TACO_OK;
@@ -1309,6 +1309,6 @@ int launch_gemm_tn2(const GemmTnArgs* probs, int n, hipStream_t stream) {
     g.first[i] = blocks;
     blocks += nb;
   }
-  hipLaunchKernelGGL(gemm_tn2_kernel, dim3(blocks), dim3(256), 2 * 2 * 32 * 128 * sizeof(float), stream, g);
+  TACO_KLAUNCH(gemm_tn2_kernel, dim3(blocks), dim3(256), 2 * 2 * 32 * 128 * sizeof(float), stream, g);
   return TACO_OK;
 }

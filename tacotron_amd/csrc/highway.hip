@@ -313,8 +313,8 @@ int launch_highway_stack_bwd(const HighwayStackBwdArgs& a, hipStream_t s) {
                "highway_stack_bwd: cannot reserve %zu bytes of LDS", kHwBwdSmem);
   const int pslot = taco_prof_begin(2, s);
   taco_prof_label(2, pslot, "highway-bwd M=%d nl=%d%s", a.M, a.nl, ad ? " +adapters" : "");
-  if (ad) hipLaunchKernelGGL(highway_stack_bwd_kernel<true>, dim3(cdiv(a.M, HB)), dim3(256), kHwBwdSmem, s, a);
-  else hipLaunchKernelGGL(highway_stack_bwd_kernel<false>, dim3(cdiv(a.M, HB)), dim3(256), kHwBwdSmem, s, a);
+  if (ad) TACO_KLAUNCH(highway_stack_bwd_kernel<true>, dim3(cdiv(a.M, HB)), dim3(256), kHwBwdSmem, s, a);
+  else TACO_KLAUNCH(highway_stack_bwd_kernel<false>, dim3(cdiv(a.M, HB)), dim3(256), kHwBwdSmem, s, a);
   taco_prof_end(2, pslot, s, 2.0 * a.M * HC * (ad ? 3 : 2) * HC * a.nl);
   TACO_LAUNCH_CHECK("highway_stack_bwd");
   return TACO_OK;
@@ -328,8 +328,8 @@ int launch_highway_stack_fwd(const HighwayStackArgs& a, hipStream_t s) {
                "highway_stack_fwd: the adapter form needs wa / rowb / hx of all four layers and the sequence length");
   const int pslot = taco_prof_begin(2, s);
   taco_prof_label(2, pslot, "highway-fwd M=%d nl=%d%s", a.M, a.nl, ad ? " +adapters" : "");
-  if (ad) hipLaunchKernelGGL(highway_stack_fwd_kernel<true>, dim3(cdiv(a.M, HB)), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(highway_stack_fwd_kernel<false>, dim3(cdiv(a.M, HB)), dim3(256), 0, s, a);
+  if (ad) TACO_KLAUNCH(highway_stack_fwd_kernel<true>, dim3(cdiv(a.M, HB)), dim3(256), 0, s, a);
+  else TACO_KLAUNCH(highway_stack_fwd_kernel<false>, dim3(cdiv(a.M, HB)), dim3(256), 0, s, a);
   taco_prof_end(2, pslot, s, 2.0 * a.M * HC * (ad ? 3 : 2) * HC * a.nl);
   TACO_LAUNCH_CHECK("highway_stack_fwd");
   return TACO_OK;

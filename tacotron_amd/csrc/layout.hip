@@ -13,6 +13,154 @@ void taco_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* taco_last_error_string(void) { return g_err; }
+
+// ---- tail events (common.h) ----
+namespace {
+constexpr int kTailRing = 64, kTailStreams = 8, kPlanWords = 8, kPlans = 8;   // (a plan covers 64 * kPlanWords launches per stream)
+struct TailTrack {
+  bool used = false;
+  hipStream_t s = nullptr;
+  hipEvent_t ring[kTailRing] = {};
+  int next = 0;
+  int tail_slot = -1;          // ring slot that still owns `tail` (-1: stolen, or no tail)
+  hipEvent_t tail = nullptr;   // rides on the last launch on s; nullptr once anything else was enqueued behind it
+  int launches = 0;            // launches on s in this scope
+  int tail_idx = -1;           // launch index of `tail`
+  bool declined = false;       // the last launch on s carried no event because the plan did not ask for one
+};
+// Which launches of a call need an event is learned, not declared: the first call of a kind / shape puts an event on EVERY launch
+// and notes the (stream, launch index) pairs a fork, join or segment actually consumed; later calls put events on those only
+// (an event on all ~90 launches of a step costs what the ~17 markers it replaces cost: measured, profiles/r06_tail_events_ab.txt).
+// A fork that finds no event because the plan declined it falls back to a recorded marker -- always correct -- and the plan is
+// learned again by the next call.
+struct TailPlan {
+  bool used = false, learned = false;
+  uint64_t key = 0;
+  uint64_t bits[kTailStreams][kPlanWords] = {};
+};
+thread_local TailTrack g_tail[kTailStreams];
+thread_local TailPlan g_plans[kPlans];
+thread_local TailPlan* g_plan = nullptr;
+thread_local int g_plan_next = 0;
+thread_local bool g_tail_on = false, g_learning = false;
+TailTrack* tail_find(hipStream_t s, bool create) {
+  for (TailTrack& t : g_tail)
+    if (t.used && t.s == s) return &t;
+  if (create)
+    for (TailTrack& t : g_tail)
+      if (!t.used) {
+        t.used = true;
+        t.s = s;
+        return &t;
+      }
+  return nullptr;
+}
+void tail_consumed(TailTrack* t) {
+  if (g_learning && g_plan && t->tail_idx >= 0 && t->tail_idx < 64 * kPlanWords)
+    g_plan->bits[t - g_tail][t->tail_idx >> 6] |= 1ull << (t->tail_idx & 63);
+}
+}  // namespace
+
+hipEvent_t taco_tail_take(hipStream_t s) {
+  if (!g_tail_on) return nullptr;
+  TailTrack* t = tail_find(s, true);
+  if (!t) return nullptr;   // (more streams than the table holds: those launch plainly and fork through recorded events)
+  const int idx = t->launches++;
+  const bool want = g_learning || (g_plan && idx < 64 * kPlanWords && ((g_plan->bits[t - g_tail][idx >> 6] >> (idx & 63)) & 1));
+  if (!want) {
+    t->tail = nullptr;
+    t->tail_slot = -1;
+    t->declined = true;
+    return nullptr;
+  }
+  const int slot = t->next;
+  t->next = (slot + 1) % kTailRing;
+  t->declined = false;
+  if (!t->ring[slot] && hipEventCreateWithFlags(&t->ring[slot], hipEventDisableTiming) != hipSuccess) {
+    t->ring[slot] = nullptr;
+    t->tail = nullptr;
+    t->tail_slot = -1;
+    return nullptr;
+  }
+  t->tail = t->ring[slot];
+  t->tail_slot = slot;
+  t->tail_idx = idx;
+  return t->tail;
+}
+hipEvent_t taco_tail_event(hipStream_t s) {
+  if (!g_tail_on) return nullptr;
+  TailTrack* t = tail_find(s, false);
+  if (!t) return nullptr;
+  if (t->tail) tail_consumed(t);
+  else if (t->declined && g_plan && !g_learning) g_plan->learned = false;   // (mispredicted: this call falls back, the next one learns)
+  return t->tail;
+}
+hipEvent_t taco_tail_steal(hipStream_t s, hipEvent_t give) {
+  hipEvent_t e = taco_tail_event(s);
+  if (!e) return nullptr;
+  TailTrack* t = tail_find(s, false);
+  if (t->tail_slot < 0 || t->ring[t->tail_slot] != e) return nullptr;   // (already stolen: the caller records its own event)
+  t->ring[t->tail_slot] = give;   // (an event lives in exactly one place: a ring slot or its new owner)
+  t->tail_slot = -1;
+  return e;
+}
+void taco_tail_touch(hipStream_t s) {
+  TailTrack* t = tail_find(s, false);
+  if (t) {
+    t->tail = nullptr;
+    t->tail_slot = -1;
+    t->declined = false;
+  }
+}
+void taco_tail_open(uint64_t key) {
+  const char* e = getenv("TACO_TAIL_EVENTS");
+  g_tail_on = !(e && atoi(e) == 0);
+  g_plan = nullptr;
+  g_learning = false;
+  for (TailTrack& t : g_tail) {
+    t.tail = nullptr;
+    t.tail_slot = -1;
+    t.launches = 0;
+    t.tail_idx = -1;
+    t.declined = false;
+  }
+  if (!g_tail_on) return;
+  for (TailPlan& p : g_plans)
+    if (p.used && p.key == key) g_plan = &p;
+  if (!g_plan) {
+    g_plan = &g_plans[g_plan_next];
+    g_plan_next = (g_plan_next + 1) % kPlans;
+    *g_plan = TailPlan();
+    g_plan->used = true;
+    g_plan->key = key;
+  }
+  if (!g_plan->learned || (e && atoi(e) == 2)) {   // (TACO_TAIL_EVENTS=2: an event on every launch, always)
+    g_learning = true;
+    for (auto& row : g_plan->bits)
+      for (uint64_t& w : row) w = 0;
+  }
+}
+void taco_tail_close() {
+  if (g_tail_on && g_learning && g_plan) g_plan->learned = true;
+  g_tail_on = false;
+  g_learning = false;
+  g_plan = nullptr;
+  for (TailTrack& t : g_tail) {
+    t.tail = nullptr;
+    t.tail_slot = -1;
+  }
+}
+bool taco_tail_wait(hipStream_t waiter, hipStream_t producer) {
+  hipEvent_t e = taco_tail_event(producer);
+  if (!e) return false;
+  if (hipStreamWaitEvent(waiter, e, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  taco_tail_touch(waiter);   // (the wait itself is not covered by the waiter's last launch)
+  return true;
+}
+
 extern "C" int taco_version(void) { return TACO_VERSION; }
 
 int validate_shape(const TacoShape* s) {

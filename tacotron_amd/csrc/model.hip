@@ -340,7 +340,11 @@ int record_segment(int seg, hipStream_t on) {
     taco_set_error("taco_backward: cannot create the gradient-segment event");
     return TACO_ELAUNCH;
   }
-  if (hipEventRecord(x.ev_seg[seg], on) != hipSuccess) {
+  // (tail events, common.h: the segment's event is the one riding on the last launch on `on` -- taken out of that stream's ring,
+  //  this segment's previous event refills the slot -- instead of a marker behind it)
+  if (hipEvent_t t = taco_tail_steal(on, x.ev_seg[seg])) {
+    x.ev_seg[seg] = t;
+  } else if (hipEventRecord(x.ev_seg[seg], on) != hipSuccess) {
     taco_set_error("taco_backward: hipEventRecord(segment %d) failed", seg);
     return TACO_ELAUNCH;
   }
@@ -352,16 +356,20 @@ hipStream_t side_fork(hipStream_t s) {
   // (profile bit 4: everything on the caller's stream, so that the per-launch event timing of the GEMM family measures each
   //  kernel by itself instead of two streams' kernels sharing the chip)
   if (x.off || (g_prof_mask & 16)) return s;
+  if (taco_tail_wait(x.side, s)) return x.side;
   if (hipEventRecord(x.ev_fork, s) != hipSuccess || hipStreamWaitEvent(x.side, x.ev_fork, 0) != hipSuccess) return s;
+  taco_tail_touch(x.side);
   return x.side;
 }
 int side_join(hipStream_t s, hipStream_t side) {
   if (side == s) return TACO_OK;
   SideStream& x = side_stream();
+  if (taco_tail_wait(s, side)) return TACO_OK;
   if (hipEventRecord(x.ev_join, side) != hipSuccess || hipStreamWaitEvent(s, x.ev_join, 0) != hipSuccess) {
     taco_set_error("side_join: event record/wait failed");
     return TACO_ELAUNCH;
   }
+  taco_tail_touch(s);
   return TACO_OK;
 }
 
@@ -474,6 +482,22 @@ static int register_weight_images(const Layouts& L, const WsLayout& W, const flo
   return rc;
 }
 
+// Tail events (common.h) are tracked while one of these is alive: the C-ABI calls that fork / join streams.  Not while the
+// caller's stream is being captured into a graph (a stop event on a captured launch is not a graph dependency).
+struct TailScope {
+  bool open = false;
+  TailScope(hipStream_t s, int kind, const TacoShape& sh) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return;
+    uint64_t key = 1469598103934665603ull;   // (FNV-1a over the call's kind and shape)
+    const int64_t f[8] = {kind, sh.B, sh.Tt, sh.Td, sh.r, sh.V, sh.S, (int64_t)(uintptr_t)s};
+    for (int64_t v : f) key = (key ^ (uint64_t)v) * 1099511628211ull;
+    taco_tail_open(key);
+    open = true;
+  }
+  ~TailScope() { if (open) taco_tail_close(); }
+};
+
 // encoder + attention memory + decoder + post-net; shared by train and inference forward.
 int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const float* P, const int32_t* text,
                  const int32_t* text_length, const int32_t* speaker, const float* mel, const uint8_t* ek1, const uint8_t* ek2, const uint8_t* dk1,
@@ -490,11 +514,19 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
   TACO_TRY(register_weight_images(L, W, P, ws, train, 0, true));
   TACO_TRY(weight_images_build(sd));
   bool img_event = false;
+  hipEvent_t img_ev = nullptr;
   if (sd != s) {
     SideStream& x = side_stream();
-    if (!x.ev_img && hipEventCreateWithFlags(&x.ev_img, hipEventDisableTiming) != hipSuccess) x.ev_img = nullptr;
-    if (x.ev_img && hipEventRecord(x.ev_img, sd) == hipSuccess) img_event = true;
-    else TACO_TRY(side_join(s, sd));   // (no event: fall back to a full join here)
+    // (tail events: the image launch's own event.  Its ring slot comes round again after 64 more launches on the side stream --
+    //  far more than are enqueued before the wait below -- and would then name a LATER launch of the same stream: still correct)
+    img_ev = taco_tail_event(sd);
+    if (img_ev) {
+      img_event = true;
+    } else {
+      if (!x.ev_img && hipEventCreateWithFlags(&x.ev_img, hipEventDisableTiming) != hipSuccess) x.ev_img = nullptr;
+      if (x.ev_img && hipEventRecord(x.ev_img, sd) == hipSuccess) img_event = true, img_ev = x.ev_img;
+      else TACO_TRY(side_join(s, sd));   // (no event: fall back to a full join here)
+    }
   }
   // ONE batched init launch for everything that is a plain copy / zero pad of parameters (side stream, first thing on it):
   //   post/dense (256, 1025) kernel -> pitch 1028 so the W tile loads are 16-byte aligned float4 (pad columns are never stored);
@@ -568,9 +600,12 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
     TACO_TRY(launch_embedding(P + PL.spk_embed, speaker, ws + W.spk_e, B, sh.S, s, 16));
     eb.spk_e = ws + W.spk_e;
   }
-  if (img_event && hipStreamWaitEvent(s, side_stream().ev_img, 0) != hipSuccess) {
-    taco_set_error("forward: cannot wait for the weight images");
-    return TACO_ELAUNCH;
+  if (img_event) {
+    if (hipStreamWaitEvent(s, img_ev, 0) != hipSuccess) {
+      taco_set_error("forward: cannot wait for the weight images");
+      return TACO_ELAUNCH;
+    }
+    taco_tail_touch(s);
   }
   TACO_TRY(cbhg_fwd(P, PL.enc, ws + W.p2, B, Tt, eb, train, s));
   // attention memory (BahdanauAttention.__init__; tacotron.py:48-52)
@@ -683,10 +718,15 @@ int tn_route(hipStream_t s, hipStream_t* out) {
     taco_set_error("weight-gradient side stream: cannot create an event");
     return TACO_ELAUNCH;
   }
+  if (taco_tail_wait(g_tn_side, s)) {
+    *out = g_tn_side;
+    return TACO_OK;
+  }
   if (hipEventRecord(g_tn_ev, s) != hipSuccess || hipStreamWaitEvent(g_tn_side, g_tn_ev, 0) != hipSuccess) {
     taco_set_error("weight-gradient side stream: event record/wait failed");
     return TACO_ELAUNCH;
   }
+  taco_tail_touch(g_tn_side);
   *out = g_tn_side;
   return TACO_OK;
 }
@@ -864,6 +904,7 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
     TACO_TRY(launch_add(w.dh0, w.dh0 + (int64_t)B * kCb, w.dsm2[4], (int64_t)B * kCb, s));
   } else if (c.spk) {
     hipError_t e = hipMemsetAsync(w.dspk_e, 0, (size_t)B * 16 * sizeof(float), s);
+    taco_tail_touch(s);
     if (e != hipSuccess) {
       taco_set_error("cbhg_bwd: memset: %s", hipGetErrorString(e));
       return TACO_ELAUNCH;
@@ -1044,6 +1085,7 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
   {
     if (!sc.dx_zeroed) {
       hipError_t e = hipMemsetAsync(dx_out, 0, (size_t)M * c.cin * sizeof(float), s);
+      taco_tail_touch(s);
       if (e != hipSuccess) {
         taco_set_error("cbhg_bwd: memset: %s", hipGetErrorString(e));
         return TACO_ELAUNCH;
@@ -1175,6 +1217,7 @@ extern "C" int taco_forward(const TacoShape* shape, const float* params, const i
   const WsLayout& W = L.Wtrain;
   float* ws = static_cast<float*>(workspace);
   hipStream_t s = as_stream(stream);
+  TailScope tails(s, 0, *shape);
   TACO_TRY(forward_impl(*shape, L, W, params, text, text_length, speaker, mel, enc_keep1, enc_keep2, dec_keep1, dec_keep2, sample,
                         seq2seq_output, output, alignments, ws, true, s));
   // add_loss_op (tacotron.py:156-165) + sign gradients for the backward pass
@@ -1192,6 +1235,7 @@ extern "C" int taco_infer(const TacoShape* shape, const float* params, const int
   TACO_REQUIRE(params && text && text_length && seq2seq_output && output && alignments && workspace,
                "taco_infer: null pointer argument");
   const Layouts& L = layouts_for(*shape);
+  TailScope tails(as_stream(stream), 1, *shape);
   return forward_impl(*shape, L, L.Winfer, params, text, text_length, speaker, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                       seq2seq_output, output, alignments, static_cast<float*>(workspace), false, as_stream(stream));
 }
@@ -1217,6 +1261,7 @@ extern "C" int taco_backward(const TacoShape* shape, const float* params, const 
   float* PT = ws + W.paramsT;
 
   g_tn_side = nullptr;
+  TailScope tails(s, 2, *shape);
   // the weight-image table of this call (the images themselves were built by the taco_forward that ran on this workspace)
   weight_images_clear();
   TACO_TRY(register_weight_images(L, W, P, ws, true, 0, false));

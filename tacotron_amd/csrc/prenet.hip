@@ -246,7 +246,7 @@ int launch_mlp2(const PrenetArgs& a, hipStream_t s, const char* what) {
                "%s: cannot reserve %zu bytes of LDS", what, smem);
   const int pslot = taco_prof_begin(2, s);
   taco_prof_label(2, pslot, "%s M=%d", what, a.M);
-  hipLaunchKernelGGL((mlp2_kernel<K1, N1, N2, BWD>), dim3(cdiv(a.M, PB)), dim3(256), smem, s, a);
+  TACO_KLAUNCH((mlp2_kernel<K1, N1, N2, BWD>), dim3(cdiv(a.M, PB)), dim3(256), smem, s, a);
   taco_prof_end(2, pslot, s, 2.0 * a.M * ((double)K1 * N1 + (double)N1 * N2));
   return TACO_OK;
 }

@@ -189,16 +189,16 @@ int launch_griffinlim(const float* mag_t, const float* phase0, float* wave, floa
   float* seg = ang + (int64_t)B * F * NBIN * 2;
   float* wss = seg + (int64_t)B * F * WIN;
   const int n = NFFT + HOP * (F - 1);
-  hipLaunchKernelGGL(gl_wss_kernel, dim3((n + 255) / 256), dim3(256), 0, s, wss, F);
+  TACO_KLAUNCH(gl_wss_kernel, dim3((n + 255) / 256), dim3(256), 0, s, wss, F);
   const int64_t total = (int64_t)B * F * NBIN;
-  hipLaunchKernelGGL(gl_init_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, s, phase0, ang, F,
+  TACO_KLAUNCH(gl_init_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, s, phase0, ang, F,
                      total);
   for (int it = 0; it < n_iter; ++it) {
-    hipLaunchKernelGGL(gl_synth_kernel, dim3(F, B), dim3(FT), 0, s, mag_t, ang, seg, F);
-    hipLaunchKernelGGL(gl_anal_kernel, dim3(F, B), dim3(FT), 0, s, seg, wss, ang, F);
+    TACO_KLAUNCH(gl_synth_kernel, dim3(F, B), dim3(FT), 0, s, mag_t, ang, seg, F);
+    TACO_KLAUNCH(gl_anal_kernel, dim3(F, B), dim3(FT), 0, s, seg, wss, ang, F);
   }
-  hipLaunchKernelGGL(gl_synth_kernel, dim3(F, B), dim3(FT), 0, s, mag_t, ang, seg, F);
-  hipLaunchKernelGGL(gl_wave_kernel, dim3((HOP * (F - 1) + 255) / 256, B), dim3(256), 0, s, seg, wss, wave, F);
+  TACO_KLAUNCH(gl_synth_kernel, dim3(F, B), dim3(FT), 0, s, mag_t, ang, seg, F);
+  TACO_KLAUNCH(gl_wave_kernel, dim3((HOP * (F - 1) + 255) / 256, B), dim3(256), 0, s, seg, wss, wave, F);
   TACO_LAUNCH_CHECK("griffinlim");
   return TACO_OK;
 }
