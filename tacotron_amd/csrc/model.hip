@@ -916,7 +916,16 @@ int cbhg_bwd(const float* P, const float* PT, float* G, const CbhgP& c, const Cb
   }
   float* gh = sc.gE;     // (M,128) gradient wrt current highway output
   float* gh2 = sc.gF;    // ping-pong
-  TACO_TRY(launch_conv_gemm(dense_problem(dxg, 6 * kCb, PT + t.gru_x, kCb, nullptr, gh, kCb, M, kCb, 6 * kCb, TACO_ACT_NONE), s));
+  {
+    // d h4 = dxg . Wx^T: (M, 768) x (768, 128) is 50 / 90 tiles of 128 x 128 -- too few for the DMA kernel, and as 64 x 64 tiles of the
+    // small kernel one wave of workgroups that each walk all 768 k (37 / 49 us on an idle chip, 55-105 us beside the weight
+    // gradients).  Cut along k instead (launch_conv_gemm_tapsplit: S grouped chunks + ordered slab sum; the slab area is free until
+    // the bank gather at the end of this pass).  TACO_XPROJ_BWD_KSPLIT=0: one launch, as in rounds 1-6.
+    const ConvGemmProblem q = dense_problem(dxg, 6 * kCb, PT + t.gru_x, kCb, nullptr, gh, kCb, M, kCb, 6 * kCb, TACO_ACT_NONE);
+    const char* e = getenv("TACO_XPROJ_BWD_KSPLIT");
+    if (w.tapsplit && !(e && atoi(e) == 0) && !taco_deterministic()) TACO_TRY(launch_conv_gemm_tapsplit(q, w.tapsplit, w.tapsplit_floats, s));
+    else TACO_TRY(launch_conv_gemm(q, s));
+  }
   // ---- highway layers 3..0 (with their input adapters / speaker sites) ----
   // d[T|H] of every layer gets its own (M,256) slice of gA (free until dpool below), so the T / H weight gradients of all
   // four layers can wait for ONE grouped launch after the loop; only adapter layers, whose operands live in the ping-pong

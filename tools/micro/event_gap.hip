@@ -23,7 +23,46 @@ __global__ void spin_kernel(long long ticks, float* out) {
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
+__global__ void stamp_kernel(long long ticks, long long* out) {   // out[0] = start, out[1] = end (100 MHz wall clock)
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) { }
+  if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = t0; out[1] = wall_clock64(); }
+}
+
+// Does a stream that waits for a stop event (never passed to hipEventRecord) really wait?  A (2 ms) on s1 carries e; s2 waits
+// for e and runs B.  Then the event is re-used by a second launch A2 (4 ms) on s1 BEFORE B can have started: B must still start
+// behind A (the wait captured A's command) -- behind A2 as well would be correct but later than necessary.
+static int dependency_check(hipStream_t s1, hipStream_t s2) {
+  long long* st;
+  if (hipMalloc(&st, 6 * sizeof(long long)) != hipSuccess) return 1;
+  hipEvent_t e;
+  if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return 1;
+  int bad = 0;
+  for (int rep = 0; rep < 3; ++rep) {
+    (void)hipMemset(st, 0, 6 * sizeof(long long));
+    hipExtLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, s1, nullptr, e, 0, 200000LL, st);        // A: 2 ms
+    if (hipStreamWaitEvent(s2, e, 0) != hipSuccess) return 1;
+    hipExtLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, s1, nullptr, e, 0, 400000LL, st + 2);    // A2: 4 ms, same event
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, s2, 10LL, st + 4);                           // B
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    long long h[6];
+    (void)hipMemcpy(h, st, sizeof(h), hipMemcpyDeviceToHost);
+    const double a_end = h[1] / 100.0, a2_end = h[3] / 100.0, b_start = h[4] / 100.0, a_start = h[0] / 100.0;
+    printf("dependency check %d: A ends at %.1f us, B starts at %.1f us, A2 ends at %.1f us (since A's start) -> %s\n", rep, a_end - a_start,
+           b_start - a_start, a2_end - a_start,
+           b_start >= a_end ? (b_start < a2_end ? "B waited for A (not for A2): OK" : "B waited for A2 as well: correct, late") : "B DID NOT WAIT");
+    if (b_start < a_end) bad = 1;
+  }
+  return bad;
+}
+
 int main() {
+  {
+    hipStream_t q1, q2;
+    CK(hipStreamCreateWithFlags(&q1, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&q2, hipStreamNonBlocking));
+    if (dependency_check(q1, q2)) { printf("DEPENDENCY CHECK FAILED\n"); return 2; }
+  }
   const int N = 40, REP = 5;
   hipStream_t A, B;
   CK(hipStreamCreateWithFlags(&A, hipStreamNonBlocking));
