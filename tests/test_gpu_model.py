@@ -515,18 +515,69 @@ def test_pooled_bank_epilogue_tile_edges(built_lib, B, Tt, Td, monkeypatch):
 
 
 @pytest.mark.parametrize('knob', ['TACO_NO_BANK_GATHER=1', 'TACO_GEMM2_XCD=0', 'TACO_GEMM2_BF16X=0', 'TACO_DEC_NO_LRES=1',
-                                  'TACO_TN_XCD=0', 'TACO_GEMM2_BANK_XCD=0', 'TACO_GEMM2_BSPLIT=0', 'TACO_TN_MERGE_TAPS=0'])
+                                  'TACO_TN_XCD=0', 'TACO_GEMM2_BANK_XCD=0', 'TACO_GEMM2_BSPLIT=0', 'TACO_TN_MERGE_TAPS=0',
+                                  'TACO_TAIL_EVENTS=0', 'TACO_TAIL_EVENTS=2', 'TACO_XPROJ_BWD_KSPLIT=0'])
 def test_medium_shape_with_optional_paths(built_lib, knob, monkeypatch):
     """The fallback / A-B switches of the train step keep parity: the conv bank's input gradient as K atomic-accumulating problems
     (TACO_NO_BANK_GATHER=1: the path taken when the slabs do not fit or the kernels are not contiguous), gemm2's plain tile order
     (TACO_GEMM2_XCD=0), the fp32 MFMA form of the big GEMMs (TACO_GEMM2_BF16X=0, rounds 2-4), the decoder kernels without
     launch-resident weight rows in LDS (TACO_DEC_NO_LRES=1), the weight-gradient kernels' and the conv banks' plain block orders
     (TACO_TN_XCD=0, TACO_GEMM2_BANK_XCD=0: round 5's XCD-aware orders off) and the weight operand split in registers instead of
-    read from the pre-split plane images (TACO_GEMM2_BSPLIT=0, round 6)."""
+    read from the pre-split plane images (TACO_GEMM2_BSPLIT=0, round 6); cross-stream forks / joins through recorded marker packets
+    (TACO_TAIL_EVENTS=0, rounds 1-6) or with a stop event on every launch (=2, the learning call's form) instead of the learned
+    launch plan; the bi-GRU x-projection's input gradient as one launch (TACO_XPROJ_BWD_KSPLIT=0)."""
     k, v = knob.split('=')
     monkeypatch.setenv(k, v)
     test_medium_shape_forward_backward(built_lib)
     test_backward_without_masks_and_ragged_lengths(built_lib)
+
+
+def test_tail_event_plan_replays_the_learning_call(built_lib, monkeypatch):
+    """Cross-stream forks / joins wait for a stop event that rides on the producing stream's last launch (common.h, layout.hip).
+    Which launches carry one is LEARNED: the first call of a kind / shape puts an event on every launch, later calls only on the
+    launches a fork / join / gradient segment consumed.  Same inputs, TACO_DETERMINISTIC=1 (fixed summation orders, so a race
+    would show as a changed bit): the learning call, three planned calls, a call on recorded markers (TACO_TAIL_EVENTS=0), a call
+    that mispredicts (a switch that changes the launch sequence flips between calls: that call falls back to markers, the next
+    one learns again) -- outputs, loss and every gradient bit-identical; inference likewise."""
+    monkeypatch.setenv('TACO_DETERMINISTIC', '1')
+    B, Tt, Td, r, V = 6, 70, 24, 2, 40
+    p = on.init_params(V, r, seed=5, perturb=0.3)
+    inp, masks = _full_case(B, Tt, Td, r, V, seed_masks=3)
+    R = Runner(built_lib, B, Tt, Td, r, V)
+    R.set(p, inp, masks)
+
+    def run():
+        R.forward()
+        R.backward()
+        torch.cuda.synchronize()
+        R.check_err()
+        return (R.s2s.cpu().numpy().copy(), R.out.cpu().numpy().copy(), R.al.cpu().numpy().copy(), R.loss.cpu().numpy().copy(),
+                R.grads.cpu().numpy().copy())
+
+    ref = run()                       # learning call (an event on every launch)
+    runs = [run() for _ in range(3)]  # planned calls
+    monkeypatch.setenv('TACO_TAIL_EVENTS', '0')
+    runs.append(run())                # recorded markers
+    monkeypatch.delenv('TACO_TAIL_EVENTS')
+    runs.append(run())                # (the plan survives a call that did not use it)
+    monkeypatch.setenv('TACO_NO_PRENET_FUSE', '1')   # two launches where the plan expects one: mispredicted forks fall back
+    alt = run()
+    monkeypatch.delenv('TACO_NO_PRENET_FUSE')
+    runs.append(run())                # learns again
+    runs.append(run())                # planned again
+    for i, got in enumerate(runs):
+        for a, b, name in zip(got, ref, ('s2s', 'out', 'align', 'loss', 'grads')):
+            assert np.array_equal(a, b), 'run %d: %s differs from the learning call' % (i, name)
+    assert np.abs(alt[4].astype(np.float64) - ref[4]).max() <= 1e-4 * np.abs(ref[4]).max()   # (another kernel pair: not bitwise)
+    assert np.isfinite(ref[4]).all() and np.abs(ref[4]).max() > 0
+    Ri = Runner(built_lib, B, Tt, Td, r, V, train=False)
+    Ri.set(p, inp)
+    outs = []
+    for _ in range(3):
+        Ri.infer()
+        torch.cuda.synchronize()
+        outs.append((Ri.out.cpu().numpy().copy(), Ri.al.cpu().numpy().copy()))
+    assert all(np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1]) for o in outs)
 
 
 def _full_case(B, Tt, Td, r, V, seed_masks=0):
