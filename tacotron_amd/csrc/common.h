@@ -127,18 +127,22 @@ static inline bool ensure_dyn_smem(DynSmemOnce& done, const void* func, size_t b
 // the event of the last kernel launched on s (streams are in order), and a fork / join waits for that -- no marker.  Whatever
 // else is enqueued on a stream (memset, event wait) "touches" it: its tail event no longer covers the stream and the next
 // fork falls back to a recorded event.  TACO_TAIL_EVENTS=0: recorded events everywhere (A/B runs).
-hipEvent_t taco_tail_take(hipStream_t s);      // the event the NEXT launch on s carries (nullptr: tracking is off)
-hipEvent_t taco_tail_event(hipStream_t s);     // the event of the LAST launch on s if it still covers the stream, else nullptr
-hipEvent_t taco_tail_steal(hipStream_t s, hipEvent_t give);   // tail event taken OUT of the ring (caller owns it; `give` refills the slot), or nullptr
+hipEvent_t taco_tail_take(hipStream_t s, hipEvent_t* start);   // the stop event the NEXT launch on s carries (nullptr: none) and, for a launch bracketed by the profiling ring, its start event
+hipEvent_t taco_tail_event(hipStream_t s, hipStream_t for_stream);   // the event of the LAST launch on s if it covers everything `for_stream` has to wait for, else nullptr
+hipEvent_t taco_tail_steal(hipStream_t s, hipEvent_t give, bool* owned);   // tail event for a longer-lived use: taken OUT of the ring (*owned; `give` refills the slot) or an alias of an event the ring does not own; nullptr: none
 void taco_tail_touch(hipStream_t s);           // something that is not a library launch was enqueued on s
 void taco_tail_open(uint64_t key);              // opens the scope of one C-ABI call; key = kind + shape of the call (its launch plan, layout.hip)
 void taco_tail_close();
 bool taco_tail_wait(hipStream_t waiter, hipStream_t producer);   // waiter waits for producer's tail event; false: caller records an event
+// profiling ring (model.hip): inside a scope a bracket's start / stop events ride on the bracketed launch itself instead of two markers
+bool taco_tail_arm_timing(hipStream_t s, hipEvent_t start, hipEvent_t stop);   // false: no scope, the caller records `start`
+int taco_tail_disarm_timing(hipStream_t s);    // launches on s since the arm (1: the pair rode on that launch; else the caller records what is missing)
 
 #define TACO_KLAUNCH(kernel, grid, block, smem, stream, ...)                                                        \
   do {                                                                                                              \
-    hipEvent_t tev__ = taco_tail_take(stream);                                                                      \
-    if (tev__) hipExtLaunchKernelGGL(kernel, grid, block, smem, stream, nullptr, tev__, 0, __VA_ARGS__);            \
+    hipEvent_t tst__ = nullptr;                                                                                     \
+    hipEvent_t tev__ = taco_tail_take(stream, &tst__);                                                              \
+    if (tev__) hipExtLaunchKernelGGL(kernel, grid, block, smem, stream, tst__, tev__, 0, __VA_ARGS__);              \
     else hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);                                        \
   } while (0)
 

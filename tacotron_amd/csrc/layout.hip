@@ -17,16 +17,22 @@ extern "C" const char* taco_last_error_string(void) { return g_err; }
 // ---- tail events (common.h) ----
 namespace {
 constexpr int kTailRing = 64, kTailStreams = 8, kPlanWords = 8, kPlans = 8;   // (a plan covers 64 * kPlanWords launches per stream)
+hipStream_t const kDepMany = reinterpret_cast<hipStream_t>(~(uintptr_t)0);
 struct TailTrack {
   bool used = false;
   hipStream_t s = nullptr;
   hipEvent_t ring[kTailRing] = {};
   int next = 0;
-  int tail_slot = -1;          // ring slot that still owns `tail` (-1: stolen, or no tail)
-  hipEvent_t tail = nullptr;   // rides on the last launch on s; nullptr once anything else was enqueued behind it
+  int tail_slot = -1;          // ring slot that still owns `tail` (-1: stolen, not a ring event, or no tail)
+  hipEvent_t tail = nullptr;   // rides on the last launch on s; nullptr once anything it does not cover was enqueued behind it
+  bool has_dep = false;        // behind the last launch s was made to wait for events of stream `dep` (kDepMany: of several streams):
+  hipStream_t dep = nullptr;   //   `tail` then still covers everything a fork TO `dep` has to wait for (dep's own order covers the rest)
   int launches = 0;            // launches on s in this scope
   int tail_idx = -1;           // launch index of `tail`
   bool declined = false;       // the last launch on s carried no event because the plan did not ask for one
+  bool armed = false;          // profiling bracket: the next launch carries these two events
+  hipEvent_t arm_start = nullptr, arm_stop = nullptr;
+  int arm_launches = 0;
 };
 // Which launches of a call need an event is learned, not declared: the first call of a kind / shape puts an event on EVERY launch
 // and notes the (stream, launch index) pairs a fork, join or segment actually consumed; later calls put events on those only
@@ -59,17 +65,35 @@ void tail_consumed(TailTrack* t) {
   if (g_learning && g_plan && t->tail_idx >= 0 && t->tail_idx < 64 * kPlanWords)
     g_plan->bits[t - g_tail][t->tail_idx >> 6] |= 1ull << (t->tail_idx & 63);
 }
+void tail_drop(TailTrack* t) {
+  t->tail = nullptr;
+  t->tail_slot = -1;
+  t->has_dep = false;
+  t->dep = nullptr;
+}
 }  // namespace
 
-hipEvent_t taco_tail_take(hipStream_t s) {
+hipEvent_t taco_tail_take(hipStream_t s, hipEvent_t* start) {
+  *start = nullptr;
   if (!g_tail_on) return nullptr;
   TailTrack* t = tail_find(s, true);
   if (!t) return nullptr;   // (more streams than the table holds: those launch plainly and fork through recorded events)
   const int idx = t->launches++;
+  ++t->arm_launches;
+  t->has_dep = false;       // (this launch is ordered behind every wait enqueued so far: its event covers them)
+  t->dep = nullptr;
+  if (t->armed) {           // a profiling bracket's pair: timing events the ring does not own
+    t->armed = false;
+    *start = t->arm_start;
+    t->tail = t->arm_stop;
+    t->tail_slot = -1;
+    t->tail_idx = idx;
+    t->declined = false;
+    return t->tail;
+  }
   const bool want = g_learning || (g_plan && idx < 64 * kPlanWords && ((g_plan->bits[t - g_tail][idx >> 6] >> (idx & 63)) & 1));
   if (!want) {
-    t->tail = nullptr;
-    t->tail_slot = -1;
+    tail_drop(t);
     t->declined = true;
     return nullptr;
   }
@@ -78,8 +102,7 @@ hipEvent_t taco_tail_take(hipStream_t s) {
   t->declined = false;
   if (!t->ring[slot] && hipEventCreateWithFlags(&t->ring[slot], hipEventDisableTiming) != hipSuccess) {
     t->ring[slot] = nullptr;
-    t->tail = nullptr;
-    t->tail_slot = -1;
+    tail_drop(t);
     return nullptr;
   }
   t->tail = t->ring[slot];
@@ -87,28 +110,31 @@ hipEvent_t taco_tail_take(hipStream_t s) {
   t->tail_idx = idx;
   return t->tail;
 }
-hipEvent_t taco_tail_event(hipStream_t s) {
+hipEvent_t taco_tail_event(hipStream_t s, hipStream_t for_stream) {
   if (!g_tail_on) return nullptr;
   TailTrack* t = tail_find(s, false);
   if (!t) return nullptr;
+  if (t->tail && t->has_dep && (t->dep == kDepMany || t->dep != for_stream)) return nullptr;   // (waits behind the launch that `for_stream` does not inherit by its own order)
   if (t->tail) tail_consumed(t);
   else if (t->declined && g_plan && !g_learning) g_plan->learned = false;   // (mispredicted: this call falls back, the next one learns)
   return t->tail;
 }
-hipEvent_t taco_tail_steal(hipStream_t s, hipEvent_t give) {
-  hipEvent_t e = taco_tail_event(s);
+hipEvent_t taco_tail_steal(hipStream_t s, hipEvent_t give, bool* owned) {
+  *owned = false;
+  hipEvent_t e = taco_tail_event(s, nullptr);
   if (!e) return nullptr;
   TailTrack* t = tail_find(s, false);
-  if (t->tail_slot < 0 || t->ring[t->tail_slot] != e) return nullptr;   // (already stolen: the caller records its own event)
-  t->ring[t->tail_slot] = give;   // (an event lives in exactly one place: a ring slot or its new owner)
-  t->tail_slot = -1;
-  return e;
+  if (t->tail_slot >= 0 && t->ring[t->tail_slot] == e) {
+    t->ring[t->tail_slot] = give;   // (an event lives in exactly one place: a ring slot or its new owner)
+    t->tail_slot = -1;
+    *owned = true;
+  }
+  return e;   // (not owned: a profiling bracket's stop event, or one that was stolen before -- whoever waits for it does so before it is bound again)
 }
 void taco_tail_touch(hipStream_t s) {
   TailTrack* t = tail_find(s, false);
   if (t) {
-    t->tail = nullptr;
-    t->tail_slot = -1;
+    tail_drop(t);
     t->declined = false;
   }
 }
@@ -118,11 +144,11 @@ void taco_tail_open(uint64_t key) {
   g_plan = nullptr;
   g_learning = false;
   for (TailTrack& t : g_tail) {
-    t.tail = nullptr;
-    t.tail_slot = -1;
+    tail_drop(&t);
     t.launches = 0;
     t.tail_idx = -1;
     t.declined = false;
+    t.armed = false;
   }
   if (!g_tail_on) return;
   for (TailPlan& p : g_plans)
@@ -146,19 +172,43 @@ void taco_tail_close() {
   g_learning = false;
   g_plan = nullptr;
   for (TailTrack& t : g_tail) {
-    t.tail = nullptr;
-    t.tail_slot = -1;
+    tail_drop(&t);
+    t.armed = false;
   }
 }
 bool taco_tail_wait(hipStream_t waiter, hipStream_t producer) {
-  hipEvent_t e = taco_tail_event(producer);
+  hipEvent_t e = taco_tail_event(producer, waiter);
   if (!e) return false;
   if (hipStreamWaitEvent(waiter, e, 0) != hipSuccess) {
     (void)hipGetLastError();
     return false;
   }
-  taco_tail_touch(waiter);   // (the wait itself is not covered by the waiter's last launch)
+  // the wait itself is not covered by the waiter's last launch -- except for a fork back TO the producer, whose own order covers it
+  if (TailTrack* w = tail_find(waiter, false)) {
+    if (!w->has_dep) {
+      w->has_dep = true;
+      w->dep = producer;
+    } else if (w->dep != producer) {
+      w->dep = kDepMany;
+    }
+  }
   return true;
+}
+bool taco_tail_arm_timing(hipStream_t s, hipEvent_t start, hipEvent_t stop) {
+  if (!g_tail_on) return false;
+  TailTrack* t = tail_find(s, true);
+  if (!t) return false;
+  t->armed = true;
+  t->arm_start = start;
+  t->arm_stop = stop;
+  t->arm_launches = 0;
+  return true;
+}
+int taco_tail_disarm_timing(hipStream_t s) {
+  TailTrack* t = tail_find(s, false);
+  if (!t) return 0;
+  t->armed = false;
+  return t->arm_launches;
 }
 
 extern "C" int taco_version(void) { return TACO_VERSION; }

@@ -47,6 +47,7 @@ struct ProfRing {
   static constexpr int kCap = 4096;
   hipEvent_t start[kCap], stop[kCap];
   double flops[kCap];
+  bool armed[kCap];       // the pair rides on the bracketed launch (tail events, common.h) instead of being recorded as two markers
   char label[kCap][96];   // what the launch was (taco_prof_label; read by taco_debug_profile_labels before taco_profile_read2)
   int created = 0;   // events created so far (lazily, in steps: creating 2 x 4096 events up front costs milliseconds)
   int n = 0;
@@ -64,7 +65,10 @@ int taco_prof_begin(int which, hipStream_t s) {
     if (hipEventCreate(&r.start[r.created]) != hipSuccess || hipEventCreate(&r.stop[r.created]) != hipSuccess) return -1;
     ++r.created;
   }
-  (void)hipEventRecord(r.start[r.n], s);
+  // inside a tail-event scope (common.h) the pair rides on the bracketed launch itself -- two marker packets around the decoder
+  // kernels were ~20 us of the timed step; outside (op-level calls, capture) the bracket is two recorded markers as before
+  r.armed[r.n] = taco_tail_arm_timing(s, r.start[r.n], r.stop[r.n]);
+  if (!r.armed[r.n]) (void)hipEventRecord(r.start[r.n], s);
   r.label[r.n][0] = 0;
   return r.n;
 }
@@ -78,7 +82,16 @@ void taco_prof_label(int which, int slot, const char* fmt, ...) {
 void taco_prof_end(int which, int slot, hipStream_t s, double flops) {
   if (slot < 0) return;
   ProfRing& r = g_prof[which];
-  (void)hipEventRecord(r.stop[slot], s);
+  if (!r.armed[slot]) {
+    (void)hipEventRecord(r.stop[slot], s);
+  } else {
+    // the pair was armed for the next launch on s.  One launch since: it carried both events.  Several (a k-split pair, the decoder
+    // in chunks of 32 rows): the first one carried both -- `stop` is recorded again behind the last, which is what counts.  None:
+    // both are recorded now.
+    const int rode = taco_tail_disarm_timing(s);
+    if (rode == 0) (void)hipEventRecord(r.start[slot], s);
+    if (rode != 1) (void)hipEventRecord(r.stop[slot], s);
+  }
   r.flops[slot] = flops;
   r.n = slot + 1;
 }
@@ -316,6 +329,7 @@ struct SideStream {
   // segment [4] post-net, [3] decoder, [2] encoder projections / highways / bi-GRU, [1] encoder conv bank, [0] embedding + encoder
   // pre_net of the flat gradient buffer is final
   hipEvent_t ev_seg[kGradSegments] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_seg_use[kGradSegments] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // what taco_wait_grad_segment waits for: ev_seg or a tail event (common.h)
   bool seg_recorded = false;
 };
 SideStream& side_stream() {
@@ -342,11 +356,16 @@ int record_segment(int seg, hipStream_t on) {
   }
   // (tail events, common.h: the segment's event is the one riding on the last launch on `on` -- taken out of that stream's ring,
   //  this segment's previous event refills the slot -- instead of a marker behind it)
-  if (hipEvent_t t = taco_tail_steal(on, x.ev_seg[seg])) {
-    x.ev_seg[seg] = t;
-  } else if (hipEventRecord(x.ev_seg[seg], on) != hipSuccess) {
-    taco_set_error("taco_backward: hipEventRecord(segment %d) failed", seg);
-    return TACO_ELAUNCH;
+  bool owned = false;
+  if (hipEvent_t t = taco_tail_steal(on, x.ev_seg[seg], &owned)) {
+    if (owned) x.ev_seg[seg] = t;
+    x.ev_seg_use[seg] = t;   // (not owned: the stop event of a profiling bracket -- taco_wait_grad_segment waits for it before it is bound again)
+  } else {
+    if (hipEventRecord(x.ev_seg[seg], on) != hipSuccess) {
+      taco_set_error("taco_backward: hipEventRecord(segment %d) failed", seg);
+      return TACO_ELAUNCH;
+    }
+    x.ev_seg_use[seg] = x.ev_seg[seg];
   }
   if (seg == 0) x.seg_recorded = true;
   return TACO_OK;
@@ -519,7 +538,7 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
     SideStream& x = side_stream();
     // (tail events: the image launch's own event.  Its ring slot comes round again after 64 more launches on the side stream --
     //  far more than are enqueued before the wait below -- and would then name a LATER launch of the same stream: still correct)
-    img_ev = taco_tail_event(sd);
+    img_ev = taco_tail_event(sd, s);
     if (img_ev) {
       img_event = true;
     } else {
@@ -1545,8 +1564,8 @@ extern "C" int taco_grad_segments(const TacoShape* shape, int64_t* bounds) {
 extern "C" int taco_wait_grad_segment(int seg, void* stream) {
   TACO_REQUIRE(seg >= 0 && seg < kGradSegments, "taco_wait_grad_segment: segment %d out of range", seg);
   SideStream& x = side_stream();
-  TACO_REQUIRE(x.seg_recorded && x.ev_seg[seg], "taco_wait_grad_segment: no taco_backward was issued by this thread on this device");
-  if (hipStreamWaitEvent(as_stream(stream), x.ev_seg[seg], 0) != hipSuccess) {
+  TACO_REQUIRE(x.seg_recorded && x.ev_seg_use[seg], "taco_wait_grad_segment: no taco_backward was issued by this thread on this device");
+  if (hipStreamWaitEvent(as_stream(stream), x.ev_seg_use[seg], 0) != hipSuccess) {
     taco_set_error("taco_wait_grad_segment: hipStreamWaitEvent failed");
     return TACO_ELAUNCH;
   }
