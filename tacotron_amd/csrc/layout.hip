@@ -30,6 +30,8 @@ struct TailTrack {
   int launches = 0;            // launches on s in this scope
   int tail_idx = -1;           // launch index of `tail`
   bool declined = false;       // the last launch on s carried no event because the plan did not ask for one
+  int dev = 0;                 // device the ring's events belong to
+  uint64_t stamp = 0;          // last use (least-recently-used take-over when a caller keeps handing in new streams)
   bool armed = false;          // profiling bracket: the next launch carries these two events
   hipEvent_t arm_start = nullptr, arm_stop = nullptr;
   int arm_launches = 0;
@@ -49,17 +51,38 @@ thread_local TailPlan g_plans[kPlans];
 thread_local TailPlan* g_plan = nullptr;
 thread_local int g_plan_next = 0;
 thread_local bool g_tail_on = false, g_learning = false;
+thread_local uint64_t g_tail_clock = 0;
+void tail_drop(TailTrack* t);
 TailTrack* tail_find(hipStream_t s, bool create) {
   for (TailTrack& t : g_tail)
-    if (t.used && t.s == s) return &t;
-  if (create)
-    for (TailTrack& t : g_tail)
-      if (!t.used) {
-        t.used = true;
-        t.s = s;
-        return &t;
-      }
-  return nullptr;
+    if (t.used && t.s == s) {
+      t.stamp = ++g_tail_clock;
+      return &t;
+    }
+  if (!create) return nullptr;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  TailTrack* lru = nullptr;
+  for (TailTrack& t : g_tail) {
+    if (!t.used) {
+      t.used = true;
+      t.s = s;
+      t.dev = dev;
+      t.stamp = ++g_tail_clock;
+      return &t;
+    }
+    // a caller that hands in ever new streams: the least recently used entry of the SAME device is taken over (its ring events
+    // are not bound to a stream); entries of streams that launched in this scope are left alone
+    if (t.dev == dev && t.launches == 0 && !t.tail && !t.armed && (!lru || t.stamp < lru->stamp)) lru = &t;
+  }
+  if (lru) {
+    lru->s = s;
+    lru->stamp = ++g_tail_clock;
+    tail_drop(lru);
+    lru->tail_idx = -1;
+    lru->declined = false;
+  }
+  return lru;
 }
 void tail_consumed(TailTrack* t) {
   if (g_learning && g_plan && t->tail_idx >= 0 && t->tail_idx < 64 * kPlanWords)

@@ -578,6 +578,15 @@ def test_tail_event_plan_replays_the_learning_call(built_lib, monkeypatch):
         torch.cuda.synchronize()
         outs.append((Ri.out.cpu().numpy().copy(), Ri.al.cpu().numpy().copy()))
     assert all(np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1]) for o in outs)
+    # a caller that hands in ever new streams (more than the per-thread stream table holds): entries are taken over, results unchanged
+    streams = [torch.cuda.Stream() for _ in range(12)]
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            for _ in range(2):
+                Ri.infer()
+            torch.cuda.synchronize()
+            assert np.array_equal(Ri.out.cpu().numpy(), outs[0][0]) and np.array_equal(Ri.al.cpu().numpy(), outs[0][1])
 
 
 def _full_case(B, Tt, Td, r, V, seed_masks=0):
