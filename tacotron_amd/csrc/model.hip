@@ -361,7 +361,11 @@ int record_segment(int seg, hipStream_t on) {
     if (owned) x.ev_seg[seg] = t;
     x.ev_seg_use[seg] = t;   // (not owned: the stop event of a profiling bracket -- taco_wait_grad_segment waits for it before it is bound again)
   } else {
-    if (hipEventRecord(x.ev_seg[seg], on) != hipSuccess) {
+    // no tail event to take (`on` waits for side-stream work behind its last launch: the end of the pass): the marker goes to the
+    // SIDE stream, made to wait for `on`'s last launch first -- it covers both streams and sits between no two kernels of `on`
+    hipStream_t at = on;
+    if (x.side && x.side != on && !x.off && taco_tail_wait(x.side, on)) at = x.side;
+    if (hipEventRecord(x.ev_seg[seg], at) != hipSuccess) {
       taco_set_error("taco_backward: hipEventRecord(segment %d) failed", seg);
       return TACO_ELAUNCH;
     }
@@ -507,7 +511,11 @@ struct TailScope {
   bool open = false;
   TailScope(hipStream_t s, int kind, const TacoShape& sh) {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+      (void)hipGetLastError();   // (not this call's failure to report: launches are checked with hipGetLastError)
+      return;
+    }
+    if (st != hipStreamCaptureStatusNone) return;
     uint64_t key = 1469598103934665603ull;   // (FNV-1a over the call's kind and shape)
     const int64_t f[8] = {kind, sh.B, sh.Tt, sh.Td, sh.r, sh.V, sh.S, (int64_t)(uintptr_t)s};
     for (int64_t v : f) key = (key ^ (uint64_t)v) * 1099511628211ull;
