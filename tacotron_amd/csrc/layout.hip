@@ -16,7 +16,7 @@ extern "C" const char* taco_last_error_string(void) { return g_err; }
 
 // ---- tail events (common.h) ----
 namespace {
-constexpr int kTailRing = 64, kTailStreams = 8, kPlanWords = 8, kPlans = 8;   // (a plan covers 64 * kPlanWords launches per stream)
+constexpr int kTailRing = 64, kTailStreams = 8, kPlanWords = 8, kPlans = 32;   // (a plan covers 64 * kPlanWords launches per stream)
 hipStream_t const kDepMany = reinterpret_cast<hipStream_t>(~(uintptr_t)0);
 struct TailTrack {
   bool used = false;

@@ -533,6 +533,9 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
   const ParamLayout& PL = L.P;
   const int B = sh.B, Tt = sh.Tt, Td = sh.Td, r = sh.r, R80 = kMel * r;
   const int M1 = B * Tt, M2 = B * Td * r;
+  // embedding (tacotron.py:111-114) first: the side stream's fork below then waits for THIS launch's stop event (tail events,
+  // common.h) instead of a marker recorded on the caller's stream in front of the call's first kernel
+  TACO_TRY(launch_embedding(P + PL.emb, text, ws + W.emb, M1, sh.V, s));
   // decoder composites depend on the parameters only: side stream, concurrent with the encoder
   hipStream_t sd = side_fork(s);
   // pre-split bf16 plane images of the forward weights (gemm2.hip's B-image form): first thing on the side stream, beside the
@@ -600,8 +603,7 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
       TACO_TRY(launch_conv_gemm(q2, sd));
     }
   }
-  // embedding + encoder pre_net (tacotron.py:111-114, 128)
-  TACO_TRY(launch_embedding(P + PL.emb, text, ws + W.emb, M1, sh.V, s));
+  // encoder pre_net (tacotron.py:128) on the embedding gathered above
   if (!getenv("TACO_NO_PRENET_FUSE")) {   // both layers in one launch (prenet.hip)
     PrenetArgs pa;
     pa.x = ws + W.emb; pa.w1 = P + PL.enc_pre1.w; pa.b1 = P + PL.enc_pre1.b; pa.w2 = P + PL.enc_pre2.w; pa.b2 = P + PL.enc_pre2.b;
