@@ -535,6 +535,7 @@ int forward_impl(const TacoShape& sh, const Layouts& L, const WsLayout& W, const
   const int M1 = B * Tt, M2 = B * Td * r;
   // embedding (tacotron.py:111-114) first: the side stream's fork below then waits for THIS launch's stop event (tail events,
   // common.h) instead of a marker recorded on the caller's stream in front of the call's first kernel
+  // (same box, alternated four times: 7.02-7.13 vs 7.07-7.16 ms per step, profiles/r06_fwd_fork_order_ab.txt)
   TACO_TRY(launch_embedding(P + PL.emb, text, ws + W.emb, M1, sh.V, s));
   // decoder composites depend on the parameters only: side stream, concurrent with the encoder
   hipStream_t sd = side_fork(s);
