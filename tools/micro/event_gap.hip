@@ -56,12 +56,49 @@ static int dependency_check(hipStream_t s1, hipStream_t s2) {
   return bad;
 }
 
+// Is what the producing launch wrote VISIBLE to a launch on another stream that only waited for its stop event (no marker, no
+// system-scope fence)?  The producer fills 64 MB with a per-round pattern from workgroups on every XCD; the consumer -- other
+// workgroup-to-XCD assignment (reversed block order) -- reads it back and counts mismatches; the consumer's own result buffer is
+// then overwritten by the next round's producer on the first stream, ordered the same way in the other direction.
+__global__ void fill_kernel(unsigned* buf, size_t n, unsigned pat) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) buf[i] = pat ^ (unsigned)i;
+}
+__global__ void verify_kernel(const unsigned* buf, size_t n, unsigned pat, unsigned* bad) {
+  unsigned miss = 0;
+  const size_t nb = gridDim.x;
+  for (size_t i = (size_t)(nb - 1 - blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += nb * blockDim.x) miss += buf[i] != (pat ^ (unsigned)i);
+  if (miss) atomicAdd(bad, miss);
+}
+static int visibility_check(hipStream_t s1, hipStream_t s2) {
+  const size_t n = (size_t)16 << 20;   // 64 MB: 16 x the L2 of one XCD
+  unsigned *buf, *bad;
+  if (hipMalloc(&buf, n * 4) != hipSuccess || hipMalloc(&bad, 4) != hipSuccess) return 1;
+  (void)hipMemset(bad, 0, 4);
+  hipEvent_t e1, e2;
+  if (hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess) return 1;
+  (void)hipDeviceSynchronize();
+  const int rounds = 200;
+  for (int r = 0; r < rounds; ++r) {
+    const unsigned pat = 0x9e3779b9u * (unsigned)(r + 1);
+    if (r) (void)hipStreamWaitEvent(s1, e2, 0);   // the producer overwrites only after the previous round's consumer has read
+    hipExtLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, s1, nullptr, e1, 0, buf, n, pat);
+    (void)hipStreamWaitEvent(s2, e1, 0);
+    hipExtLaunchKernelGGL(verify_kernel, dim3(2048), dim3(256), 0, s2, nullptr, e2, 0, (const unsigned*)buf, n, pat, bad);
+  }
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  unsigned h = 1;
+  (void)hipMemcpy(&h, bad, 4, hipMemcpyDeviceToHost);
+  printf("visibility check: %d rounds of 64 MB written on one stream, verified on another behind its stop event: %u stale words\n", rounds, h);
+  return h != 0;
+}
+
 int main() {
   {
     hipStream_t q1, q2;
     CK(hipStreamCreateWithFlags(&q1, hipStreamNonBlocking));
     CK(hipStreamCreateWithFlags(&q2, hipStreamNonBlocking));
     if (dependency_check(q1, q2)) { printf("DEPENDENCY CHECK FAILED\n"); return 2; }
+    if (visibility_check(q1, q2)) { printf("VISIBILITY CHECK FAILED\n"); return 3; }
   }
   const int N = 40, REP = 5;
   hipStream_t A, B;
